@@ -1,0 +1,285 @@
+/*
+ * bitswap_oracle.c -- CPU restatement of the Bit-Swap entropy-coding hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under bitswap_amd/ may import, link or call
+ * this file.  It exists so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg can check / time the HIP path against a plain-C statement of
+ * what the reference (fhkingma/bitswap, pure Python) computes.
+ *
+ * Parity status
+ *   integer half (tables from pmfs, rANS push/pop words): PINNED -- checked
+ *     bit-for-bit against the reference's own ANS class run in-process
+ *     (tests/golden/make_golden.py -> tests/golden/ fixtures, tests/test_oracle.py).
+ *   float half (logistic CDF, float64 sigmoid): parity UNPINNED by any reference
+ *     test; torch.sigmoid(float64) is a third-party routine (PyTorch 1.0.0 pinned in
+ *     the reference README.md:91) whose last bit differs between builds/ISAs.
+ *     mode 0 below restates the reference formula with libm exp() and is checked
+ *     against torch within a few ulp; mode 1 restates the deterministic routine
+ *     the HIP kernels implement (spec: DESIGN.md "Deterministic logistic CDF")
+ *     and is checked bit-for-bit against the GPU.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define ORC_OK 0
+#define ORC_UNDERFLOW 1   /* "too few initial bits": list.pop on an empty stack, mnist_compress.py:66 */
+#define ORC_OVERFLOW 2    /* stack capacity exhausted (the reference list is unbounded)               */
+#define ORC_BAD_TABLE 3   /* cdf[K] != 2^bits, the assert at mnist_compress.py:47                     */
+
+/* ------------------------------------------------------------------------- */
+/* Deterministic sigmoid (mode 1).  IEEE-754 binary64 operations only: sub,    */
+/* mul, min, max, rint (ties-to-even), fma, exact scaling by 2^n, add and a    */
+/* correctly rounded reciprocal.  Identical bits on any conforming machine.    */
+/* ------------------------------------------------------------------------- */
+static const double DET_LOG2E  = 0x1.71547652b82fep+0;
+static const double DET_LN2_HI = 0x1.62e42fee00000p-1;
+static const double DET_LN2_LO = 0x1.a39ef35793c76p-33;
+static const double DET_C[12] = {
+    1.0, 1.0,
+    0x1.0000000000011p-1,  0x1.555555555555ap-3,  0x1.555555554f0ccp-5,
+    0x1.111111110f224p-7,  0x1.6c16c187fc4dep-10, 0x1.a01a01b143bc8p-13,
+    0x1.a01991ab61789p-16, 0x1.71ddf573e8618p-19, 0x1.28b4068ef93d2p-22,
+    0x1.af631e4ea6521p-26,
+};
+
+static double det_pow2(int n) { /* exact 2^n, -1022 <= n <= 1023 */
+    uint64_t b = (uint64_t)(n + 1023) << 52;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+
+double orc_det_sigmoid(double t) {
+    double a = -t;
+    a = fmin(fmax(a, -700.0), 700.0);
+    double kd = rint(a * DET_LOG2E);
+    double r = fma(-kd, DET_LN2_HI, a);
+    r = fma(-kd, DET_LN2_LO, r);
+    double p = DET_C[11];
+    for (int i = 10; i >= 0; --i) p = fma(p, r, DET_C[i]);
+    double e = p * det_pow2((int)kd);
+    return 1.0 / (1.0 + e);
+}
+
+/* reference formula: torch.sigmoid((x - mu) / scale), utils/torch/rand.py:67-68 */
+static double ref_sigmoid(double x, double mu, double scale) {
+    double t = (x - mu) / scale;
+    return 1.0 / (1.0 + exp(-t));
+}
+
+/*
+ * orc_logistic_pmf: CDF at the K-1 interior endpoints + pmf assembly.
+ *   reference: utils/torch/rand.py:67-68 (logistic_cdf) and
+ *              mnist_compress.py:183-185 (adjacent difference, pad with
+ *              cdf[0] and 1 - cdf[-1]).
+ *   endpoints [D,K-1] f64 row-major (row d = zendpoints[zi][d, :]); mu, scale [D].
+ *   mode 0: libm restatement of the reference formula.
+ *   mode 1: the deterministic spec of the HIP kernels:
+ *           rs = 1/scale (correctly rounded), t = (e - mu) * rs, det sigmoid.
+ */
+void orc_logistic_pmf(const double* endpoints, const double* mu, const double* scale,
+                      int64_t D, int K, int mode, double* pmf) {
+    for (int64_t d = 0; d < D; ++d) {
+        const double* e = endpoints + d * (int64_t)(K - 1);
+        double* p = pmf + d * (int64_t)K;
+        double prev = 0.0;
+        double rs = 1.0 / scale[d];
+        for (int j = 0; j < K - 1; ++j) {
+            double c = mode ? orc_det_sigmoid((e[j] - mu[d]) * rs)
+                            : ref_sigmoid(e[j], mu[d], scale[d]);
+            p[j] = (j == 0) ? c : c - prev;
+            prev = c;
+        }
+        p[K - 1] = 1.0 - prev;
+    }
+}
+
+/*
+ * orc_tables: integer pmf/cdf tables, ANS.__init__ (mnist_compress.py:14-47).
+ *   multiplier = 2^bits - 2^quantbits            (:29)
+ *   f = trunc(pmf * multiplier) + 1              (:30,:33; .long() truncates toward zero)
+ *   f[first argmax f] += 2^bits - sum f          (:36; torch.argmax -> first maximal index)
+ *   cdf = [0, inclusive cumsum f]                (:39-40)
+ *   assert cdf[K] == 2^bits                      (:47)
+ * f_out [D,K], cdf_out [D,K+1] as uint32 (every value <= 2^31 for bits = 31).
+ */
+int orc_tables(const double* pmf, int64_t D, int K, int bits, int quantbits,
+               uint32_t* f_out, uint32_t* cdf_out) {
+    const double mult = (double)(((int64_t)1 << bits) - ((int64_t)1 << quantbits));
+    int rc = ORC_OK;
+    int64_t* f = (int64_t*)malloc(sizeof(int64_t) * (size_t)K);
+    for (int64_t d = 0; d < D; ++d) {
+        const double* p = pmf + d * (int64_t)K;
+        int64_t sum = 0, best = INT64_MIN;
+        int arg = 0;
+        for (int j = 0; j < K; ++j) {
+            f[j] = (int64_t)(p[j] * mult) + 1;
+            sum += f[j];
+            if (f[j] > best) { best = f[j]; arg = j; }
+        }
+        f[arg] += ((int64_t)1 << bits) - sum;
+        int64_t acc = 0;
+        uint32_t* fo = f_out ? f_out + d * (int64_t)K : 0;
+        uint32_t* co = cdf_out + d * (int64_t)(K + 1);
+        co[0] = 0;
+        for (int j = 0; j < K; ++j) {
+            if (fo) fo[j] = (uint32_t)f[j];
+            if (f[j] < 1) rc = ORC_BAD_TABLE;
+            acc += f[j];
+            co[j + 1] = (uint32_t)acc;
+        }
+        if (acc != ((int64_t)1 << bits)) rc = ORC_BAD_TABLE;
+    }
+    free(f);
+    return rc;
+}
+
+/*
+ * orc_push: ANS.encode (mnist_compress.py:49-56).  Symbols are pushed in
+ * order i = 0..D-1.  State = 64-bit head + stack of 32-bit words (the
+ * reference keeps both in one Python list, head last).
+ *   if head >= 2^33 * f: push(head & 0xffffffff); head >>= 32     (:52-54)
+ *   head = (head // f) << bits + head % f + c                      (:55)
+ * cdf rows have stride ld (>= K+1); f = cdf[s+1] - cdf[s].
+ */
+int orc_push(uint64_t* head, uint32_t* stack, int64_t* len, int64_t cap,
+             const uint32_t* cdf, int64_t ld, int64_t D, int bits, const int32_t* sym) {
+    uint64_t h = *head;
+    int64_t n = *len;
+    for (int64_t i = 0; i < D; ++i) {
+        const uint32_t* row = cdf + i * ld;
+        uint64_t c = row[sym[i]];
+        uint64_t f = (uint64_t)row[sym[i] + 1] - c;
+        /* ((lbound >> bits) << 32) * pmf with lbound = 2^32 (:22,:52) */
+        if (h >= ((((uint64_t)1 << 32) >> bits) << 32) * f) {
+            if (n >= cap) { *head = h; *len = n; return ORC_OVERFLOW; }
+            stack[n++] = (uint32_t)(h & 0xffffffffu);
+            h >>= 32;
+        }
+        h = ((h / f) << bits) + (h % f) + c;
+    }
+    *head = h;
+    *len = n;
+    return ORC_OK;
+}
+
+/* same, from per-symbol (f, c) pairs -- the layout the HIP encode-flavour kernel emits */
+int orc_push_fc(uint64_t* head, uint32_t* stack, int64_t* len, int64_t cap,
+                const uint32_t* fs, const uint32_t* cs, int64_t D, int bits) {
+    uint64_t h = *head;
+    int64_t n = *len;
+    for (int64_t i = 0; i < D; ++i) {
+        uint64_t f = fs[i], c = cs[i];
+        if (h >= ((((uint64_t)1 << 32) >> bits) << 32) * f) {
+            if (n >= cap) { *head = h; *len = n; return ORC_OVERFLOW; }
+            stack[n++] = (uint32_t)(h & 0xffffffffu);
+            h >>= 32;
+        }
+        h = ((h / f) << bits) + (h % f) + c;
+    }
+    *head = h;
+    *len = n;
+    return ORC_OK;
+}
+
+/*
+ * orc_pop: ANS.decode (mnist_compress.py:58-68).  Symbols are popped in
+ * order i = D-1..0.
+ *   m = head & (2^bits - 1)                                        (:61)
+ *   s = searchsorted(cdf[i, :-1], m, 'right') - 1                  (:62)
+ *   head = f_s * (head >> bits) + m - c_s                          (:64)
+ *   if head < 2^32: head = head << 32 | stack.pop()                (:65-66)
+ */
+int orc_pop(uint64_t* head, uint32_t* stack, int64_t* len,
+            const uint32_t* cdf, int64_t ld, int64_t D, int K, int bits, int32_t* sym_out) {
+    uint64_t h = *head;
+    int64_t n = *len;
+    const uint64_t mask = ((uint64_t)1 << bits) - 1;
+    for (int64_t i = D - 1; i >= 0; --i) {
+        const uint32_t* row = cdf + i * ld;
+        uint64_t m = h & mask;
+        int lo = 0, hi = K; /* number of entries in row[0..K-1] that are <= m */
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if ((uint64_t)row[mid] <= m) lo = mid + 1; else hi = mid;
+        }
+        int s = lo - 1;
+        sym_out[i] = s;
+        uint64_t c = row[s];
+        uint64_t f = (uint64_t)row[s + 1] - c;
+        h = f * (h >> bits) + m - c;
+        if (h < ((uint64_t)1 << 32)) {
+            if (n <= 0) { *head = h; *len = n; return ORC_UNDERFLOW; }
+            h = (h << 32) | stack[--n];
+        }
+    }
+    *head = h;
+    *len = n;
+    return ORC_OK;
+}
+
+/*
+ * Fused layer operations used by the chain replay and the CPU baseline:
+ * logistic rows -> integer table -> pop / push for ONE chain, one latent
+ * layer, without materialising more than one row.  Same arithmetic as the
+ * three functions above (mnist_compress.py:183-188 / :198-203).
+ */
+static void row_table(const double* e, double mu, double scale, int K, int bits, int quantbits,
+                      int mode, double* p, int64_t* f, uint32_t* c) {
+    double prev = 0.0, rs = 1.0 / scale;
+    for (int j = 0; j < K - 1; ++j) {
+        double v = mode ? orc_det_sigmoid((e[j] - mu) * rs) : ref_sigmoid(e[j], mu, scale);
+        p[j] = (j == 0) ? v : v - prev;
+        prev = v;
+    }
+    p[K - 1] = 1.0 - prev;
+    const double mult = (double)(((int64_t)1 << bits) - ((int64_t)1 << quantbits));
+    int64_t sum = 0, best = INT64_MIN;
+    int arg = 0;
+    for (int j = 0; j < K; ++j) {
+        f[j] = (int64_t)(p[j] * mult) + 1;
+        sum += f[j];
+        if (f[j] > best) { best = f[j]; arg = j; }
+    }
+    f[arg] += ((int64_t)1 << bits) - sum;
+    int64_t acc = 0;
+    c[0] = 0;
+    for (int j = 0; j < K; ++j) { acc += f[j]; c[j + 1] = (uint32_t)acc; }
+}
+
+int orc_layer_pop(uint64_t* head, uint32_t* stack, int64_t* len,
+                  const double* endpoints, const double* mu, const double* scale,
+                  int64_t D, int K, int bits, int quantbits, int mode, int32_t* sym_out) {
+    double* p = (double*)malloc(sizeof(double) * (size_t)K);
+    int64_t* f = (int64_t*)malloc(sizeof(int64_t) * (size_t)K);
+    uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(K + 1));
+    int rc = ORC_OK;
+    for (int64_t i = D - 1; i >= 0 && rc == ORC_OK; --i) {
+        row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, p, f, c);
+        rc = orc_pop(head, stack, len, c, 0, 1, K, bits, sym_out + i);
+    }
+    free(p); free(f); free(c);
+    return rc;
+}
+
+int orc_layer_push(uint64_t* head, uint32_t* stack, int64_t* len, int64_t cap,
+                   const double* endpoints, const double* mu, const double* scale,
+                   int64_t D, int K, int bits, int quantbits, int mode, const int32_t* sym) {
+    double* p = (double*)malloc(sizeof(double) * (size_t)K);
+    int64_t* f = (int64_t*)malloc(sizeof(int64_t) * (size_t)K);
+    uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(K + 1));
+    int rc = ORC_OK;
+    for (int64_t i = 0; i < D && rc == ORC_OK; ++i) {
+        row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, p, f, c);
+        rc = orc_push(head, stack, len, cap, c, 0, 1, bits, sym + i);
+    }
+    free(p); free(f); free(c);
+    return rc;
+}
+
+int orc_version(void) { return 1; }

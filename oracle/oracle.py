@@ -1,0 +1,164 @@
+"""ctypes binding of oracle/bitswap_oracle.c (the C restatement of the reference).
+
+TEST INFRASTRUCTURE ONLY -- see the header of bitswap_oracle.c.  Function names
+mirror the reference: tables = ANS.__init__ (mnist_compress.py:14-47),
+push = ANS.encode (:49-56), pop = ANS.decode (:58-68),
+logistic_pmf = logistic_cdf + pmf assembly (utils/torch/rand.py:67-68,
+mnist_compress.py:183-185).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+OK, UNDERFLOW, OVERFLOW, BAD_TABLE = 0, 1, 2, 3
+MODE_LIBM, MODE_DET = 0, 1
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (idempotent)."""
+    src = os.path.join(_HERE, "bitswap_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        p = C.c_void_p
+        i64, i32 = C.c_int64, C.c_int
+        L.orc_det_sigmoid.restype = C.c_double
+        L.orc_det_sigmoid.argtypes = [C.c_double]
+        L.orc_logistic_pmf.restype = None
+        L.orc_logistic_pmf.argtypes = [p, p, p, i64, i32, i32, p]
+        L.orc_tables.restype = i32
+        L.orc_tables.argtypes = [p, i64, i32, i32, i32, p, p]
+        L.orc_push.restype = i32
+        L.orc_push.argtypes = [p, p, p, i64, p, i64, i64, i32, p]
+        L.orc_push_fc.restype = i32
+        L.orc_push_fc.argtypes = [p, p, p, i64, p, p, i64, i32]
+        L.orc_pop.restype = i32
+        L.orc_pop.argtypes = [p, p, p, p, i64, i64, i32, i32, p]
+        L.orc_layer_pop.restype = i32
+        L.orc_layer_pop.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, p]
+        L.orc_layer_push.restype = i32
+        L.orc_layer_push.argtypes = [p, p, p, i64, p, p, p, i64, i32, i32, i32, i32, p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def det_sigmoid(t):
+    L = lib()
+    t = np.asarray(t, dtype=np.float64)
+    out = np.empty_like(t)
+    flat, o = t.reshape(-1), out.reshape(-1)
+    for i in range(flat.size):
+        o[i] = L.orc_det_sigmoid(float(flat[i]))
+    return out
+
+
+def logistic_pmf(endpoints, mu, scale, mode=MODE_LIBM):
+    """endpoints [D,K-1], mu/scale [D] -> pmf [D,K] float64."""
+    e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
+    D, Km1 = e.shape
+    pmf = np.empty((D, Km1 + 1), dtype=np.float64)
+    lib().orc_logistic_pmf(_ptr(e), _ptr(mu), _ptr(scale), D, Km1 + 1, mode, _ptr(pmf))
+    return pmf
+
+
+def tables(pmf, bits=31, quantbits=8):
+    """pmf [D,K] f64 -> (f [D,K] u32, cdf [D,K+1] u32, rc).  ANS.__init__."""
+    pmf = _f64(pmf)
+    D, K = pmf.shape
+    f = np.empty((D, K), dtype=np.uint32)
+    cdf = np.empty((D, K + 1), dtype=np.uint32)
+    rc = lib().orc_tables(_ptr(pmf), D, K, bits, quantbits, _ptr(f), _ptr(cdf))
+    return f, cdf, rc
+
+
+class Stack:
+    """One rANS state: 64-bit head + stack of 32-bit words (the reference's
+    Python list `state`, head = state[-1], mnist_compress.py:158-159)."""
+
+    def __init__(self, words, cap=None):
+        words = list(words)
+        self.head = np.array([words[-1]], dtype=np.uint64)
+        n = len(words) - 1
+        cap = max(cap or 0, n + 16)
+        self.stack = np.zeros(cap, dtype=np.uint32)
+        self.stack[:n] = np.array(words[:-1], dtype=np.uint64).astype(np.uint32)
+        self.len = np.array([n], dtype=np.int64)
+        self.cap = cap
+
+    def tolist(self):
+        n = int(self.len[0])
+        return [int(w) for w in self.stack[:n]] + [int(self.head[0])]
+
+    def grow(self, extra):
+        if self.len[0] + extra > self.cap:
+            cap = int(self.len[0] + extra) * 2
+            s = np.zeros(cap, dtype=np.uint32)
+            s[: self.cap] = self.stack
+            self.stack, self.cap = s, cap
+
+
+def push(st, cdf, sym, bits=31):
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    sym = np.ascontiguousarray(sym, dtype=np.int32)
+    D = sym.shape[0]
+    st.grow(D)
+    return lib().orc_push(_ptr(st.head), _ptr(st.stack), _ptr(st.len), st.cap,
+                          _ptr(cdf), cdf.shape[1], D, bits, _ptr(sym))
+
+
+def push_fc(st, f, c, bits=31):
+    f = np.ascontiguousarray(f, dtype=np.uint32)
+    c = np.ascontiguousarray(c, dtype=np.uint32)
+    st.grow(f.shape[0])
+    return lib().orc_push_fc(_ptr(st.head), _ptr(st.stack), _ptr(st.len), st.cap,
+                             _ptr(f), _ptr(c), f.shape[0], bits)
+
+
+def pop(st, cdf, bits=31):
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    D, ld = cdf.shape
+    sym = np.empty(D, dtype=np.int32)
+    rc = lib().orc_pop(_ptr(st.head), _ptr(st.stack), _ptr(st.len), _ptr(cdf), ld, D, ld - 1, bits, _ptr(sym))
+    return sym, rc
+
+
+def layer_pop(st, endpoints, mu, scale, bits=31, quantbits=10, mode=MODE_DET):
+    e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
+    D, Km1 = e.shape
+    sym = np.empty(D, dtype=np.int32)
+    rc = lib().orc_layer_pop(_ptr(st.head), _ptr(st.stack), _ptr(st.len), _ptr(e), _ptr(mu), _ptr(scale),
+                             D, Km1 + 1, bits, quantbits, mode, _ptr(sym))
+    return sym, rc
+
+
+def layer_push(st, endpoints, mu, scale, sym, bits=31, quantbits=10, mode=MODE_DET):
+    e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
+    sym = np.ascontiguousarray(sym, dtype=np.int32)
+    D, Km1 = e.shape
+    st.grow(D)
+    return lib().orc_layer_push(_ptr(st.head), _ptr(st.stack), _ptr(st.len), st.cap, _ptr(e), _ptr(mu),
+                                _ptr(scale), D, Km1 + 1, bits, quantbits, mode, _ptr(sym))

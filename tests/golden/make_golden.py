@@ -1,0 +1,421 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REFERENCE code (fhkingma/bitswap) in-process.
+
+Run in the build container only (needs /root/reference; the GPU box has no copy):
+
+    python tests/golden/make_golden.py
+
+The reference ships no tests, golden vectors or checkpoints, so
+the fixtures are outputs of the reference's own classes on seeded synthetic inputs:
+
+  tables.npz      logistic_cdf (utils/torch/rand.py:67-68) + pmf assembly
+                  (mnist_compress.py:183-185) + ANS.__init__ integer tables (:14-47)
+  rans.npz        ANS.decode / ANS.encode (:49-68) word streams on those tables
+  model_*.npz     reference Model.infer(i)/generate(i) outputs (model/mnist_train.py:315-438)
+  chain_*.npz     sender (mnist_compress.py:176-251) and receiver (:284-354) loops replayed
+                  around the imported ANS/Model/logistic_cdf on device "cpu", with every
+                  (mu, scale, symbols, state) captured per coding operation
+  bins.npz        Bins / ImageBins / discretize_kbins outputs (rand.py:78-153,
+                  discretization.py:105-118)
+
+The reference is imported unmodified; torchvision and tensorboardX (absent here) are
+stubbed exactly as SURVEY.md section 8(c) describes.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("BITSWAP_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_missing_modules():
+    tv = types.ModuleType("torchvision")
+    tv.__all__ = []
+    for n in ("datasets", "transforms", "utils"):
+        m = types.ModuleType("torchvision." + n)
+        setattr(tv, n, m)
+        sys.modules["torchvision." + n] = m
+    sys.modules["torchvision"] = tv
+    tb = types.ModuleType("tensorboardX")
+    tb.SummaryWriter = object
+    sys.modules["tensorboardX"] = tb
+
+
+_stub_missing_modules()
+sys.path.insert(0, REF)
+import mnist_compress as ref_mc  # noqa: E402
+from discretization import discretize_kbins  # noqa: E402
+from model.mnist_train import Model as RefModel  # noqa: E402
+from model.imagenetcrop_train import Model as RefCropModel  # noqa: E402
+from utils.torch.rand import Bins, ImageBins, logistic_cdf, logistic_eps, transform  # noqa: E402
+
+ANS = ref_mc.ANS
+F64 = torch.float64
+
+
+def ref_pmfs(endpoints, mu, scale):
+    """mnist_compress.py:183-185 verbatim."""
+    cdfs = logistic_cdf(endpoints.t(), mu, scale).t()
+    pmfs = cdfs[:, 1:] - cdfs[:, :-1]
+    pmfs = torch.cat((cdfs[:, 0].unsqueeze(1), pmfs, 1. - cdfs[:, -1].unsqueeze(1)), dim=1)
+    return cdfs, pmfs
+
+
+def init_state(n=10000):
+    """mnist_compress.py:158-159 (caller seeds numpy)."""
+    state = list(map(int, np.random.randint(low=1 << 16, high=(1 << 32) - 1, size=n, dtype=np.uint32)))
+    state[-1] = state[-1] << 32
+    return state
+
+
+def words(state):
+    """Python-int state list -> uint32 words + (head_lo, head_hi)."""
+    head = state[-1]
+    return np.array(state[:-1] + [head & 0xFFFFFFFF, head >> 32], dtype=np.uint64).astype(np.uint32)
+
+
+# --------------------------------------------------------------------------- tables + rans
+def make_tables_and_rans():
+    rng = np.random.RandomState(1234)
+    out = {}
+    cases = {}
+    # latent op: K = 1024 equal-mass top-layer bins (discretization.py:25-27) and uniform bins
+    D = 24
+    top = Bins(torch.zeros((1, 1, D)), torch.ones((1, 1, D)), 10).endpoints()[0, 0].to(F64)
+    lo = rng.uniform(-9, -3, size=D)
+    hi = rng.uniform(3, 9, size=D)
+    uni = torch.from_numpy(np.stack([np.linspace(a, b, 1025)[1:-1] for a, b in zip(lo, hi)]))
+    mu = torch.from_numpy((rng.randn(D) * 0.7).astype(np.float32)).to(F64)
+    sc = torch.from_numpy(rng.uniform(0.1, 1.0, size=D).astype(np.float32)).to(F64)
+    # edge rows: far-off mean (saturated tails), minimum scale, exact ties at the mode
+    mu[0], sc[0] = 30.0, 0.1
+    mu[1], sc[1] = -30.0, 0.1
+    mu[2], sc[2] = 0.0, 1.0
+    mu[3], sc[3] = 0.0, 0.1
+    cases["ztop"] = (top, mu, sc, 10)
+    cases["zuni"] = (uni, mu.clone(), sc.clone(), 10)
+    # pixel op: K = 256 (rand.py:134-153), quantbits = 8 (mnist_compress.py:203)
+    Dx = 48
+    xe = ImageBins(F64, "cpu", Dx).endpoints()
+    mux = torch.from_numpy(rng.uniform(-1.2, 1.2, size=Dx).astype(np.float32)).to(F64)
+    scx = torch.from_numpy(rng.choice([2. / 255. / 8., 0.02, 0.1, 0.7], size=Dx).astype(np.float32)).to(F64)
+    cases["x"] = (xe, mux, scx, 8)
+
+    np.random.seed(100)
+    for name, (e, m, s, q) in cases.items():
+        cdfs, pmfs = ref_pmfs(e, m, s)
+        a = ANS(pmfs, bits=31, quantbits=q)
+        out[f"{name}_endpoints"] = e.numpy()
+        out[f"{name}_mu"] = m.numpy()
+        out[f"{name}_scale"] = s.numpy()
+        out[f"{name}_quantbits"] = np.int32(q)
+        out[f"{name}_cdf_f64"] = cdfs.numpy()
+        out[f"{name}_pmf_f64"] = pmfs.numpy()
+        out[f"{name}_f"] = a.pmfs.astype(np.uint32)
+        out[f"{name}_cdf"] = a.cdfs.astype(np.uint32)
+        # rANS: pop D symbols, push them back, push fresh symbols
+        st = init_state(200)
+        out[f"{name}_state0"] = words(st)
+        st, sym = a.decode(st)
+        out[f"{name}_pop_sym"] = sym.numpy().astype(np.int32)
+        out[f"{name}_state_after_pop"] = words(st)
+        st = a.encode(st, sym)
+        assert words(st).tolist() == out[f"{name}_state0"].tolist()
+        fresh = torch.from_numpy(rng.randint(0, pmfs.shape[1], size=pmfs.shape[0]))
+        st = a.encode(st, fresh)
+        out[f"{name}_push_sym"] = fresh.numpy().astype(np.int32)
+        out[f"{name}_state_after_push"] = words(st)
+    # a hand-made pmf table with exact ties for the argmax rule (mnist_compress.py:36)
+    tie = np.full((4, 16), 1.0 / 16)
+    tie[1, 3] = tie[1, 9] = 0.2
+    tie[1] /= tie[1].sum()
+    tie[2] = 0.0
+    tie[2, 15] = 1.0
+    tie[3] = np.linspace(1, 16, 16)
+    tie[3] /= tie[3].sum()
+    a = ANS(torch.from_numpy(tie), bits=31, quantbits=4)
+    out["tie_pmf_f64"] = tie
+    out["tie_f"] = a.pmfs.astype(np.uint32)
+    out["tie_cdf"] = a.cdfs.astype(np.uint32)
+    np.savez_compressed(os.path.join(OUT, "tables_rans.npz"), **out)
+    print("tables_rans.npz", {k: v.shape for k, v in out.items() if k.endswith("_f")})
+
+
+# --------------------------------------------------------------------------- bins
+def make_bins():
+    out = {}
+    b = Bins(torch.zeros((1, 1, 8)), torch.ones((1, 1, 8)), 10)
+    out["top_endpoints_q10"] = b.endpoints().numpy()[0, 0, 0]   # identical for every dim
+    out["top_centres_q10"] = b.centres().numpy()[0, 0, 0]
+    b = Bins(torch.zeros((1, 1, 8)), torch.ones((1, 1, 8)), 8)
+    out["top_endpoints_q8"] = b.endpoints().numpy()[0, 0, 0]
+    out["top_centres_q8"] = b.centres().numpy()[0, 0, 0]
+    ib = ImageBins(F64, "cpu", 5)
+    out["x_endpoints"] = ib.endpoints().numpy()[0]
+    out["x_centres"] = ib.centres().numpy()[0]
+    rng = np.random.RandomState(7)
+    samples = rng.randn(500, 2, 4, 4).astype(np.float16).astype(np.float64)  # float64 cast: SURVEY 7(f)
+
+    class M:
+        zdim = (2, 4, 4)
+    e, c = discretize_kbins(M, samples, 6, strategy="uniform")
+    out["kbins_samples"] = samples
+    out["kbins_endpoints_q6"] = e
+    out["kbins_centres_q6"] = c
+    np.savez_compressed(os.path.join(OUT, "bins.npz"), **out)
+    print("bins.npz")
+
+
+# --------------------------------------------------------------------------- model + chains
+def synth_images(rng, n, xs):
+    """Smooth synthetic blocks: 8x8 Gaussian field upsampled + noise."""
+    c, h, w = xs
+    base = rng.randn(n, c, 8, 8).astype(np.float32)
+    up = torch.nn.functional.interpolate(torch.from_numpy(base), size=(h, w), mode="bilinear", align_corners=False)
+    img = 127.5 + 60.0 * up.numpy() + rng.randn(n, c, h, w) * 4.0
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synth_bins(model, nz, zdim_flat, quantbits, images, rng):
+    """discretize() (discretization.py:9-99) with a synthetic 'dataset' and ppb reduced to 2."""
+    K = 1 << quantbits
+    zend = np.zeros((nz, zdim_flat, K - 1))
+    zcen = np.zeros((nz, zdim_flat, K))
+    zb = Bins(torch.zeros((1, 1, zdim_flat)), torch.ones((1, 1, zdim_flat)), quantbits)
+    zend[nz - 1] = zb.endpoints().numpy()
+    zcen[nz - 1] = zb.centres().numpy()
+    nsamples = 2 * K
+    bs = 128
+    batches = nsamples // bs
+    data = torch.from_numpy(images[rng.randint(0, len(images), size=nsamples)]).float()
+    gen = np.zeros((nz, nsamples) + model.zdim, dtype=np.float16)
+    gen[-1] = logistic_eps((nsamples,) + model.zdim, device="cpu", bound=1e-30).numpy()
+    inf = np.zeros((nz, nsamples) + model.zdim, dtype=np.float16)
+    with torch.no_grad():
+        for zi in reversed(range(1, nz)):
+            for bi in range(batches):
+                mu, scale = model.generate(zi)(given=torch.from_numpy(gen[zi][bi * bs: bi * bs + bs]).float())
+                gen[zi - 1][bi * bs: bi * bs + bs] = transform(logistic_eps(mu.shape, device="cpu", bound=1e-30), mu, scale)
+            for bi in range(batches):
+                given = (data[bi * bs: bi * bs + bs] if nz - zi - 1 == 0
+                         else torch.from_numpy(inf[nz - zi - 2][bi * bs: bi * bs + bs]).float())
+                mu, scale = model.infer(nz - zi - 1)(given=given)
+                inf[nz - zi - 1][bi * bs: bi * bs + bs] = transform(logistic_eps(mu.shape, device="cpu", bound=1e-30), mu, scale).numpy()
+    mins, maxs = [], []
+    for zi in range(nz - 1):
+        samples = np.concatenate([gen[zi], inf[zi]], axis=0).astype(np.float64)
+        zend[zi], zcen[zi] = discretize_kbins(model, samples, quantbits, strategy="uniform")
+        flat = samples.reshape(-1, zdim_flat)
+        mins.append(flat.min(0))
+        maxs.append(flat.max(0))
+        # compact form must regenerate the reference arrays exactly (checked here, relied on by tests)
+        edges = np.stack([np.linspace(a, b, K + 1) for a, b in zip(mins[-1], maxs[-1])])
+        assert np.array_equal(edges[:, 1:-1], zend[zi])
+        assert np.array_equal((edges[:, :-1] + edges[:, 1:]) / 2, zcen[zi])
+    return zend, zcen, np.array(mins), np.array(maxs)
+
+
+def replay_chain(model, zend, zcen, images, nz, bitswap, quantbits, xdim, zdim, cap):
+    """Sender mnist_compress.py:164-263 and receiver :277-358 around the imported ANS/Model."""
+    zendpoints, zcentres = torch.from_numpy(zend), torch.from_numpy(zcen)
+    xbins = ImageBins(F64, "cpu", xdim)
+    xendpoints, xcentres = xbins.endpoints(), xbins.centres()
+    zrange, xrange = torch.arange(zdim), torch.arange(xdim)
+    ansbits = 31
+    model.compress()
+    ops = []  # (kind, layer, quantbits, mu, scale, sym, words_after)
+
+    def rec(kind, table, q, mu, scale, sym, state):
+        ops.append(dict(kind=kind, table=table, q=q, mu=mu.numpy().astype(np.float32), scale=scale.numpy().astype(np.float32),
+                        sym=np.asarray(sym, dtype=np.int32), nwords=len(state), head=state[-1]))
+
+    np.random.seed(100)
+    state = init_state(10000)
+    initialstate = state.copy()
+    restbits = None
+    datapoints = [torch.from_numpy(im.astype(np.float32)).view(xdim) for im in images]
+    nets, cma = [], []
+    with torch.no_grad():
+        for xi, x in enumerate(datapoints):
+            if bitswap:
+                for zi in range(nz):
+                    input = zcentres[zi - 1, zrange, zsym] if zi > 0 else xcentres[xrange, x.long()]
+                    mu, scale = model.infer(zi)(given=input)
+                    _, pmfs = ref_pmfs(zendpoints[zi], mu, scale)
+                    state, zsymtop = ANS(pmfs, bits=ansbits, quantbits=quantbits).decode(state)
+                    rec(0, zi, quantbits, mu, scale, zsymtop, state)
+                    if xi == zi == 0:
+                        restbits = state.copy()
+                        assert len(restbits) > 1
+                    z = zcentres[zi, zrange, zsymtop]
+                    mu, scale = model.generate(zi)(given=z)
+                    _, pmfs = ref_pmfs(zendpoints[zi - 1] if zi > 0 else xendpoints, mu, scale)
+                    sym = zsym if zi > 0 else x.long()
+                    state = ANS(pmfs, bits=ansbits, quantbits=(quantbits if zi > 0 else 8)).encode(state, sym)
+                    rec(1, zi - 1, quantbits if zi > 0 else 8, mu, scale, sym, state)
+                    zsym = zsymtop
+            else:
+                zs = []
+                for zi in range(nz):
+                    input = zcentres[zi - 1, zrange, zsym] if zi > 0 else xcentres[xrange, x.long()]
+                    mu, scale = model.infer(zi)(given=input)
+                    _, pmfs = ref_pmfs(zendpoints[zi], mu, scale)
+                    state, zsymtop = ANS(pmfs, bits=ansbits, quantbits=quantbits).decode(state)
+                    rec(0, zi, quantbits, mu, scale, zsymtop, state)
+                    zs.append(zsymtop)
+                    zsym = zsymtop
+                if xi == 0:
+                    restbits = state.copy()
+                    assert len(restbits) > 1
+                for zi in range(nz):
+                    zsymtop = zs.pop(0)
+                    z = zcentres[zi, zrange, zsymtop]
+                    mu, scale = model.generate(zi)(given=z)
+                    _, pmfs = ref_pmfs(zendpoints[zi - 1] if zi > 0 else xendpoints, mu, scale)
+                    sym = zsym if zi > 0 else x.long()
+                    state = ANS(pmfs, bits=ansbits, quantbits=(quantbits if zi > 0 else 8)).encode(state, sym)
+                    rec(1, zi - 1, quantbits if zi > 0 else 8, mu, scale, sym, state)
+                    zsym = zsymtop
+                assert zs == []
+            _, pmfs = ref_pmfs(zendpoints[-1], torch.zeros(1, dtype=F64), torch.ones(1, dtype=F64))
+            state = ANS(pmfs, bits=ansbits, quantbits=quantbits).encode(state, zsymtop)
+            rec(1, nz - 1, quantbits, torch.zeros(zdim), torch.ones(zdim), zsymtop, state)
+            totaladdedbits = (len(state) - len(initialstate)) * 32
+            totalbits = (len(state) - (len(restbits) - 1)) * 32
+            nets.append((totaladdedbits / xdim) - sum(nets))
+            cma.append(totalbits / (xdim * (xi + 1)))
+        sent = state.copy()
+
+        # receiver (:277-358), decoded images and state unwinding asserted as the reference does
+        for xi, x in enumerate(reversed(datapoints)):
+            _, pmfs = ref_pmfs(zendpoints[-1], torch.zeros(1, dtype=F64), torch.ones(1, dtype=F64))
+            state, zsymtop = ANS(pmfs, bits=ansbits, quantbits=quantbits).decode(state)
+            if bitswap:
+                for zi in reversed(range(nz)):
+                    z = zcentres[zi, zrange, zsymtop]
+                    mu, scale = model.generate(zi)(given=z)
+                    _, pmfs = ref_pmfs(zendpoints[zi - 1] if zi > 0 else xendpoints, mu, scale)
+                    state, sym = ANS(pmfs, bits=ansbits, quantbits=quantbits if zi > 0 else 8).decode(state)
+                    input = zcentres[zi - 1, zrange, sym] if zi > 0 else xcentres[xrange, sym]
+                    mu, scale = model.infer(zi)(given=input)
+                    _, pmfs = ref_pmfs(zendpoints[zi], mu, scale)
+                    state = ANS(pmfs, bits=ansbits, quantbits=quantbits).encode(state, zsymtop)
+                    zsymtop = sym
+                assert torch.all(x.long() == zsymtop)
+            else:
+                zs = [zsymtop]
+                for zi in reversed(range(nz)):
+                    z = zcentres[zi, zrange, zsymtop]
+                    mu, scale = model.generate(zi)(given=z)
+                    _, pmfs = ref_pmfs(zendpoints[zi - 1] if zi > 0 else xendpoints, mu, scale)
+                    state, sym = ANS(pmfs, bits=ansbits, quantbits=quantbits if zi > 0 else 8).decode(state)
+                    zs.append(sym)
+                    zsymtop = sym
+                zsymtop = zs.pop(0)
+                for zi in reversed(range(nz)):
+                    sym = zs.pop(0) if zi > 0 else zs[0]
+                    input = zcentres[zi - 1, zrange, sym] if zi > 0 else xcentres[xrange, sym]
+                    mu, scale = model.infer(zi)(given=input)
+                    _, pmfs = ref_pmfs(zendpoints[zi], mu, scale)
+                    state = ANS(pmfs, bits=ansbits, quantbits=quantbits).encode(state, zsymtop)
+                    zsymtop = sym
+                assert torch.all(x.long() == zs[0])
+        assert initialstate == state
+    return ops, sent, restbits, nets, cma
+
+
+def make_model_and_chains():
+    torch.manual_seed(50)
+    rng = np.random.RandomState(11)
+    # MNIST-shaped (zchannels=1, xs=(1,32,32)) with a narrow ResNet so the fixture stays small
+    nz, quantbits = 2, 10
+    xs, zch = (1, 32, 32), 1
+    model = RefModel(xs=xs, nz=nz, zchannels=zch, nprocessing=1, kernel_size=3, resdepth=2, reswidth=12,
+                     root_process=False)
+    # perturb the data-independent init so layers are not degenerate (gain 0 / bias 0 everywhere)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(".b") or n.endswith("gen_std"):
+                p.add_(torch.randn_like(p) * 0.3)
+            if n.endswith(".gain"):
+                p.add_(torch.randn_like(p) * 0.2)
+    model.eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    xdim, zdim = int(np.prod(xs)), zch * 16 * 16
+    images = synth_images(rng, 64, xs)
+    zend, zcen, mins, maxs = synth_bins(model, nz, zdim, quantbits, images, rng)
+
+    # model outputs (batched, non-compress mode is what the new framework's Model must reproduce)
+    out = {"sd_" + k: v for k, v in sd.items()}
+    out["cfg"] = np.array([xs[0], nz, zch, 1, 3, 2, 12], dtype=np.int64)
+    with torch.no_grad():
+        x = torch.from_numpy(images[:5].astype(np.float32))
+        model.compress(False)
+        mu, sc = model.infer(0)(given=x)
+        out["infer0_in"], out["infer0_mu"], out["infer0_scale"] = images[:5], mu.numpy(), sc.numpy()
+        z = torch.randn(5, *model.zdim)
+        out["z_in"] = z.numpy()
+        for i in range(nz):
+            mu, sc = model.generate(i)(given=z)
+            out[f"gen{i}_mu"], out[f"gen{i}_scale"] = mu.numpy(), np.broadcast_to(sc.numpy(), mu.shape).copy()
+            if i > 0:
+                mu, sc = model.infer(i)(given=z)
+                out[f"infer{i}_mu"], out[f"infer{i}_scale"] = mu.numpy(), sc.numpy()
+    np.savez_compressed(os.path.join(OUT, "model_mnist_small.npz"), **out)
+    print("model_mnist_small.npz")
+
+    nblocks = 3
+    for bitswap in (1, 0):
+        ops, sent, restbits, nets, cma = replay_chain(model, zend, zcen, images[:nblocks], nz, bitswap, quantbits,
+                                                      xdim, zdim, cap=20000)
+        o = {
+            "cfg": np.array([xs[0], nz, zch, 1, 3, 2, 12, quantbits, bitswap, nblocks], dtype=np.int64),
+            "images": images[:nblocks],
+            "z_top_endpoints": zend[nz - 1][0], "z_top_centres": zcen[nz - 1][0],
+            "z_mins": mins, "z_maxs": maxs,
+            "sent_words": words(sent), "restbits_len": np.int64(len(restbits)),
+            "nets": np.array(nets), "cma": np.array(cma),
+            "op_kind": np.array([p["kind"] for p in ops], dtype=np.int8),
+            "op_table": np.array([p["table"] for p in ops], dtype=np.int8),
+            "op_q": np.array([p["q"] for p in ops], dtype=np.int8),
+            "op_nwords": np.array([p["nwords"] for p in ops], dtype=np.int64),
+            "op_head": np.array([p["head"] for p in ops], dtype=np.uint64),
+        }
+        for i, p in enumerate(ops):
+            o[f"op{i}_mu"], o[f"op{i}_scale"], o[f"op{i}_sym"] = p["mu"], p["scale"], p["sym"].astype(np.int16)
+        name = f"chain_mnist_small_{'bitswap' if bitswap else 'bbans'}.npz"
+        np.savez_compressed(os.path.join(OUT, name), **o)
+        print(name, "ops", len(ops), "words", len(sent), "cma", cma)
+
+    # crop-model variant (gen_std is a conv, imagenetcrop_train.py:306-315,417): outputs only
+    torch.manual_seed(51)
+    cm = RefCropModel(xs=(3, 32, 32), nz=2, zchannels=2, nprocessing=1, kernel_size=3, resdepth=2, reswidth=10,
+                      root_process=False)
+    with torch.no_grad():
+        for n, p in cm.named_parameters():
+            if n.endswith(".b"):
+                p.add_(torch.randn_like(p) * 0.3)
+    cm.eval()
+    out = {"sd_" + k: v.numpy() for k, v in cm.state_dict().items()}
+    out["cfg"] = np.array([3, 2, 2, 1, 3, 2, 10], dtype=np.int64)
+    with torch.no_grad():
+        z = torch.randn(3, *cm.zdim)
+        out["z_in"] = z.numpy()
+        mu, sc = cm.generate(0)(given=z)
+        out["gen0_mu"], out["gen0_scale"] = mu.numpy(), sc.numpy()
+        x = torch.from_numpy(synth_images(rng, 3, (3, 32, 32)).astype(np.float32))
+        out["infer0_in"] = x.numpy().astype(np.uint8)
+        mu, sc = cm.infer(0)(given=x)
+        out["infer0_mu"], out["infer0_scale"] = mu.numpy(), sc.numpy()
+    np.savez_compressed(os.path.join(OUT, "model_crop_small.npz"), **out)
+    print("model_crop_small.npz")
+
+
+if __name__ == "__main__":
+    make_tables_and_rans()
+    make_bins()
+    make_model_and_chains()
