@@ -1,0 +1,721 @@
+// bitswap_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the Bit-Swap / BB-ANS hot path.
+//
+// What runs where (see DESIGN.md for the roofline of each kernel):
+//   k_logistic<NPL,PT,DECODE>  one 64-lane wavefront per (latent dim d, group of chains); the
+//                              K-1 float64 bin endpoints of dim d stay in registers (NPL = K/64
+//                              consecutive bins per lane) and are reused for every chain of the
+//                              group; per chain: NPL deterministic float64 sigmoids per lane,
+//                              adjacent difference, trunc-multiply, wave-wide sum / first-argmax
+//                              (DPP), remnant bump, exclusive scan (DPP) -> integer cdf row
+//                              (decode flavour) or the (f, c) pair of one symbol (encode flavour).
+//   k_table_rows / _generic    the same integer tail for caller-supplied float64 pmf rows
+//                              (bit-exact ANS.__init__).
+//   k_rans_pop<NV>             one wavefront per chain; streams the chain's cdf rows with
+//                              coalesced 16-byte loads (next row prefetched into registers while
+//                              the current one is searched), symbol = popcount of 64-wide ballots;
+//                              the 64-bit head lives in scalar registers.
+//   k_rans_push / _table       one lane per chain, serial 64-bit division per symbol.
+//
+// Reference lines are cited in include/bitswap_hip.h next to each entry point.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bitswap_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// wave64 primitives (DPP: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143)
+// ------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or0(uint32_t v) {
+    // lanes whose source is out of range, or whose row is masked off, read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
+    v += dpp_or0<0x111, 0xf>(v);
+    v += dpp_or0<0x112, 0xf>(v);
+    v += dpp_or0<0x114, 0xf>(v);
+    v += dpp_or0<0x118, 0xf>(v);
+    v += dpp_or0<0x142, 0xa>(v);
+    v += dpp_or0<0x143, 0xc>(v);
+    return v;
+}
+
+// maximum over the 64 lanes, returned in every lane (wave-uniform)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_or0<0x111, 0xf>(v));
+    v = max(v, dpp_or0<0x112, 0xf>(v));
+    v = max(v, dpp_or0<0x114, 0xf>(v));
+    v = max(v, dpp_or0<0x118, 0xf>(v));
+    v = max(v, dpp_or0<0x142, 0xa>(v));
+    v = max(v, dpp_or0<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ double lane_shift_up_f64(double v) {
+    // value of lane-1 (lane 0 receives garbage; caller overrides)
+    return __shfl_up(v, 1, 64);
+}
+
+// ------------------------------------------------------------------------------------------
+// Deterministic float64 sigmoid -- BS_CDF_SPEC 1 (DESIGN.md "Deterministic logistic CDF").
+// IEEE-754 binary64 sub/mul/min/max/rint/fma/ldexp/add + a correctly rounded reciprocal only;
+// compiled with -ffp-contract=off so nothing else is fused.  oracle/bitswap_oracle.c carries
+// an independent C restatement that must agree bit for bit.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double det_sigmoid(double t) {
+    double a = -t;
+    a = fmin(fmax(a, -700.0), 700.0);
+    const double kd = rint(a * 0x1.71547652b82fep+0);
+    double r = fma(-kd, 0x1.62e42fee00000p-1, a);
+    r = fma(-kd, 0x1.a39ef35793c76p-33, r);
+    double p = 0x1.af631e4ea6521p-26;
+    p = fma(p, r, 0x1.28b4068ef93d2p-22);
+    p = fma(p, r, 0x1.71ddf573e8618p-19);
+    p = fma(p, r, 0x1.a01991ab61789p-16);
+    p = fma(p, r, 0x1.a01a01b143bc8p-13);
+    p = fma(p, r, 0x1.6c16c187fc4dep-10);
+    p = fma(p, r, 0x1.111111110f224p-7);
+    p = fma(p, r, 0x1.555555554f0ccp-5);
+    p = fma(p, r, 0x1.555555555555ap-3);
+    p = fma(p, r, 0x1.0000000000011p-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double e = ldexp(p, (int)kd);
+    return 1.0 / (1.0 + e);
+}
+
+// ------------------------------------------------------------------------------------------
+// integer tail shared by the table kernels: f[] (NPL consecutive bins per lane) -> remnant bump
+// on the first maximal bin -> exclusive prefix (returned: the lane's starting cumulative value)
+// ------------------------------------------------------------------------------------------
+template <int NPL>
+__device__ __forceinline__ uint32_t bump_and_scan(uint32_t (&f)[NPL], int lane, int bits, bool& bad) {
+    uint32_t fsum = 0, best = 0;
+    int barg = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        fsum += f[i];
+        if (f[i] > best) { best = f[i]; barg = i; }
+    }
+    const uint32_t incl0 = wave_incl_scan_add(fsum);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+    const uint32_t mx = wave_max_u32(best);
+    const unsigned long long who = __ballot(best == mx);
+    const int first = __ffsll((long long)who) - 1;
+    const uint32_t rem = (1u << bits) - total;  // two's complement: may be "negative"
+    const bool mine = lane == first;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+        if (mine && i == barg) f[i] += rem;
+    bad = mine && ((int32_t)(best + rem) < 1);
+    // exclusive prefix of the bumped per-lane sums: lanes after `first` shift by rem
+    uint32_t excl = incl0 - fsum;
+    if (lane > first) excl += rem;
+    return excl;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_logistic: fused logistic CDF -> integer table, NPL = K/64 bins per lane
+// ------------------------------------------------------------------------------------------
+template <int NPL, typename PT, bool DECODE, bool VEC>
+__global__ __launch_bounds__(256) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
+                                                  const PT* __restrict__ mu, const PT* __restrict__ scale,
+                                                  const int32_t* __restrict__ sym, int B, int D, int bits,
+                                                  int quantbits, int nb, uint32_t* __restrict__ out0,
+                                                  uint32_t* __restrict__ out1, int64_t ld,
+                                                  int32_t* __restrict__ status) {
+    constexpr int K = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (d >= D) return;
+    const int b0 = blockIdx.y * nb;
+    const int b1 = min(B, b0 + nb);
+
+    // this lane's NPL upper bin boundaries (the last bin of lane 63 has none: C = 1)
+    double e[NPL];
+    const double* er = endpoints + (int64_t)d * e_stride + lane * NPL;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) e[i] = (lane * NPL + i < K - 1) ? er[i] : 0.0;
+
+    const double M = (double)((1ll << bits) - (1ll << quantbits));
+    for (int b = b0; b < b1; ++b) {
+        const int64_t row = (int64_t)b * D + d;
+        const double m_ = (double)mu[row];
+        const double rs = 1.0 / (double)scale[row];
+
+        uint32_t f[NPL];
+        double c0 = det_sigmoid((e[0] - m_) * rs);
+        if (NPL == 1 && lane == 63) c0 = 1.0;
+        double prev = c0;
+#pragma unroll
+        for (int i = 1; i < NPL; ++i) {
+            double c = det_sigmoid((e[i] - m_) * rs);
+            if (i == NPL - 1 && lane == 63) c = 1.0;
+            f[i] = (uint32_t)((int32_t)((c - prev) * M) + 1);
+            prev = c;
+        }
+        double below = lane_shift_up_f64(prev);
+        // reference: pmf[0] = cdf[0] (no subtraction), mnist_compress.py:185
+        const double p0 = (lane == 0) ? c0 : c0 - below;
+        f[0] = (uint32_t)((int32_t)(p0 * M) + 1);
+
+        bool bad;
+        uint32_t c = bump_and_scan<NPL>(f, lane, bits, bad);
+
+        if (DECODE) {
+            uint32_t* o = out0 + row * ld + lane * NPL;
+            if (VEC) {
+#pragma unroll
+                for (int i = 0; i < NPL; i += 4) {
+                    uint4 v;
+                    v.x = c; c += f[i];
+                    v.y = c; c += f[i + 1];
+                    v.z = c; c += f[i + 2];
+                    v.w = c; c += f[i + 3];
+                    *reinterpret_cast<uint4*>(o + i) = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) { o[i] = c; c += f[i]; }
+            }
+            if (lane == 63) out0[row * ld + K] = 1u << bits;
+        } else {
+            const int s = sym[row];
+            const bool ok = (s >= 0) && (s < K);
+            if (!ok && lane == 0) status[b] = BS_ST_BADSYMBOL;
+            const int ss = ok ? s : 0;
+            if (lane == ss / NPL) {
+                const int idx = ss % NPL;
+                uint32_t fo = 0, co = 0;
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    if (i == idx) { fo = f[i]; co = c; }
+                    c += f[i];
+                }
+                out0[row] = fo;
+                out1[row] = co;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_table_rows: ANS.__init__ on caller-supplied pmf rows, K = 64*NPL, one wave per row
+// ------------------------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(256) void k_table_rows(const double* __restrict__ pmf, int64_t rows, int bits,
+                                                    int quantbits, uint32_t* __restrict__ f_out,
+                                                    uint32_t* __restrict__ cdf_out, int64_t ld,
+                                                    int32_t* __restrict__ status) {
+    constexpr int K = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const double M = (double)((1ll << bits) - (1ll << quantbits));
+    const double* p = pmf + row * K + lane * NPL;
+    uint32_t f[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) f[i] = (uint32_t)((int32_t)(p[i] * M) + 1);
+    bool bad;
+    uint32_t c = bump_and_scan<NPL>(f, lane, bits, bad);
+    if (status && __ballot(bad) != 0ull && lane == 0) status[row] = BS_ST_BADTABLE;
+    uint32_t* co = cdf_out + row * ld + lane * NPL;
+    uint32_t* fo = f_out ? f_out + row * K + lane * NPL : nullptr;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        co[i] = c;
+        if (fo) fo[i] = f[i];
+        c += f[i];
+    }
+    if (lane == 63) cdf_out[row * ld + K] = 1u << bits;
+}
+
+// any K >= 1: bins strided over the lanes (j = it*64 + lane), two passes over the row
+__global__ __launch_bounds__(256) void k_table_rows_generic(const double* __restrict__ pmf, int64_t rows, int K,
+                                                            int bits, int quantbits, uint32_t* __restrict__ f_out,
+                                                            uint32_t* __restrict__ cdf_out, int64_t ld,
+                                                            int32_t* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const double M = (double)((1ll << bits) - (1ll << quantbits));
+    const double* p = pmf + row * K;
+    // pass 1: sum, maximum, first index of the maximum
+    uint32_t fsum = 0, best = 0;
+    int barg = 0x7fffffff;
+    for (int j = lane; j < K; j += 64) {
+        const uint32_t fj = (uint32_t)((int32_t)(p[j] * M) + 1);
+        fsum += fj;
+        if (fj > best) { best = fj; barg = j; }
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add(fsum), 63);
+    const uint32_t mx = wave_max_u32(best);
+    // smallest bin index among the lanes holding the maximum
+    uint32_t cand = (best == mx) ? (uint32_t)(0x7fffffff - barg) : 0u;
+    const int arg = 0x7fffffff - (int)wave_max_u32(cand);
+    const uint32_t rem = (1u << bits) - total;
+    if (status && lane == 0 && (int32_t)(mx + rem) < 1) status[row] = BS_ST_BADTABLE;
+    // pass 2: exclusive prefix, 64 bins at a time
+    uint32_t carry = 0;
+    for (int j0 = 0; j0 < K; j0 += 64) {
+        const int j = j0 + lane;
+        uint32_t fj = 0;
+        if (j < K) {
+            fj = (uint32_t)((int32_t)(p[j] * M) + 1);
+            if (j == arg) fj += rem;
+        }
+        const uint32_t incl = wave_incl_scan_add(fj);
+        if (j < K) {
+            cdf_out[row * ld + j] = carry + incl - fj;
+            if (f_out) f_out[row * K + j] = fj;
+        }
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) cdf_out[row * ld + K] = 1u << bits;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rans_pop: one wavefront per chain.  NV = uint4 loads per lane per row (K = 256*NV), rows
+// 16-byte aligned; the next row is fetched while the current one is searched.
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                 int32_t* __restrict__ len, int64_t cap,
+                                                 const uint32_t* __restrict__ cdf, int64_t chain_stride, int64_t ld,
+                                                 int D, int bits, int32_t* __restrict__ sym_out,
+                                                 const double* __restrict__ centres, int64_t c_stride,
+                                                 float* __restrict__ centre_out, int32_t* __restrict__ status) {
+    constexpr int K = NV * 256;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) return;
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t* tab = cdf + (int64_t)b * chain_stride;
+    const uint64_t mask = (1ull << bits) - 1;
+    int st = BS_ST_OK;
+
+    uint4 cur[NV], nxt[NV];
+    {
+        const uint4* r = reinterpret_cast<const uint4*>(tab + (int64_t)(D - 1) * ld);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) nxt[i] = r[i * 64 + lane];
+    }
+    int mysym = 0;
+    for (int d = D - 1; d >= 0; --d) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
+        if (d > 0) {
+            const uint4* r = reinterpret_cast<const uint4*>(tab + (int64_t)(d - 1) * ld);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) nxt[i] = r[i * 64 + lane];
+        }
+        const uint32_t m = (uint32_t)(h & mask);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            cnt += __popcll(__ballot(cur[i].x <= m));
+            cnt += __popcll(__ballot(cur[i].y <= m));
+            cnt += __popcll(__ballot(cur[i].z <= m));
+            cnt += __popcll(__ballot(cur[i].w <= m));
+        }
+        const int s = cnt - 1;  // c_0 = 0 <= m always, so s >= 0
+        const uint32_t* row = tab + (int64_t)d * ld;
+        const uint32_t cs = row[s];
+        const uint32_t cs1 = row[s + 1];
+        const uint64_t f = (uint64_t)(cs1 - cs);
+        h = f * (h >> bits) + (uint64_t)(m - cs);
+        if (h < (1ull << 32)) {
+            if (n <= 0) { st = BS_ST_UNDERFLOW; break; }
+            h = (h << 32) | (uint64_t)stk[--n];
+        }
+        if (lane == (d & 63)) mysym = s;
+        if ((d & 63) == 0) {
+            const int dd = d + lane;
+            if (dd < D) {
+                const int64_t o = (int64_t)b * D + dd;
+                sym_out[o] = mysym;
+                if (centres) centre_out[o] = (float)centres[(int64_t)dd * c_stride + mysym];
+            }
+        }
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+}
+
+// any K / any alignment (reference layout ld = K+1): scalar strided loads, no prefetch
+__global__ __launch_bounds__(64) void k_rans_pop_generic(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                         int32_t* __restrict__ len, int64_t cap,
+                                                         const uint32_t* __restrict__ cdf, int64_t chain_stride,
+                                                         int64_t ld, int D, int K, int bits,
+                                                         int32_t* __restrict__ sym_out,
+                                                         const double* __restrict__ centres, int64_t c_stride,
+                                                         float* __restrict__ centre_out,
+                                                         int32_t* __restrict__ status) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) return;
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t* tab = cdf + (int64_t)b * chain_stride;
+    const uint64_t mask = (1ull << bits) - 1;
+    int st = BS_ST_OK;
+    for (int d = D - 1; d >= 0; --d) {
+        const uint32_t* row = tab + (int64_t)d * ld;
+        const uint32_t m = (uint32_t)(h & mask);
+        int cnt = 0;
+        for (int j0 = 0; j0 < K; j0 += 64) {
+            const int j = j0 + lane;
+            const bool le = (j < K) && (row[j] <= m);
+            cnt += __popcll(__ballot(le));
+        }
+        const int s = cnt - 1;
+        const uint32_t cs = row[s];
+        const uint32_t cs1 = row[s + 1];
+        const uint64_t f = (uint64_t)(cs1 - cs);
+        h = f * (h >> bits) + (uint64_t)(m - cs);
+        if (h < (1ull << 32)) {
+            if (n <= 0) { st = BS_ST_UNDERFLOW; break; }
+            h = (h << 32) | (uint64_t)stk[--n];
+        }
+        if (lane == 0) {
+            const int64_t o = (int64_t)b * D + d;
+            sym_out[o] = s;
+            if (centres) centre_out[o] = (float)centres[(int64_t)d * c_stride + s];
+        }
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rans_push: one lane per chain
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool push_step(uint64_t& h, uint32_t* stk, int& n, int64_t cap, uint32_t fv, uint32_t cv,
+                                          int bits) {
+    const uint64_t f = fv;
+    if (h >= (f << (64 - bits))) {  // ((2^32 >> bits) << 32) * f, mnist_compress.py:52
+        if (n >= cap) return false;
+        stk[n++] = (uint32_t)h;
+        h >>= 32;
+    }
+    h = ((h / f) << bits) + (h % f) + (uint64_t)cv;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_rans_push(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                  int32_t* __restrict__ len, int64_t cap,
+                                                  const uint32_t* __restrict__ fs, const uint32_t* __restrict__ cs,
+                                                  int B, int D, int bits, int32_t* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || status[b] != BS_ST_OK) return;
+    uint64_t h = head[b];
+    int n = len[b];
+    uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t* f = fs + (int64_t)b * D;
+    const uint32_t* c = cs + (int64_t)b * D;
+    int st = BS_ST_OK;
+    for (int d = 0; d < D; ++d) {
+        if (!push_step(h, stk, n, cap, f[d], c[d], bits)) { st = BS_ST_OVERFLOW; break; }
+    }
+    head[b] = h;
+    len[b] = n;
+    if (st != BS_ST_OK) status[b] = st;
+}
+
+__global__ __launch_bounds__(64) void k_rans_push_table(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                        int32_t* __restrict__ len, int64_t cap,
+                                                        const uint32_t* __restrict__ cdf, int64_t chain_stride,
+                                                        int64_t ld, const int32_t* __restrict__ sym, int B, int D,
+                                                        int K, int bits, int32_t* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || status[b] != BS_ST_OK) return;
+    uint64_t h = head[b];
+    int n = len[b];
+    uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t* tab = cdf + (int64_t)b * chain_stride;
+    const int32_t* sy = sym + (int64_t)b * D;
+    int st = BS_ST_OK;
+    for (int d = 0; d < D; ++d) {
+        const int s = sy[d];
+        if (s < 0 || s >= K) { st = BS_ST_BADSYMBOL; break; }
+        const uint32_t* row = tab + (int64_t)d * ld;
+        const uint32_t c0 = row[s], c1 = row[s + 1];
+        if (c1 <= c0) { st = BS_ST_BADTABLE; break; }
+        if (!push_step(h, stk, n, cap, c1 - c0, c0, bits)) { st = BS_ST_OVERFLOW; break; }
+    }
+    head[b] = h;
+    len[b] = n;
+    if (st != BS_ST_OK) status[b] = st;
+}
+
+__global__ void k_gather_centres(const double* __restrict__ centres, int64_t c_stride,
+                                 const int32_t* __restrict__ sym, int64_t total, int D, int K,
+                                 float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % D);
+    int s = sym[i];
+    s = min(max(s, 0), K - 1);
+    out[i] = (float)centres[(int64_t)d * c_stride + s];
+}
+
+__global__ void k_sigmoid(const double* __restrict__ t, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = det_sigmoid(t[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// self test of the wave primitives against shuffle-based restatements
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_selftest(unsigned long long* failures) {
+    const int lane = threadIdx.x;
+    unsigned long long bad = 0;
+    uint32_t x = (uint32_t)(lane * 2654435761u + blockIdx.x * 40503u) >> 8;
+    // reference inclusive scan through LDS
+    __shared__ uint32_t sh[64];
+    sh[lane] = x;
+    __syncthreads();
+    uint32_t ref = 0, rmax = 0;
+    for (int i = 0; i <= lane; ++i) ref += sh[i];
+    for (int i = 0; i < 64; ++i) rmax = max(rmax, sh[i]);
+    if (wave_incl_scan_add(x) != ref) bad++;
+    if (wave_max_u32(x) != rmax) bad++;
+    const double dv = (double)x * 0.25;
+    const double up = lane_shift_up_f64(dv);
+    if (lane > 0 && up != (double)sh[lane - 1] * 0.25) bad++;
+    // bump_and_scan on a 4-bins-per-lane row whose maximum repeats
+    uint32_t f[4];
+    uint32_t tot = 0;
+    for (int i = 0; i < 4; ++i) f[i] = 1 + ((x >> (3 * i)) & 7u);
+    if (lane == 9 || lane == 40) f[2] = 100;  // tie: first (lane 9, bin 2) must win
+    __shared__ uint32_t fall[256];
+    for (int i = 0; i < 4; ++i) fall[lane * 4 + i] = f[i];
+    __syncthreads();
+    for (int i = 0; i < 256; ++i) tot += fall[i];
+    bool badrow;
+    uint32_t c = bump_and_scan<4>(f, lane, 20, badrow);
+    uint32_t rc = 0;
+    for (int i = 0; i < lane * 4; ++i) rc += fall[i] + ((i == 9 * 4 + 2) ? ((1u << 20) - tot) : 0u);
+    if (c != rc) bad++;
+    if (lane == 9 && f[2] != 100 + ((1u << 20) - tot)) bad++;
+    if (lane == 40 && f[2] != 100) bad++;
+    if (bad) atomicAdd(failures, bad);
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_rc() { return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int NPL, typename PT>
+int launch_logistic(bool decode, bool vec, const double* endpoints, int64_t e_stride, const void* mu,
+                    const void* scale, const int32_t* sym, int B, int D, int bits, int quantbits,
+                    uint32_t* out0, uint32_t* out1, int64_t ld, int32_t* status, hipStream_t st) {
+    // chains per wavefront: amortise the endpoint fetch, but keep >= ~8 waves per SIMD in flight
+    int nb = 4;
+    while (nb > 1 && (int64_t)((D + 3) / 4) * ((B + nb - 1) / nb) < 4096) nb >>= 1;
+    dim3 grid((D + 3) / 4, (B + nb - 1) / nb), block(256);
+    const PT* m = static_cast<const PT*>(mu);
+    const PT* s = static_cast<const PT*>(scale);
+    if (decode) {
+        if (vec && NPL >= 4)
+            hipLaunchKernelGGL((k_logistic<NPL, PT, true, (NPL >= 4)>), grid, block, 0, st, endpoints, e_stride, m, s,
+                               sym, B, D, bits, quantbits, nb, out0, out1, ld, status);
+        else
+            hipLaunchKernelGGL((k_logistic<NPL, PT, true, false>), grid, block, 0, st, endpoints, e_stride, m, s, sym,
+                               B, D, bits, quantbits, nb, out0, out1, ld, status);
+    } else {
+        hipLaunchKernelGGL((k_logistic<NPL, PT, false, false>), grid, block, 0, st, endpoints, e_stride, m, s, sym, B,
+                           D, bits, quantbits, nb, out0, out1, ld, status);
+    }
+    return launch_rc();
+}
+
+template <typename PT>
+int dispatch_logistic(int K, bool decode, bool vec, const double* endpoints, int64_t e_stride, const void* mu,
+                      const void* scale, const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0,
+                      uint32_t* out1, int64_t ld, int32_t* status, hipStream_t st) {
+#define BS_CASE(NPL)                                                                                              \
+    case 64 * NPL:                                                                                                \
+        return launch_logistic<NPL, PT>(decode, vec, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits, \
+                                        out0, out1, ld, status, st)
+    switch (K) {
+        BS_CASE(1);
+        BS_CASE(2);
+        BS_CASE(4);
+        BS_CASE(8);
+        BS_CASE(16);
+        BS_CASE(32);
+        default:
+            return BS_EUNSUPPORTED;
+    }
+#undef BS_CASE
+}
+
+}  // namespace
+
+extern "C" {
+
+int bs_abi_version(void) { return BS_ABI_VERSION; }
+int bs_cdf_spec(void) { return BS_CDF_SPEC; }
+
+const char* bs_strerror(int code) {
+    switch (code) {
+        case BS_OK: return "ok";
+        case BS_EINVAL: return "invalid argument";
+        case BS_EUNSUPPORTED: return "alphabet size not supported by the fused logistic kernels (need K = 64*2^n <= 2048)";
+        case BS_ELAUNCH: return "HIP kernel launch failed";
+        case BS_ST_UNDERFLOW: return "stack underflow (too few initial bits)";
+        case BS_ST_OVERFLOW: return "stack overflow (capacity exhausted)";
+        case BS_ST_BADTABLE: return "table invariant violated (cdf[K] != 2^bits or zero frequency)";
+        case BS_ST_BADSYMBOL: return "symbol out of range";
+        default: return "unknown code";
+    }
+}
+
+int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quantbits, uint32_t* f_out,
+                      uint32_t* cdf_out, int64_t ld, int32_t* status, void* stream) {
+    if (!pmf || !cdf_out || rows < 0 || K < 1 || ld < K + 1 || bits < 1 || bits > 31 || quantbits < 0 ||
+        quantbits >= bits)
+        return BS_EINVAL;
+    if (rows == 0) return BS_OK;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = S(stream);
+    switch (K) {
+        case 256:
+            hipLaunchKernelGGL(k_table_rows<4>, grid, block, 0, st, pmf, rows, bits, quantbits, f_out, cdf_out, ld, status);
+            break;
+        case 1024:
+            hipLaunchKernelGGL(k_table_rows<16>, grid, block, 0, st, pmf, rows, bits, quantbits, f_out, cdf_out, ld, status);
+            break;
+        default:
+            hipLaunchKernelGGL(k_table_rows_generic, grid, block, 0, st, pmf, rows, K, bits, quantbits, f_out, cdf_out, ld,
+                               status);
+    }
+    return launch_rc();
+}
+
+int bs_logistic_tables(const double* endpoints, int64_t e_stride, const void* mu, const void* scale, int param_dtype,
+                       int B, int D, int K, int bits, int quantbits, uint32_t* cdf_out, int64_t ld, void* stream) {
+    if (!endpoints || !mu || !scale || !cdf_out || B < 0 || D < 0 || ld < K + 1 || bits < 1 || bits > 31 ||
+        quantbits < 0 || quantbits >= bits || e_stride < 0)
+        return BS_EINVAL;
+    if (B == 0 || D == 0) return BS_OK;
+    const bool vec = aligned16(cdf_out) && (ld % 4 == 0);
+    if (param_dtype == BS_PARAM_F32)
+        return dispatch_logistic<float>(K, true, vec, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
+                                        cdf_out, nullptr, ld, nullptr, S(stream));
+    if (param_dtype == BS_PARAM_F64)
+        return dispatch_logistic<double>(K, true, vec, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
+                                         cdf_out, nullptr, ld, nullptr, S(stream));
+    return BS_EINVAL;
+}
+
+int bs_logistic_fc(const double* endpoints, int64_t e_stride, const void* mu, const void* scale, int param_dtype,
+                   const int32_t* sym, int B, int D, int K, int bits, int quantbits, uint32_t* f_out, uint32_t* c_out,
+                   int32_t* status, void* stream) {
+    if (!endpoints || !mu || !scale || !sym || !f_out || !c_out || !status || B < 0 || D < 0 || bits < 1 ||
+        bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0)
+        return BS_EINVAL;
+    if (B == 0 || D == 0) return BS_OK;
+    if (param_dtype == BS_PARAM_F32)
+        return dispatch_logistic<float>(K, false, false, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
+                                        f_out, c_out, 0, status, S(stream));
+    if (param_dtype == BS_PARAM_F64)
+        return dispatch_logistic<double>(K, false, false, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
+                                         f_out, c_out, 0, status, S(stream));
+    return BS_EINVAL;
+}
+
+int bs_rans_push(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* f, const uint32_t* c,
+                 int B, int D, int bits, int32_t* status, void* stream) {
+    if (!head || !stack || !len || !f || !c || !status || B < 0 || D < 0 || cap < 0 || bits < 1 || bits > 31)
+        return BS_EINVAL;
+    if (B == 0 || D == 0) return BS_OK;
+    hipLaunchKernelGGL(k_rans_push, dim3((B + 63) / 64), dim3(64), 0, S(stream), head, stack, len, cap, f, c, B, D,
+                       bits, status);
+    return launch_rc();
+}
+
+int bs_rans_push_table(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* cdf,
+                       int64_t chain_stride, int64_t ld, const int32_t* sym, int B, int D, int K, int bits,
+                       int32_t* status, void* stream) {
+    if (!head || !stack || !len || !cdf || !sym || !status || B < 0 || D < 0 || cap < 0 || K < 1 || ld < K + 1 ||
+        chain_stride < 0 || bits < 1 || bits > 31)
+        return BS_EINVAL;
+    if (B == 0 || D == 0) return BS_OK;
+    hipLaunchKernelGGL(k_rans_push_table, dim3((B + 63) / 64), dim3(64), 0, S(stream), head, stack, len, cap, cdf,
+                       chain_stride, ld, sym, B, D, K, bits, status);
+    return launch_rc();
+}
+
+int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* cdf, int64_t chain_stride,
+                int64_t ld, int B, int D, int K, int bits, int32_t* sym_out, const double* centres, int64_t c_stride,
+                float* centre_out, int32_t* status, void* stream) {
+    if (!head || !stack || !len || !cdf || !sym_out || !status || B < 0 || D < 0 || cap < 0 || K < 1 || ld < K + 1 ||
+        chain_stride < 0 || bits < 1 || bits > 31 || (centres && !centre_out) || c_stride < 0)
+        return BS_EINVAL;
+    if (B == 0 || D == 0) return BS_OK;
+    hipStream_t st = S(stream);
+    const bool vec = aligned16(cdf) && (ld % 4 == 0) && (chain_stride % 4 == 0);
+    dim3 grid(B), block(64);
+#define BS_POP(NV)                                                                                                   \
+    hipLaunchKernelGGL(k_rans_pop<NV>, grid, block, 0, st, head, stack, len, cap, cdf, chain_stride, ld, D, bits,   \
+                       sym_out, centres, c_stride, centre_out, status)
+    if (vec && K == 256) BS_POP(1);
+    else if (vec && K == 512) BS_POP(2);
+    else if (vec && K == 1024) BS_POP(4);
+    else if (vec && K == 2048) BS_POP(8);
+    else
+        hipLaunchKernelGGL(k_rans_pop_generic, grid, block, 0, st, head, stack, len, cap, cdf, chain_stride, ld, D, K,
+                           bits, sym_out, centres, c_stride, centre_out, status);
+#undef BS_POP
+    return launch_rc();
+}
+
+int bs_gather_centres(const double* centres, int64_t c_stride, const int32_t* sym, int B, int D, int K,
+                      float* centre_out, void* stream) {
+    if (!centres || !sym || !centre_out || B < 0 || D < 0 || K < 1 || c_stride < 0) return BS_EINVAL;
+    const int64_t total = (int64_t)B * D;
+    if (total == 0) return BS_OK;
+    hipLaunchKernelGGL(k_gather_centres, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), centres,
+                       c_stride, sym, total, D, K, centre_out);
+    return launch_rc();
+}
+
+int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream) {
+    if (!t || !out || n < 0) return BS_EINVAL;
+    if (n == 0) return BS_OK;
+    hipLaunchKernelGGL(k_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), t, n, out);
+    return launch_rc();
+}
+
+int bs_selftest(int64_t* failures_host, void* stream) {
+    if (!failures_host) return BS_EINVAL;
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, sizeof(unsigned long long)) != hipSuccess) return BS_ELAUNCH;
+    hipStream_t st = S(stream);
+    if (hipMemsetAsync(d, 0, sizeof(unsigned long long), st) != hipSuccess) { (void)hipFree(d); return BS_ELAUNCH; }
+    hipLaunchKernelGGL(k_selftest, dim3(64), dim3(64), 0, st, d);
+    unsigned long long h = ~0ull;
+    hipError_t e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return BS_ELAUNCH;
+    *failures_host = (int64_t)h;
+    return BS_OK;
+}
+
+}  // extern "C"

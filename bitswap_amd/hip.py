@@ -1,0 +1,280 @@
+"""ctypes binding of libbitswap_hip.so (include/bitswap_hip.h) for torch tensors.
+
+There is NO fallback: if the library is missing or there is no GPU, every function here
+raises.  torch is used only for device memory and the current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
+ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
+PARAM_F32, PARAM_F64 = 0, 1
+
+SYMBOLS = [
+    "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
+    "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres",
+    "bs_selftest", "bs_sigmoid_f64",
+]
+
+
+class BitswapHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen libbitswap_hip.so (must have been built: `python -m bitswap_amd.build` or
+    __graft_entry__.build()).  Raises if absent -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise BitswapHipError(
+            f"{path} not found: build it with `python -m bitswap_amd.build` (hipcc, gfx950). "
+            "bitswap_amd has no CPU fallback for the entropy-coding path.")
+    L = C.CDLL(path)
+    p, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.bs_abi_version.restype = i32
+    L.bs_cdf_spec.restype = i32
+    L.bs_strerror.restype = C.c_char_p
+    L.bs_strerror.argtypes = [i32]
+    L.bs_table_rows_f64.argtypes = [p, i64, i32, i32, i32, p, p, i64, p, p]
+    L.bs_logistic_tables.argtypes = [p, i64, p, p, i32, i32, i32, i32, i32, i32, p, i64, p]
+    L.bs_logistic_fc.argtypes = [p, i64, p, p, i32, p, i32, i32, i32, i32, i32, p, p, p, p]
+    L.bs_rans_push.argtypes = [p, p, p, i64, p, p, i32, i32, i32, p, p]
+    L.bs_rans_push_table.argtypes = [p, p, p, i64, p, i64, i64, p, i32, i32, i32, i32, p, p]
+    L.bs_rans_pop.argtypes = [p, p, p, i64, p, i64, i64, i32, i32, i32, i32, p, p, i64, p, p, p]
+    L.bs_gather_centres.argtypes = [p, i64, p, i32, i32, i32, p, p]
+    L.bs_selftest.argtypes = [C.POINTER(C.c_int64), p]
+    L.bs_sigmoid_f64.argtypes = [p, i64, p, p]
+    for n in SYMBOLS:
+        if n != "bs_strerror":
+            getattr(L, n).restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != OK:
+        msg = load().bs_strerror(rc).decode()
+        raise BitswapHipError(f"{what}: {msg} (code {rc})")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise BitswapHipError("bitswap_amd kernels need tensors on a HIP device (no CPU fallback)")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _param_dtype(t):
+    if t.dtype == torch.float32:
+        return PARAM_F32
+    if t.dtype == torch.float64:
+        return PARAM_F64
+    raise BitswapHipError(f"mu/scale must be float32 or float64, got {t.dtype}")
+
+
+def _row_stride(t, width):
+    """Endpoint / centre tables: [D, width] with unit inner stride; row stride may be 0 (expanded)."""
+    if t.dim() != 2 or t.shape[1] != width or t.dtype != torch.float64:
+        raise BitswapHipError(f"expected float64 [D,{width}] table, got {tuple(t.shape)} {t.dtype}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def aligned_ld(K):
+    """Row stride (uint32 units) selecting 16-byte stores/loads: K+1 entries rounded up to 4."""
+    return (K + 1 + 3) // 4 * 4
+
+
+def selftest():
+    n = C.c_int64(-1)
+    _check(load().bs_selftest(C.byref(n), _stream()), "bs_selftest")
+    return n.value
+
+
+def sigmoid_f64(t):
+    _need_cuda(t)
+    t = t.contiguous().to(torch.float64)
+    out = torch.empty_like(t)
+    _check(load().bs_sigmoid_f64(_ptr(t), t.numel(), _ptr(out), _stream()), "bs_sigmoid_f64")
+    return out
+
+
+def table_rows(pmf, bits=31, quantbits=8, ld=None, want_f=True):
+    """ANS.__init__ on pmf [rows,K] f64 -> (f [rows,K] int32 | None, cdf [rows,ld] int32, status [rows])."""
+    _need_cuda(pmf)
+    pmf = pmf.contiguous().to(torch.float64)
+    rows, K = pmf.shape
+    ld = ld or (K + 1)
+    f = torch.empty((rows, K), dtype=torch.int32, device=pmf.device) if want_f else None
+    cdf = torch.empty((rows, ld), dtype=torch.int32, device=pmf.device)
+    status = torch.zeros(rows, dtype=torch.int32, device=pmf.device)
+    _check(load().bs_table_rows_f64(_ptr(pmf), rows, K, bits, quantbits, _ptr(f), _ptr(cdf), ld, _ptr(status),
+                                    _stream()), "bs_table_rows_f64")
+    return f, cdf, status
+
+
+def logistic_tables(endpoints, mu, scale, bits=31, quantbits=10, ld=None, out=None):
+    """Fused CDF -> integer cdf rows.  endpoints [D,K-1] f64, mu/scale [B,D] -> cdf [B,D,ld] int32."""
+    _need_cuda(endpoints, mu, scale)
+    B, D = mu.shape
+    K = endpoints.shape[1] + 1
+    endpoints, es = _row_stride(endpoints, K - 1)
+    mu, scale = mu.contiguous(), scale.contiguous()
+    ld = ld or aligned_ld(K)
+    if out is None:
+        out = torch.empty((B, D, ld), dtype=torch.int32, device=mu.device)
+    _check(load().bs_logistic_tables(_ptr(endpoints), es, _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K, bits,
+                                     quantbits, _ptr(out), ld, _stream()), "bs_logistic_tables")
+    return out
+
+
+def logistic_fc(endpoints, mu, scale, sym, status, bits=31, quantbits=10, out=None):
+    """Fused CDF -> (f, c) of the given symbols.  sym [B,D] int32 -> f, c [B,D] int32."""
+    _need_cuda(endpoints, mu, scale, sym, status)
+    B, D = mu.shape
+    K = endpoints.shape[1] + 1
+    endpoints, es = _row_stride(endpoints, K - 1)
+    mu, scale = mu.contiguous(), scale.contiguous()
+    sym = sym.contiguous()
+    if sym.dtype != torch.int32:
+        sym = sym.to(torch.int32)
+    if out is None:
+        f = torch.empty((B, D), dtype=torch.int32, device=mu.device)
+        c = torch.empty((B, D), dtype=torch.int32, device=mu.device)
+    else:
+        f, c = out
+    _check(load().bs_logistic_fc(_ptr(endpoints), es, _ptr(mu), _ptr(scale), _param_dtype(mu), _ptr(sym), B, D, K,
+                                 bits, quantbits, _ptr(f), _ptr(c), _ptr(status), _stream()), "bs_logistic_fc")
+    return f, c
+
+
+class RansState:
+    """B independent rANS states resident in HBM.
+
+    head [B] (uint64 bits in an int64 tensor), stack [B,cap] (uint32 bits in int32), len [B]
+    int32, status [B] int32.  One chain is the reference's Python list `state`
+    (mnist_compress.py:158-159): stack words followed by the 64-bit head.
+    """
+
+    def __init__(self, B, cap, device):
+        self.B, self.cap, self.device = B, int(cap), torch.device(device)
+        self.head = torch.zeros(B, dtype=torch.int64, device=device)
+        self.stack = torch.zeros((B, self.cap), dtype=torch.int32, device=device)
+        self.len = torch.zeros(B, dtype=torch.int32, device=device)
+        self.status = torch.zeros(B, dtype=torch.int32, device=device)
+
+    @classmethod
+    def from_lists(cls, states, cap=None, device="cuda"):
+        """states: list of B Python lists [w0, ..., w_{n-1}, head]."""
+        import numpy as np
+        B = len(states)
+        n = max(len(s) - 1 for s in states)
+        cap = max(int(cap or 0), n)
+        st = cls(B, cap, device)
+        stack = np.zeros((B, cap), dtype=np.uint32)
+        head = np.zeros(B, dtype=np.uint64)
+        ln = np.zeros(B, dtype=np.int32)
+        for b, s in enumerate(states):
+            k = len(s) - 1
+            stack[b, :k] = np.asarray(s[:-1], dtype=np.uint64).astype(np.uint32)
+            head[b] = s[-1]
+            ln[b] = k
+        st.stack.copy_(torch.from_numpy(stack.view(np.int32)))
+        st.head.copy_(torch.from_numpy(head.view(np.int64)))
+        st.len.copy_(torch.from_numpy(ln))
+        return st
+
+    def to_lists(self):
+        import numpy as np
+        stack = self.stack.cpu().numpy().view(np.uint32)
+        head = self.head.cpu().numpy().view(np.uint64)
+        ln = self.len.cpu().numpy()
+        return [[int(w) for w in stack[b, : ln[b]]] + [int(head[b])] for b in range(self.B)]
+
+    def check(self, what="rANS"):
+        """Synchronising: raise if any chain reported a device-side error."""
+        st = self.status.cpu()
+        if int(st.abs().max()) != 0:
+            b = int(torch.nonzero(st)[0])
+            code = int(st[b])
+            raise BitswapHipError(f"{what}: chain {b}: {load().bs_strerror(code).decode()} (status {code})")
+
+
+def rans_push(state, f, c, bits=31):
+    _need_cuda(f, c)
+    B, D = f.shape
+    _check(load().bs_rans_push(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(f), _ptr(c),
+                               B, D, bits, _ptr(state.status), _stream()), "bs_rans_push")
+
+
+def rans_push_table(state, cdf, sym, K, bits=31):
+    """cdf [B,D,ld] (per chain) or [D,ld] (shared by all chains); sym [B,D] int32."""
+    _need_cuda(cdf, sym)
+    sym = sym.contiguous()
+    if sym.dtype != torch.int32:
+        sym = sym.to(torch.int32)
+    B, D = sym.shape
+    cdf = cdf.contiguous()
+    ld = cdf.shape[-1]
+    chain_stride = 0 if cdf.dim() == 2 else D * ld
+    _check(load().bs_rans_push_table(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(cdf),
+                                     chain_stride, ld, _ptr(sym), B, D, K, bits, _ptr(state.status), _stream()),
+           "bs_rans_push_table")
+
+
+def rans_pop(state, cdf, K, bits=31, centres=None, B=None):
+    """Pop D symbols per chain.  Returns (sym [B,D] int32, z [B,D] float32 | None)."""
+    _need_cuda(cdf, centres)
+    cdf = cdf.contiguous()
+    ld = cdf.shape[-1]
+    if cdf.dim() == 2:
+        D, chain_stride, B = cdf.shape[0], 0, (B or state.B)
+    else:
+        B, D = cdf.shape[0], cdf.shape[1]
+        chain_stride = D * ld
+    sym = torch.empty((B, D), dtype=torch.int32, device=cdf.device)
+    z, cs = None, 0
+    if centres is not None:
+        centres, cs = _row_stride(centres, K)
+        z = torch.empty((B, D), dtype=torch.float32, device=cdf.device)
+    _check(load().bs_rans_pop(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(cdf),
+                              chain_stride, ld, B, D, K, bits, _ptr(sym), _ptr(centres), cs, _ptr(z),
+                              _ptr(state.status), _stream()), "bs_rans_pop")
+    return sym, z
+
+
+def gather_centres(centres, sym):
+    """z[b,d] = float32(centres[d, sym[b,d]])  (mnist_compress.py:181,196 + Model's .float())."""
+    _need_cuda(centres, sym)
+    B, D = sym.shape
+    K = centres.shape[1]
+    centres, cs = _row_stride(centres, K)
+    sym = sym.contiguous()
+    if sym.dtype != torch.int32:
+        sym = sym.to(torch.int32)
+    out = torch.empty((B, D), dtype=torch.float32, device=sym.device)
+    _check(load().bs_gather_centres(_ptr(centres), cs, _ptr(sym), B, D, K, _ptr(out), _stream()),
+           "bs_gather_centres")
+    return out

@@ -1,0 +1,156 @@
+/*
+ * bitswap_hip.h -- C ABI of libbitswap_hip.so, the MI355X (gfx950) implementation of the
+ * Bit-Swap / BB-ANS entropy-coding hot path.
+ *
+ * The reference (fhkingma/bitswap) has no FFI layer: its hot path is the Python class
+ * `ANS` (mnist_compress.py:13-68, copied verbatim into the five other CLI scripts) plus
+ * `logistic_cdf` (utils/torch/rand.py:67-68) and the three-line pmf assembly repeated at
+ * every call site (mnist_compress.py:183-185).  Each entry point below names the reference
+ * lines it replaces.  INTEGRATION.md shows the ctypes stub a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked host; the caller allocates everything;
+ *     the library keeps no global state and may be called from several host threads on
+ *     different streams.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
+ *     enqueues work, nothing synchronises.
+ *   - return value: BS_OK or a negative BS_E* code for errors detectable on the host at
+ *     enqueue time.  Errors that only the device can see (stack underflow ...) are written
+ *     to the per-chain `status` array and are sticky: a chain whose status is non-zero is
+ *     skipped by every later call until the caller clears it.
+ *   - B = number of independent chains (rANS states), D = symbols per chain and call
+ *     (latent or pixel dimensions), K = alphabet size (2^quantbits), bits = ANS precision
+ *     (the reference hard-codes 31, mnist_compress.py:76).
+ *   - a chain's state is {head[b] : uint64 in [2^32, 2^64), stack[b*cap .. b*cap+len[b]) :
+ *     uint32 words}; this is the reference's Python list `state` with head = state[-1]
+ *     (mnist_compress.py:158-159).
+ *   - integer tables: cdf rows hold c_0 = 0 <= c_1 <= ... <= c_K = 2^bits with row stride
+ *     `ld` >= K+1 (uint32 units); f_j = c_{j+1} - c_j.  ld == K+1 is the reference layout
+ *     (ANS.cdfs, mnist_compress.py:39-40); ld % 4 == 0 (e.g. K+4) selects 16-byte stores.
+ */
+#ifndef BITSWAP_HIP_H
+#define BITSWAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BS_ABI_VERSION 1
+/* version of the deterministic logistic-CDF specification; streams written with
+ * one CDF spec can only be decoded with the same one */
+#define BS_CDF_SPEC 1
+
+#define BS_OK 0
+#define BS_EINVAL (-1)       /* bad argument (null pointer, negative size, ld < K+1 ...)   */
+#define BS_EUNSUPPORTED (-2) /* K not supported by the fused logistic kernels              */
+#define BS_ELAUNCH (-3)      /* HIP reported a launch error                                */
+
+/* per-chain device status codes */
+#define BS_ST_OK 0
+#define BS_ST_UNDERFLOW 1 /* pop on an empty stack: "too few initial bits", mnist_compress.py:66,193 */
+#define BS_ST_OVERFLOW 2  /* push beyond `cap` words (the reference list is unbounded)               */
+#define BS_ST_BADTABLE 3  /* cdf[K] != 2^bits or a zero frequency, the assert at mnist_compress.py:47 */
+#define BS_ST_BADSYMBOL 4 /* symbol outside [0, K)                                                    */
+
+#define BS_PARAM_F32 0
+#define BS_PARAM_F64 1
+
+int bs_abi_version(void);
+int bs_cdf_spec(void);
+const char* bs_strerror(int code);
+
+/*
+ * bs_table_rows_f64 -- ANS.__init__ (mnist_compress.py:14-47) for `rows` independent pmf rows.
+ *   f_j = trunc(pmf_j * (2^bits - 2^quantbits)) + 1; the first maximal f absorbs
+ *   2^bits - sum f; cdf = exclusive prefix sum with cdf[K] = 2^bits.  Bit-exact.
+ *   pmf [rows,K] f64; f_out [rows,K] (nullable); cdf_out [rows,ld]; status [rows] (nullable,
+ *   BS_ST_BADTABLE when the row violates the reference's asserts).  Any K >= 1.
+ */
+int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quantbits,
+                      uint32_t* f_out, uint32_t* cdf_out, int64_t ld, int32_t* status, void* stream);
+
+/*
+ * bs_logistic_tables -- logistic_cdf (utils/torch/rand.py:67-68) + pmf assembly
+ * (mnist_compress.py:183-185) + ANS.__init__ (:14-47) fused, "decode flavour": writes the full
+ * integer cdf row of every (chain, dim) so that bs_rans_pop can search it.
+ *   endpoints: row d at endpoints + d*e_stride doubles, K-1 interior bin endpoints, increasing
+ *              (zendpoints[zi] has e_stride = K-1; ImageBins / top-layer bins, whose rows are
+ *              all equal, may pass e_stride = 0).
+ *   mu, scale [B,D] of param_dtype (the reference's Model emits float32 and casts up,
+ *              model/mnist_train.py:375-376; both are converted to f64 exactly).
+ *   cdf_out [B,D,ld].
+ * The CDF is evaluated in float64 by the deterministic routine of DESIGN.md (BS_CDF_SPEC);
+ * it agrees with torch.sigmoid to a few ulp, everything after it is exact integer work.
+ * K must be 64*n, n in {1,2,4,8,16,32}.
+ */
+int bs_logistic_tables(const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
+                       int param_dtype, int B, int D, int K, int bits, int quantbits,
+                       uint32_t* cdf_out, int64_t ld, void* stream);
+
+/*
+ * bs_logistic_fc -- same fused computation, "encode flavour": given the symbol of every
+ * (chain, dim) emit only its frequency f and cumulative start c (what ANS.encode reads at
+ * mnist_compress.py:51,55); no table is written.
+ *   sym [B,D] int32; f_out, c_out [B,D] uint32; status [B] receives BS_ST_BADSYMBOL.
+ */
+int bs_logistic_fc(const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
+                   int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits,
+                   uint32_t* f_out, uint32_t* c_out, int32_t* status, void* stream);
+
+/*
+ * bs_rans_push -- ANS.encode (mnist_compress.py:49-56), B chains, symbols i = 0..D-1 in order:
+ *   if head >= 2^(64-bits) * f: stack[len++] = low32(head); head >>= 32
+ *   head = (head / f) << bits + head % f + c
+ *   f, c [B,D] as produced by bs_logistic_fc.
+ */
+int bs_rans_push(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
+                 const uint32_t* f, const uint32_t* c, int B, int D, int bits,
+                 int32_t* status, void* stream);
+
+/*
+ * bs_rans_push_table -- ANS.encode reading (f, c) from integer cdf rows: row of (b, d) at
+ * cdf + b*chain_stride + d*ld (chain_stride = 0 shares one table between all chains, used for
+ * the image-independent prior, mnist_compress.py:246-251).  sym [B,D].
+ */
+int bs_rans_push_table(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
+                       const uint32_t* cdf, int64_t chain_stride, int64_t ld, const int32_t* sym,
+                       int B, int D, int K, int bits, int32_t* status, void* stream);
+
+/*
+ * bs_rans_pop -- ANS.decode (mnist_compress.py:58-68), B chains, symbols i = D-1..0:
+ *   m = head & (2^bits - 1); s = max{j : c_j <= m}; head = f_s * (head >> bits) + m - c_s
+ *   if head < 2^32: head = head << 32 | stack[--len]
+ * cdf as in bs_rans_push_table.  sym_out [B,D] int32.  If `centres` is non-null (row d at
+ * centres + d*c_stride doubles, K entries) the bin centre of every decoded symbol is also
+ * written as float32 to centre_out [B,D]: the gather + cast of mnist_compress.py:181,196 and
+ * model/mnist_train.py:324,392.
+ */
+int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
+                const uint32_t* cdf, int64_t chain_stride, int64_t ld, int B, int D, int K, int bits,
+                int32_t* sym_out, const double* centres, int64_t c_stride, float* centre_out,
+                int32_t* status, void* stream);
+
+/*
+ * bs_gather_centres -- centre_out[b,d] = (float) centres[d*c_stride + sym[b,d]]
+ * (mnist_compress.py:181,196,308 followed by the .float() of model/mnist_train.py:324,392).
+ */
+int bs_gather_centres(const double* centres, int64_t c_stride, const int32_t* sym, int B, int D, int K,
+                      float* centre_out, void* stream);
+
+/*
+ * bs_selftest -- runs the wave-level primitives (DPP scan / reductions) and the deterministic
+ * sigmoid against in-kernel scalar restatements; host pointer `failures` receives the number of
+ * mismatching lanes.  Synchronises the stream.  For tests only.
+ */
+int bs_selftest(int64_t* failures_host, void* stream);
+
+/* bs_sigmoid_f64 -- out[i] = deterministic sigmoid(t[i]); exposes the CDF spec for parity tests */
+int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BITSWAP_HIP_H */

@@ -1,0 +1,50 @@
+"""CPU: the C-ABI library loads and exports every symbol include/bitswap_hip.h declares, and the
+product path refuses to run without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "bitswap_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from bitswap_amd import hip
+    assert declared_symbols() == sorted(hip.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    from bitswap_amd import build
+    lib = ctypes.CDLL(build.build_hip())
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    lib.bs_abi_version.restype = ctypes.c_int
+    assert lib.bs_abi_version() == 1
+    lib.bs_strerror.restype = ctypes.c_char_p
+    assert b"underflow" in lib.bs_strerror(1)
+
+
+def test_argument_validation_needs_no_gpu():
+    from bitswap_amd import hip
+    L = hip.load()
+    # null pointers / bad sizes are rejected on the host before any launch
+    assert L.bs_rans_push(None, None, None, 0, None, None, 1, 1, 31, None, None) == hip.EINVAL
+    assert L.bs_table_rows_f64(None, 1, 16, 31, 4, None, None, 17, None, None) == hip.EINVAL
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from bitswap_amd import hip
+    from bitswap_amd.ans import ANS
+    with pytest.raises(hip.BitswapHipError):
+        ANS(torch.full((4, 16), 1 / 16, dtype=torch.float64))
+    with pytest.raises(hip.BitswapHipError):
+        hip.logistic_tables(torch.zeros(4, 255, dtype=torch.float64), torch.zeros(1, 4), torch.ones(1, 4))

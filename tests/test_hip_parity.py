@@ -1,0 +1,299 @@
+"""GPU: the HIP kernels (through the C ABI) against the oracle and the reference-generated
+fixtures.  Integer work must be bit-exact; the float64 CDF must be bit-exact against the
+oracle's deterministic mode and within the stated budget of torch's sigmoid."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import chain_tables, reference_init_state, words_to_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def hip():
+    from bitswap_amd import hip as h
+    return h
+
+
+def u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def test_selftest_wave_primitives():
+    assert hip().selftest() == 0
+
+
+def test_sigmoid_bit_exact_vs_oracle():
+    rng = np.random.RandomState(0)
+    t = np.concatenate([rng.uniform(-45, 45, 200000), rng.uniform(-1, 1, 50000), rng.uniform(-800, 800, 5000),
+                        [0.0, -0.0, 700.0, -700.0, 1e6, -1e6, 1e-300, -1e-300]])
+    got = hip().sigmoid_f64(dev(t)).cpu().numpy()
+    want = O.det_sigmoid(t)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["ztop", "zuni", "x"])
+@pytest.mark.parametrize("aligned", [False, True])
+def test_table_rows_bit_exact_vs_reference(golden, name, aligned):
+    g = golden("tables_rans.npz")
+    q = int(g[f"{name}_quantbits"])
+    K = g[f"{name}_pmf_f64"].shape[1]
+    ld = hip().aligned_ld(K) if aligned else K + 1
+    f, cdf, st = hip().table_rows(dev(g[f"{name}_pmf_f64"]), 31, q, ld=ld)
+    assert int(st.abs().max()) == 0
+    assert np.array_equal(u32(f), g[f"{name}_f"])
+    assert np.array_equal(u32(cdf)[:, : K + 1], g[f"{name}_cdf"])
+
+
+def test_table_rows_generic_k_and_ties(golden):
+    g = golden("tables_rans.npz")
+    f, cdf, st = hip().table_rows(dev(g["tie_pmf_f64"]), 31, 4)
+    assert np.array_equal(u32(f), g["tie_f"]) and np.array_equal(u32(cdf), g["tie_cdf"])
+    # ragged K values through the generic kernel, against the oracle
+    rng = np.random.RandomState(5)
+    for K in (1, 2, 63, 64, 65, 200, 1000):
+        p = rng.dirichlet(np.ones(K) * 0.3, size=7)
+        fo, co, rc = O.tables(p, 31, 4)
+        f, cdf, st = hip().table_rows(dev(p), 31, 4)
+        assert np.array_equal(u32(f), fo) and np.array_equal(u32(cdf), co)
+
+
+@pytest.mark.parametrize("name", ["ztop", "zuni", "x"])
+@pytest.mark.parametrize("ptype", [torch.float32, torch.float64])
+def test_logistic_tables_vs_oracle_and_reference(golden, name, ptype):
+    g = golden("tables_rans.npz")
+    q = int(g[f"{name}_quantbits"])
+    e, mu, sc = g[f"{name}_endpoints"], g[f"{name}_mu"], g[f"{name}_scale"]   # mu/scale are f32-representable
+    K = e.shape[1] + 1
+    B = 5
+    rng = np.random.RandomState(1)
+    mus = np.stack([mu] + [(mu + rng.randn(*mu.shape) * 0.1).astype(np.float32).astype(np.float64) for _ in range(B - 1)])
+    scs = np.stack([sc] + [np.clip(sc * rng.uniform(0.8, 1.2, sc.shape), 1e-3, None).astype(np.float32).astype(np.float64)
+                           for _ in range(B - 1)])
+    for ld in (K + 1, hip().aligned_ld(K)):
+        cdf = hip().logistic_tables(dev(e), dev(mus, ptype), dev(scs, ptype), 31, q, ld=ld)
+        got = u32(cdf)[:, :, : K + 1]
+        for b in range(B):
+            pmf = O.logistic_pmf(e, mus[b], scs[b], O.MODE_DET)
+            _, want, rc = O.tables(pmf, 31, q)
+            assert np.array_equal(got[b], want), (name, b, ld)
+        # chain 0 uses the fixture's parameters: compare with the reference's own integer table
+        ref = g[f"{name}_cdf"].astype(np.int64)
+        mism = (np.diff(got[0].astype(np.int64), axis=1) != np.diff(ref, axis=1))
+        assert mism.mean() <= 2e-6
+
+
+def test_logistic_tables_shared_endpoint_row():
+    """ImageBins / top-layer bins are expanded views (row stride 0), rand.py:134-153."""
+    e1 = ((np.arange(1, 256) - 127.5) / 127.5) - 1. / 255.
+    D, B = 70, 3
+    rng = np.random.RandomState(2)
+    mu = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+    sc = rng.uniform(0.003, 0.5, (B, D)).astype(np.float32)
+    et = dev(e1).unsqueeze(0).expand(D, -1)
+    cdf = u32(hip().logistic_tables(et, dev(mu), dev(sc), 31, 8))
+    full = np.broadcast_to(e1[None], (D, 255))
+    for b in range(B):
+        _, want, _ = O.tables(O.logistic_pmf(full, mu[b].astype(np.float64), sc[b].astype(np.float64), O.MODE_DET), 31, 8)
+        assert np.array_equal(cdf[b][:, :257], want)
+
+
+@pytest.mark.parametrize("K", [64, 128, 256, 512, 1024, 2048])
+def test_logistic_fc_matches_tables(K):
+    q = int(np.log2(K))
+    rng = np.random.RandomState(K)
+    D, B = 37, 6
+    lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
+    e = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
+    mu = rng.randn(B, D).astype(np.float32)
+    sc = rng.uniform(0.1, 1, (B, D)).astype(np.float32)
+    sym = rng.randint(0, K, (B, D)).astype(np.int32)
+    sym[0, :4] = [0, K - 1, 1, K - 2]
+    status = torch.zeros(B, dtype=torch.int32, device=DEV)
+    f, c = hip().logistic_fc(dev(e), dev(mu), dev(sc), dev(sym), status, 31, q)
+    cdf = u32(hip().logistic_tables(dev(e), dev(mu), dev(sc), 31, q))
+    f, c = u32(f), u32(c)
+    for b in range(B):
+        _, want, _ = O.tables(O.logistic_pmf(e, mu[b].astype(np.float64), sc[b].astype(np.float64), O.MODE_DET), 31, q)
+        assert np.array_equal(cdf[b][:, : K + 1], want)
+        rows = np.arange(D)
+        assert np.array_equal(c[b], want[rows, sym[b]])
+        assert np.array_equal(f[b], want[rows, sym[b] + 1] - want[rows, sym[b]])
+    assert int(status.abs().max()) == 0
+    # out-of-range symbol is reported, not executed
+    bad = sym.copy()
+    bad[2, 5] = K
+    hip().logistic_fc(dev(e), dev(mu), dev(sc), dev(bad), status, 31, q)
+    assert status.cpu().tolist() == [0, 0, hip().ST_BADSYMBOL, 0, 0, 0]
+
+
+@pytest.mark.parametrize("name", ["ztop", "zuni", "x"])
+@pytest.mark.parametrize("aligned", [False, True])
+def test_rans_words_bit_exact_vs_reference(golden, name, aligned):
+    h = hip()
+    g = golden("tables_rans.npz")
+    K = g[f"{name}_cdf"].shape[1] - 1
+    D = g[f"{name}_cdf"].shape[0]
+    ld = h.aligned_ld(K) if aligned else K + 1
+    tab = np.zeros((D, ld), dtype=np.uint32)
+    tab[:, : K + 1] = g[f"{name}_cdf"]
+    cdf = dev(tab.view(np.int32))
+    B = 3  # the same chain three times + per-chain tables
+    s0 = words_to_state(g[f"{name}_state0"])
+    st = h.RansState.from_lists([s0] * B, cap=len(s0) + 2 * D + 8, device=DEV)
+    sym, _ = h.rans_pop(st, cdf.unsqueeze(0).expand(B, -1, -1).contiguous(), K)
+    st.check()
+    for b in range(B):
+        assert np.array_equal(sym[b].cpu().numpy(), g[f"{name}_pop_sym"])
+    assert st.to_lists() == [words_to_state(g[f"{name}_state_after_pop"])] * B
+    h.rans_push_table(st, cdf, sym, K)               # shared table, chain_stride 0
+    st.check()
+    assert st.to_lists() == [s0] * B
+    h.rans_push_table(st, cdf.unsqueeze(0).expand(B, -1, -1).contiguous(), dev(np.tile(g[f"{name}_push_sym"], (B, 1))), K)
+    st.check()
+    assert st.to_lists() == [words_to_state(g[f"{name}_state_after_push"])] * B
+
+
+def test_rans_push_fc_equals_push_table(golden):
+    h = hip()
+    g = golden("tables_rans.npz")
+    cdf_np = g["zuni_cdf"]
+    D, K = cdf_np.shape[0], cdf_np.shape[1] - 1
+    sym = g["zuni_push_sym"]
+    s0 = words_to_state(g["zuni_state0"])
+    st = h.RansState.from_lists([s0], cap=len(s0) + D + 8, device=DEV)
+    rows = np.arange(D)
+    f = (cdf_np[rows, sym + 1] - cdf_np[rows, sym]).astype(np.uint32).view(np.int32)[None]
+    c = cdf_np[rows, sym].astype(np.uint32).view(np.int32)[None]
+    h.rans_push(st, dev(f), dev(c))
+    st.check()
+    o = O.Stack(s0)
+    assert O.push(o, cdf_np, sym) == O.OK
+    assert st.to_lists()[0] == o.tolist()
+
+
+def test_status_codes():
+    h = hip()
+    K, D = 256, 300
+    p = np.full((D, K), 1.0 / K)
+    _, cdf, _ = h.table_rows(dev(p), 31, 8, ld=h.aligned_ld(K))
+    # underflow: a head and two words cannot feed 300 8-bit symbols
+    st = h.RansState.from_lists([[7, 9, 5 << 32], reference_init_state(400)], cap=1024, device=DEV)
+    sym, _ = h.rans_pop(st, cdf, K, B=2)
+    assert st.status.cpu().tolist() == [h.ST_UNDERFLOW, 0]
+    with pytest.raises(h.BitswapHipError):
+        st.check()
+    # sticky: the failed chain is skipped, the healthy one keeps working
+    before = st.to_lists()
+    h.rans_push_table(st, cdf, sym, K)
+    after = st.to_lists()
+    assert after[0] == before[0] and after[1] == reference_init_state(400)
+    # overflow: capacity too small for the pushed words
+    st = h.RansState.from_lists([reference_init_state(50)], cap=60, device=DEV)
+    s = torch.zeros((1, D), dtype=torch.int32, device=DEV)
+    h.rans_push_table(st, cdf, s, K)
+    assert st.status.cpu().tolist() == [h.ST_OVERFLOW]
+    # bad symbol
+    st = h.RansState.from_lists([reference_init_state(50)], cap=600, device=DEV)
+    s[0, 3] = K
+    h.rans_push_table(st, cdf, s, K)
+    assert st.status.cpu().tolist() == [h.ST_BADSYMBOL]
+
+
+def test_ans_class_drop_in(golden):
+    """The reference call pattern, verbatim: ANS(pmfs, bits, quantbits).decode(state) / .encode(state, sym)."""
+    from bitswap_amd.ans import ANS
+    g = golden("tables_rans.npz")
+    for name in ("ztop", "x"):
+        pmfs = dev(g[f"{name}_pmf_f64"])
+        q = int(g[f"{name}_quantbits"])
+        a = ANS(pmfs, bits=31, quantbits=q)
+        assert np.array_equal(a.pmfs, g[f"{name}_f"].astype(np.int64))
+        assert np.array_equal(a.cdfs, g[f"{name}_cdf"].astype(np.int64))
+        state = words_to_state(g[f"{name}_state0"])
+        same = state
+        state, sym = a.decode(state)
+        assert state is same and sym.dtype == torch.int64 and sym.is_cuda
+        assert np.array_equal(sym.cpu().numpy(), g[f"{name}_pop_sym"])
+        assert state == words_to_state(g[f"{name}_state_after_pop"])
+        state = ANS(pmfs, bits=31, quantbits=q).encode(state, sym)
+        assert state == words_to_state(g[f"{name}_state0"])
+        state = a.encode(state, [int(s) for s in g[f"{name}_push_sym"]])
+        assert state == words_to_state(g[f"{name}_state_after_push"])
+    a = ANS(dev(np.full((40, 16), 1 / 16)), 31, 4)
+    with pytest.raises(IndexError):
+        a.decode([3 << 32])
+
+
+@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
+def test_chain_replay_matches_reference_words(golden, sched):
+    """Teacher-forced replay of the reference sender through the HIP kernels: same popped symbols,
+    same per-operation state, same final word stream as the reference's Python run."""
+    h = hip()
+    g = golden(f"chain_mnist_small_{sched}.npz")
+    zend, xend, zcen = chain_tables(g)
+    zend_d = [dev(z) for z in zend]
+    xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)
+    B = 2
+    s0 = reference_init_state()
+    st = h.RansState.from_lists([s0] * B, cap=40000, device=DEV)
+    for i, (kind, tab, q) in enumerate(zip(g["op_kind"], g["op_table"], g["op_q"])):
+        e = xend_d if tab < 0 else zend_d[tab]
+        K = e.shape[1] + 1
+        mu = dev(np.tile(g[f"op{i}_mu"], (B, 1)))
+        sc = dev(np.tile(g[f"op{i}_scale"], (B, 1)))
+        if kind == 0:
+            cdf = h.logistic_tables(e, mu, sc, 31, int(q))
+            sym, z = h.rans_pop(st, cdf, K, centres=dev(zcen[tab]))
+            assert np.array_equal(sym[1].cpu().numpy(), g[f"op{i}_sym"])
+            want_z = zcen[tab][np.arange(zcen.shape[1]), g[f"op{i}_sym"]].astype(np.float32)
+            assert np.array_equal(z[0].cpu().numpy(), want_z)
+        else:
+            sym = dev(np.tile(g[f"op{i}_sym"].astype(np.int32), (B, 1)))
+            f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, int(q))
+            h.rans_push(st, f, c)
+        assert (st.len.cpu() + 1).tolist() == [int(g["op_nwords"][i])] * B
+        assert int(st.head[0].cpu().numpy().view(np.uint64)) == int(g["op_head"][i])
+    st.check()
+    assert st.to_lists() == [words_to_state(g["sent_words"])] * B
+
+
+def test_full_size_round_trip_property():
+    """BASELINE config sizes (D=2048, K=1024 latents; D=3072, K=256 pixels), 64 chains: bits-back
+    pop followed by push of the same symbols restores every state exactly; pushing then popping
+    returns the pushed symbols.  Size-independent property, no oracle needed."""
+    h = hip()
+    rng = np.random.RandomState(9)
+    for (D, K, q) in ((2048, 1024, 10), (3072, 256, 8)):
+        B = 64
+        lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
+        e = dev(np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)]))
+        mu = dev(rng.randn(B, D).astype(np.float32))
+        sc = dev(rng.uniform(0.1, 1.0, (B, D)).astype(np.float32))
+        states = [reference_init_state(3000, seed=100 + b) for b in range(B)]
+        st = h.RansState.from_lists(states, cap=3000 + D + 64, device=DEV)
+        cdf = h.logistic_tables(e, mu, sc, 31, q)
+        sym, _ = h.rans_pop(st, cdf, K)
+        f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, q)
+        h.rans_push(st, f, c)
+        st.check()
+        assert st.to_lists() == states
+        data = dev(rng.randint(0, K, (B, D)).astype(np.int32))
+        f, c = h.logistic_fc(e, mu, sc, data, st.status, 31, q)
+        h.rans_push(st, f, c)
+        back, _ = h.rans_pop(st, cdf, K)
+        st.check()
+        assert torch.equal(back, data)
+        assert st.to_lists() == states
+        # every cdf row is a valid table
+        t = u32(cdf[:4])[:, :, : K + 1].astype(np.int64)
+        assert np.all(t[:, :, 0] == 0) and np.all(t[:, :, -1] == 1 << 31) and np.all(np.diff(t, axis=2) >= 1)
