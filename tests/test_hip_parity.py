@@ -79,6 +79,9 @@ def test_logistic_tables_vs_oracle_and_reference(golden, name, ptype):
     mus = np.stack([mu] + [(mu + rng.randn(*mu.shape) * 0.1).astype(np.float32).astype(np.float64) for _ in range(B - 1)])
     scs = np.stack([sc] + [np.clip(sc * rng.uniform(0.8, 1.2, sc.shape), 1e-3, None).astype(np.float32).astype(np.float64)
                            for _ in range(B - 1)])
+    if ptype == torch.float32:   # the kernel converts float32 parameters to float64 exactly
+        mus, scs = mus.astype(np.float32).astype(np.float64), scs.astype(np.float32).astype(np.float64)
+    exact_inputs = np.array_equal(mus[0], mu) and np.array_equal(scs[0], sc)
     for ld in (K + 1, hip().aligned_ld(K)):
         cdf = hip().logistic_tables(dev(e), dev(mus, ptype), dev(scs, ptype), 31, q, ld=ld)
         got = u32(cdf)[:, :, : K + 1]
@@ -88,8 +91,9 @@ def test_logistic_tables_vs_oracle_and_reference(golden, name, ptype):
             assert np.array_equal(got[b], want), (name, b, ld)
         # chain 0 uses the fixture's parameters: compare with the reference's own integer table
         ref = g[f"{name}_cdf"].astype(np.int64)
-        mism = (np.diff(got[0].astype(np.int64), axis=1) != np.diff(ref, axis=1))
-        assert mism.mean() <= 2e-6
+        if exact_inputs:
+            mism = (np.diff(got[0].astype(np.int64), axis=1) != np.diff(ref, axis=1))
+            assert mism.mean() <= 2e-6
 
 
 def test_logistic_tables_shared_endpoint_row():
