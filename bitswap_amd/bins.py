@@ -1,0 +1,93 @@
+"""Latent discretization bins: mirror of the reference's discretization.py.
+
+`discretize(nz, quantbits, type, device, model, dataset)` returns (zendpoints [nz, Z, 2^q - 1],
+zcentres [nz, Z, 2^q]) exactly as discretization.py:9-99 does: the top layer has equal-mass bins
+under Logistic(0,1) (computed in float32 like the reference, :25-27), every lower layer has
+uniform-width bins per dimension between the minimum and maximum of samples drawn from the
+generative model (ancestral) and the inference model (posterior on training images), stored as
+float16 (:59-61).  File names of the cache (`bins/<ds>_nz<k>_z{endpoints,centres}<q>.pt`) are the
+reference's, so its published bins drop in.
+
+Differences: sampling runs on the device in one pass per layer; there are no datasets offline, so
+the caller supplies training images (`data`); scikit-learn's KBinsDiscretizer(strategy='uniform')
+is replaced by its closed form, numpy.linspace(min, max, K+1) on float64-cast samples (NumPy 2
+would otherwise return float16 edges for float16 samples -- SURVEY 7f).
+"""
+import os
+
+import numpy as np
+import torch
+
+from .rand import Bins, logistic_eps, transform
+
+
+def uniform_bins(mins, maxs, quantbits):
+    """Closed form of discretize_kbins(..., strategy='uniform') (discretization.py:105-118):
+    per dimension edges = numpy.linspace(min, max, K+1); endpoints = edges[1:-1],
+    centres = midpoints.  mins/maxs float64 [Z] -> ([Z, K-1], [Z, K]) float64."""
+    K = 1 << quantbits
+    mins, maxs = np.asarray(mins, dtype=np.float64), np.asarray(maxs, dtype=np.float64)
+    edges = np.stack([np.linspace(a, b, K + 1) for a, b in zip(mins, maxs)])
+    return edges[:, 1:-1], (edges[:, :-1] + edges[:, 1:]) / 2
+
+
+def top_bins(zdim_flat, quantbits):
+    """discretization.py:25-27 -- float32 zeros/ones on the CPU, like the reference."""
+    zb = Bins(torch.zeros((1, 1, zdim_flat)), torch.ones((1, 1, zdim_flat)), quantbits)
+    return zb.endpoints().numpy()[0, 0].astype(np.float64), zb.centres().numpy()[0, 0].astype(np.float64)
+
+
+def _cache_names(cache_dir, dataset, nz, quantbits):
+    return (os.path.join(cache_dir, f"{dataset}_nz{nz}_zendpoints{quantbits}.pt"),
+            os.path.join(cache_dir, f"{dataset}_nz{nz}_zcentres{quantbits}.pt"))
+
+
+def discretize(nz, quantbits, type, device, model, dataset, data=None, ppb=30, cache_dir="bins", batch=128,
+               save=True):
+    """Same positional signature as the reference.  `data`: uint8/float images [N, C, 32, 32] in
+    [0, 255] used for the posterior samples when no cached bins exist."""
+    fe, fc = _cache_names(cache_dir, dataset, nz, quantbits)
+    if os.path.exists(fe) and os.path.exists(fc):
+        zendpoints = torch.load(fe, map_location="cpu")
+        zcentres = torch.load(fc, map_location="cpu")
+        return zendpoints.type(type).to(device), zcentres.type(type).to(device)
+
+    K = 1 << quantbits
+    Z = int(np.prod(model.zdim))
+    nsamples = ppb * K
+    zendpoints = np.zeros((nz, Z, K - 1))
+    zcentres = np.zeros((nz, Z, K))
+    zendpoints[nz - 1], zcentres[nz - 1] = top_bins(Z, quantbits)
+    if nz > 1:
+        if data is None:
+            raise FileNotFoundError(f"{fe} not found and no training images given to sample the bins from")
+        data = torch.as_tensor(data)
+        was_compressing = model.compressing
+        model.compress(False)
+        dev = torch.device(device)
+        nb = (nsamples + batch - 1) // batch
+        with torch.no_grad():
+            gen = torch.zeros((nz, nsamples) + tuple(model.zdim), dtype=torch.float16, device=dev)
+            inf = torch.zeros((nz, nsamples) + tuple(model.zdim), dtype=torch.float16, device=dev)
+            gen[-1] = logistic_eps((nsamples,) + tuple(model.zdim), device=dev, bound=1e-30).half()
+            idx = torch.randint(0, data.shape[0], (nsamples,))
+            for zi in reversed(range(1, nz)):
+                li = nz - zi - 1   # inference layer sampled in this round (discretization.py:73-78)
+                for bi in range(nb):
+                    sl = slice(bi * batch, min(nsamples, (bi + 1) * batch))
+                    mu, scale = model.generate(zi)(given=gen[zi][sl].float())
+                    gen[zi - 1][sl] = transform(logistic_eps(mu.shape, device=dev, bound=1e-30), mu, scale).half()
+                    given = data[idx[sl]].to(dev).float() if li == 0 else inf[li - 1][sl].float()
+                    mu, scale = model.infer(li)(given=given)
+                    inf[li][sl] = transform(logistic_eps(mu.shape, device=dev, bound=1e-30), mu, scale).half()
+            for zi in range(nz - 1):
+                s = torch.cat([gen[zi], inf[zi]], dim=0).reshape(-1, Z).double()
+                zendpoints[zi], zcentres[zi] = uniform_bins(s.min(0).values.cpu().numpy(),
+                                                            s.max(0).values.cpu().numpy(), quantbits)
+        model.compress(was_compressing)
+    zendpoints, zcentres = torch.from_numpy(zendpoints), torch.from_numpy(zcentres)
+    if save:
+        os.makedirs(cache_dir, exist_ok=True)
+        torch.save(zendpoints, fe)
+        torch.save(zcentres, fc)
+    return zendpoints.type(type).to(device), zcentres.type(type).to(device)

@@ -1,0 +1,267 @@
+"""Batched Bit-Swap / BB-ANS coding schedules over B independent chains held in HBM.
+
+This replaces the per-image Python loops of the reference's `compress()` functions
+(sender mnist_compress.py:164-263, receiver :277-358; Bit-Swap :176-205 / :293-319, BB-ANS
+:206-243 / :321-354, prior :245-251 / :284-291).  One "block step" codes one 32x32 block of every
+chain in lock-step: the conv stacks see a [B, ...] batch, the table kernels see B*D rows, the rANS
+kernels one chain per wavefront / lane.  Nothing in a step synchronises with the host; word counts
+for the bit accounting are snapshotted on the device.
+
+The arithmetic back-end is an object with the interface of `HipBackend` below.  The product
+constructs only `HipBackend` (HIP kernels through the C ABI, no fallback).  tests/ and bench.py's
+cpu_baseline leg may pass the oracle-backed stand-in from oracle/backend.py to run the very same
+schedule code on the CPU.
+"""
+import numpy as np
+import torch
+
+from . import hip
+from .rand import Bins, ImageBins
+
+
+class HipBackend:
+    """HIP kernels behind include/bitswap_hip.h.  All tensors live on one HIP device."""
+
+    name = "hip"
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise hip.BitswapHipError("HipBackend needs a HIP device: bitswap_amd has no CPU coding path")
+        hip.load()
+
+    def new_state(self, states, cap):
+        return hip.RansState.from_lists(states, cap=cap, device=self.device)
+
+    def tables(self, endpoints, mu, scale, quantbits, bits, out=None):
+        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out)
+
+    def pop(self, state, cdf, K, bits, centres=None):
+        return hip.rans_pop(state, cdf, K, bits, centres=centres)
+
+    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits):
+        f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits)
+        hip.rans_push(state, f, c, bits)
+
+    def push_table(self, state, cdf, sym, K, bits):
+        hip.rans_push_table(state, cdf, sym, K, bits)
+
+    def centres(self, centres, sym):
+        return hip.gather_centres(centres, sym)
+
+    def check(self, state, what):
+        state.check(what)
+
+
+def initial_states(nchains, nwords=10000, seed=100):
+    """The reference's stream initialisation (mnist_compress.py:94,158-159): numpy seeded once with
+    100, then 10000 'random' uint32 words per experiment, the last shifted up to form the head."""
+    np.random.seed(seed)
+    out = []
+    for _ in range(nchains):
+        s = list(map(int, np.random.randint(low=1 << 16, high=(1 << 32) - 1, size=nwords, dtype=np.uint32)))
+        s[-1] = s[-1] << 32
+        out.append(s)
+    return out
+
+
+class Timeline:
+    """Optional per-category device timing with events on the launch stream (used by bench.py)."""
+
+    def __init__(self, enabled=False):
+        self.enabled = enabled
+        self.spans = {}
+
+    def span(self, key):
+        return _Span(self, key)
+
+    def totals(self):
+        """-> {key: (seconds, count)}; synchronises."""
+        if self.enabled:
+            torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) * 1e-3, len(v)) for k, v in self.spans.items()}
+
+    def reset(self):
+        self.spans = {}
+
+
+class _Span:
+    def __init__(self, tl, key):
+        self.tl, self.key = tl, key
+
+    def __enter__(self):
+        if self.tl.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.tl.enabled:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.tl.spans.setdefault(self.key, []).append((self.a, b))
+
+
+class BitSwapCodec:
+    """Sender and receiver for B chains.
+
+    model       bitswap_amd.model.Model (eval mode, on the backend's device); used in compress mode
+    zendpoints  [nz, Z, K-1] float64, zcentres [nz, Z, K] float64 (discretize(), bins.py)
+    bitswap     True: Bit-Swap schedule; False: BB-ANS (all pops, then all pushes)
+    """
+
+    def __init__(self, model, zendpoints, zcentres, quantbits=10, bitswap=True, ansbits=31, backend=None,
+                 timeline=None):
+        self.backend = backend if backend is not None else HipBackend(zendpoints.device)
+        self.model = model
+        self.nz = model.nz
+        self.q, self.K, self.bits = quantbits, 1 << quantbits, ansbits
+        self.bitswap = bool(bitswap)
+        self.Z, self.X = model.zdim_flat, model.xdim
+        dev = zendpoints.device
+        self.device = dev
+        assert zendpoints.shape == (self.nz, self.Z, self.K - 1) and zcentres.shape == (self.nz, self.Z, self.K)
+        self.zend = [zendpoints[i].contiguous() for i in range(self.nz)]
+        self.zcen = [zcentres[i].contiguous() for i in range(self.nz)]
+        xb = ImageBins(torch.float64, dev, self.X)
+        self.xend, self.xcen = xb.endpoints(), xb.centres()   # expanded views, row stride 0
+        self.tl = timeline or Timeline(False)
+        self._cdf_buf = None
+        # the prior p(z_L) = Logistic(0,1) table does not depend on the image: build it once
+        # (the reference rebuilds it for every image, mnist_compress.py:246-251)
+        one = torch.ones((1, self.Z), dtype=torch.float32, device=dev)
+        self.prior_cdf = self.backend.tables(self.zend[-1], torch.zeros_like(one), one, self.q, self.bits)[0]
+        model.compress(True)
+
+    # ------------------------------------------------------------------------------------------
+    def new_states(self, nchains, nblocks, nwords=10000, seed=100, states=None):
+        states = states if states is not None else initial_states(nchains, nwords, seed)
+        worst = int(self.X * 9.5 / 32) + 64   # words a block can add on incompressible data
+        cap = max(len(s) for s in states) + nblocks * worst + 4 * self.Z
+        return self.backend.new_state(states, cap)
+
+    def _cdf(self, B):
+        ld = hip.aligned_ld(self.K)
+        if self._cdf_buf is None or self._cdf_buf.shape[0] != B:
+            self._cdf_buf = torch.empty((B, self.Z, ld), dtype=torch.int32, device=self.device)
+        return self._cdf_buf
+
+    def _pop_layer(self, state, endpoints, centres, mu, scale, quantbits, K, key):
+        with self.tl.span("tables_" + key):
+            cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
+                                      out=self._cdf(mu.shape[0]) if K == self.K else None)
+        with self.tl.span("pop_" + key):
+            return self.backend.pop(state, cdf, K, self.bits, centres=centres)
+
+    def _push_layer(self, state, endpoints, mu, scale, sym, quantbits, key):
+        with self.tl.span("push_" + key):
+            self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits)
+
+    def _net(self, fn, given):
+        with self.tl.span("net"), torch.no_grad():
+            mu, scale = fn(given)
+        return mu.contiguous(), scale.contiguous()
+
+    # ------------------------------------------------------------------------------------------
+    def encode_block(self, state, x, rest_len=None):
+        """Sender, one block per chain.  x [B, X] integer pixels.  If `rest_len` is a tensor it
+        receives the word count right after the first bits-back pop(s) (restbits, :191-193,225-227)."""
+        m, nz = self.model, self.nz
+        x = x.to(self.device, torch.int32).contiguous()
+        given = self.backend.centres(self.xcen, x)            # xcentres[xrange, x] -> float32
+        if self.bitswap:
+            zsym = None
+            for zi in range(nz):
+                mu, sc = self._net(m.infer(zi), given)
+                zsymtop, z = self._pop_layer(state, self.zend[zi], self.zcen[zi], mu, sc, self.q, self.K, "z")
+                if rest_len is not None and zi == 0:
+                    rest_len.copy_(state.len)
+                mu, sc = self._net(m.generate(zi), z)
+                if zi == 0:
+                    self._push_layer(state, self.xend, mu, sc, x, 8, "x")
+                else:
+                    self._push_layer(state, self.zend[zi - 1], mu, sc, zsym, self.q, "z")
+                zsym, given = zsymtop, z
+        else:
+            syms, zs = [], []
+            for zi in range(nz):
+                mu, sc = self._net(m.infer(zi), given)
+                s, z = self._pop_layer(state, self.zend[zi], self.zcen[zi], mu, sc, self.q, self.K, "z")
+                syms.append(s)
+                zs.append(z)
+                given = z
+            if rest_len is not None:
+                rest_len.copy_(state.len)
+            for zi in range(nz):
+                mu, sc = self._net(m.generate(zi), zs[zi])
+                if zi == 0:
+                    self._push_layer(state, self.xend, mu, sc, x, 8, "x")
+                else:
+                    self._push_layer(state, self.zend[zi - 1], mu, sc, syms[zi - 1], self.q, "z")
+            zsymtop = syms[-1]
+        with self.tl.span("push_prior"):
+            self.backend.push_table(state, self.prior_cdf, zsymtop, self.K, self.bits)
+
+    def decode_block(self, state):
+        """Receiver, one block per chain (exact mirror).  Returns x [B, X] int32."""
+        m, nz = self.model, self.nz
+        with self.tl.span("pop_prior"):
+            # prior table [Z, ld] is shared by every chain (chain stride 0)
+            zsymtop, z = self.backend.pop(state, self.prior_cdf, self.K, self.bits, centres=self.zcen[-1])
+        if self.bitswap:
+            for zi in reversed(range(nz)):
+                mu, sc = self._net(m.generate(zi), z)
+                if zi == 0:
+                    sym, given = self._pop_layer(state, self.xend, self.xcen, mu, sc, 8, 256, "x")
+                else:
+                    sym, given = self._pop_layer(state, self.zend[zi - 1], self.zcen[zi - 1], mu, sc, self.q,
+                                                 self.K, "z")
+                mu, sc = self._net(m.infer(zi), given)
+                self._push_layer(state, self.zend[zi], mu, sc, zsymtop, self.q, "z")
+                zsymtop, z = sym, given
+            return zsymtop
+        syms, cens = [zsymtop], [z]
+        for zi in reversed(range(nz)):
+            mu, sc = self._net(m.generate(zi), cens[-1])
+            if zi == 0:
+                s, c = self._pop_layer(state, self.xend, self.xcen, mu, sc, 8, 256, "x")
+            else:
+                s, c = self._pop_layer(state, self.zend[zi - 1], self.zcen[zi - 1], mu, sc, self.q, self.K, "z")
+            syms.append(s)
+            cens.append(c)
+        # syms = [z_L, ..., z_1, x]; push z_L .. z_1 back under q(z_i | z_{i-1} or x)
+        for k, zi in enumerate(reversed(range(nz))):
+            mu, sc = self._net(m.infer(zi), cens[k + 1])
+            self._push_layer(state, self.zend[zi], mu, sc, syms[k], self.q, "z")
+        return syms[-1]
+
+    # ------------------------------------------------------------------------------------------
+    def compress(self, images, state=None, nwords=10000, seed=100):
+        """images [B, nblocks, X] integers -> (state, metrics).  metrics follow the reference's bit
+        accounting (mnist_compress.py:253-261): nets, cma, total as float arrays [B, nblocks]."""
+        images = torch.as_tensor(images)
+        B, n, X = images.shape
+        assert X == self.X
+        if state is None:
+            state = self.new_states(B, n, nwords, seed)
+        init_len = state.len.clone()
+        rest_len = torch.zeros_like(state.len)
+        lens = torch.zeros((n, B), dtype=torch.int32, device=state.len.device)
+        for xi in range(n):
+            self.encode_block(state, images[:, xi], rest_len if xi == 0 else None)
+            lens[xi].copy_(state.len)
+        self.backend.check(state, "compress")
+        lens, init_len, rest_len = lens.cpu().numpy().T.astype(np.int64), init_len.cpu().numpy(), rest_len.cpu().numpy()
+        added = (lens - init_len[:, None]) * 32                      # totaladdedbits (:254)
+        total = (lens - rest_len[:, None] + 1) * 32                  # totalbits (:255): len(restbits)-1 = rest words
+        cumnet = added / X
+        nets = np.diff(np.concatenate([np.zeros((B, 1)), cumnet], axis=1), axis=1)   # (:258)
+        cma = total / (X * np.arange(1, n + 1)[None, :])                             # (:260)
+        return state, dict(nets=nets, cma=cma, total=total.astype(np.float64), rest_len=rest_len, init_len=init_len)
+
+    def decompress(self, state, nblocks):
+        """-> images [B, nblocks, X] int32 (blocks in original order); state is unwound in place."""
+        out = [None] * nblocks
+        for xi in reversed(range(nblocks)):
+            out[xi] = self.decode_block(state)
+        self.backend.check(state, "decompress")
+        return torch.stack(out, dim=1)

@@ -1,0 +1,338 @@
+"""Hierarchical-VAE `Model` for the compression path (PyTorch-ROCm modules; convs run on
+MIOpen/hipBLASLt -- the only MFMA-shaped work on the path).
+
+Mirrors the class surface of the reference's Model (model/mnist_train.py:17-438; the cifar /
+imagenet variants are identical, imagenetcrop_train.py:306-315,417 makes gen_std a conv):
+same constructor arguments, same `compress()/infer(i)/generate(i)/loss()` methods and the same
+state-dict keys, so reference checkpoints (`model/params/<ds>/nz<k>`) load unchanged.
+
+What is different, MI355X-first:
+  * no tensorboard logger is created at construction (reference :54-61 side effect);
+  * weight normalisation w = v * g / (||v|| + 1e-10) (utils/torch/modules.py:98-106) is folded
+    ONCE into a cached conv weight (`fold()`), not recomputed on every forward;
+  * compress mode accepts a whole batch of chains [B, D] and returns float32 [B, D]
+    (the reference asserts batch == 1, :372,431, and round-trips through float64);
+    1-D inputs keep the reference behaviour (output dtype = input dtype);
+  * `nn_batch`: convs always run on micro-batches of one fixed shape (zero padded), so a
+    sample's (mu, scale) bits do not depend on how many chains are coded together -- the
+    decoder must reproduce the encoder's parameters bit for bit.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+_SMALL = 1e-10  # utils/torch/modules.py:14
+
+
+def softplus(x):
+    """-logsigmoid(-x), the reference's numerically stable softplus (modules.py:112-114)."""
+    return -F.logsigmoid(-x)
+
+
+class WnConv2d(nn.Module):
+    """Weight-normalised conv (modules.py:57-109): parameters v, gain, b with identical names."""
+
+    def __init__(self, in_dim, out_dim, kernel_size, stride, padding, init_scale=1.0, loggain=True, bias=True):
+        super().__init__()
+        self.in_dim, self.out_dim, self.kernel_size = in_dim, out_dim, kernel_size
+        self.stride, self.padding, self.init_scale, self.loggain = stride, padding, init_scale, loggain
+        self.v = nn.Parameter(torch.empty(out_dim, in_dim, kernel_size, kernel_size))
+        self.gain = nn.Parameter(torch.empty(out_dim))
+        self.b = nn.Parameter(torch.empty(out_dim), requires_grad=bias)
+        nn.init.normal_(self.v, 0.0, 0.05)
+        (nn.init.zeros_ if loggain else nn.init.ones_)(self.gain)
+        nn.init.zeros_(self.b)
+        self._w = None
+
+    def weight(self):
+        g = softplus(self.gain) if self.loggain else self.gain
+        vnorm = self.v.view(self.out_dim, -1).norm(p=2, dim=1)
+        return self.v * (g / (vnorm + _SMALL)).view(self.out_dim, 1, 1, 1)
+
+    def fold(self):
+        with torch.no_grad():
+            self._w = self.weight().contiguous()
+
+    def unfold(self):
+        self._w = None
+
+    def forward(self, x):
+        w = self._w if self._w is not None else self.weight()
+        return F.conv2d(x, w, self.b, stride=self.stride, padding=self.padding)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._w = None
+        return super()._load_from_state_dict(*a, **k)
+
+
+class Pass(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class Squeeze2d(nn.Module):
+    """[C,H,W] -> [C*f*f, H/f, W/f] (modules.py:169-191)."""
+
+    def __init__(self, factor=2):
+        super().__init__()
+        self.factor = factor
+
+    def forward(self, x):
+        f = self.factor
+        n, c, h, w = x.shape
+        x = x.view(n, c, h // f, f, w // f, f).permute(0, 1, 3, 5, 2, 4)
+        return x.reshape(n, c * f * f, h // f, w // f)
+
+
+class UnSqueeze2d(nn.Module):
+    """[C,H,W] -> [C/f/f, H*f, W*f] (modules.py:194-213)."""
+
+    def __init__(self, factor=2):
+        super().__init__()
+        self.factor = factor
+
+    def forward(self, x):
+        f = self.factor
+        n, c, h, w = x.shape
+        x = x.view(n, c // (f * f), f, f, h, w).permute(0, 1, 4, 2, 5, 3)
+        return x.reshape(n, c // (f * f), h * f, w * f)
+
+
+class ResNetLayer(nn.Module):
+    """x + conv2(act(conv1(act(x)))) (modules.py:216-241); dropout is identity at p = 0 / eval."""
+
+    def __init__(self, inchannels, outchannels, kernel_size, padding, dropout_p, act):
+        super().__init__()
+        self.act = act
+        self.conv1 = WnConv2d(inchannels, outchannels, kernel_size, 1, padding, init_scale=1.0, loggain=True)
+        self.dropout = nn.Dropout(dropout_p)
+        self.dropout_p = dropout_p
+        self.conv2 = WnConv2d(outchannels, outchannels, kernel_size, 1, padding, init_scale=0.0, loggain=False)
+
+    def forward(self, x):
+        h = self.act(self.conv1(self.act(x)))
+        if self.dropout_p > 0.0:
+            h = self.dropout(h)
+        return x + self.conv2(h)
+
+
+def _resblock(width, kernel_size, padding, nlayers, dropout_p, act):
+    """ResNetBlock (modules.py:244-250): a Sequential whose children are named res<C>layer<i>."""
+    blk = nn.Sequential()
+    for i in range(nlayers):
+        blk.add_module(f"res{width}layer{i + 1}", ResNetLayer(width, width, kernel_size, padding, dropout_p, act))
+    return blk
+
+
+class Model(nn.Module):
+    def __init__(self, xs=(3, 32, 32), nz=1, zchannels=16, nprocessing=1, kernel_size=3, resdepth=2,
+                 reswidth=256, dropout_p=0., tag='', root_process=True, conditional_gen_std=False, nn_batch=None):
+        super().__init__()
+        self.compressing = False
+        self.xs, self.nz, self.zchannels, self.nprocessing = tuple(xs), nz, zchannels, nprocessing
+        self.zdim = (zchannels, 16, 16)
+        self.resdepth, self.reswidth, self.kernel_size = resdepth, reswidth, kernel_size
+        self.bitsscale = np.log2(np.e)
+        self.perdimsscale = 1. / np.prod(self.xs)
+        self.tag = tag
+        self.best_elbo = np.inf
+        self.nn_batch = nn_batch
+        self.conditional_gen_std = conditional_gen_std
+        pad5, pad = 2, (kernel_size - 1) // 2
+        assert kernel_size % 2 == 1
+
+        # ResNet layers dealt round-robin over the latent layers (mnist_train.py:66-72)
+        depth = [0] * nz
+        for k in range(resdepth):
+            depth[k % nz] += 1
+        scale = 1.0 / (nz ** 0.5)
+        W, C, X4 = reswidth, zchannels, 4 * xs[0]
+
+        self.softplus, self.sigmoid, self.act, self.actresnet = nn.Softplus(), nn.Sigmoid(), nn.ELU(), nn.ELU()
+        act, actres = self.act, self.actresnet
+
+        def conv_in(cin, k, p):
+            return nn.Sequential(WnConv2d(cin, W, k, 1, p, init_scale=1.0, loggain=True), act)
+
+        def res(k, p, n):
+            return nn.Sequential(_resblock(W, k, p, n, dropout_p, actres), act) if n > 0 else Pass()
+
+        def head(cout, s):
+            return WnConv2d(W, cout, kernel_size, 1, pad, init_scale=s)
+
+        # inference model, bottom layer (x -> z1)
+        self.infer_in = nn.Sequential(Squeeze2d(2), WnConv2d(X4, W, 5, 1, pad5, init_scale=1.0, loggain=True), act)
+        self.infer_res0 = res(5, pad5, nprocessing)
+        self.infer_res1 = res(kernel_size, pad, depth[0])
+        top = scale if nz > 1 else 2 ** 0.5 * scale
+        self.infer_mu = head(C, top)
+        self.infer_std = head(C, top)
+        # deeper inference layers (z_i -> z_{i+1})
+        self.deepinfer_in = nn.ModuleList([conv_in(C, kernel_size, pad) for _ in range(nz - 1)])
+        self.deepinfer_res = nn.ModuleList([res(kernel_size, pad, depth[i + 1]) for i in range(nz - 1)])
+        self.deepinfer_mu = nn.ModuleList(
+            [nn.Sequential(head(C, scale if i < nz - 2 else 2 ** 0.5 * scale)) for i in range(nz - 1)])
+        self.deepinfer_std = nn.ModuleList(
+            [nn.Sequential(head(C, scale if i < nz - 2 else 2 ** 0.5 * scale)) for i in range(nz - 1)])
+        # deeper generative layers (z_{i+1} -> z_i)
+        self.deepgen_in = nn.ModuleList([conv_in(C, kernel_size, pad) for _ in range(nz - 1)])
+        self.deepgen_res = nn.ModuleList([res(kernel_size, pad, depth[i + 1]) for i in range(nz - 1)])
+        self.deepgen_mu = nn.ModuleList([nn.Sequential(head(C, scale)) for _ in range(nz - 1)])
+        self.deepgen_std = nn.ModuleList([nn.Sequential(head(C, scale)) for _ in range(nz - 1)])
+        # generative model, bottom layer (z1 -> x)
+        self.gen_in = conv_in(C, kernel_size, pad)
+        self.gen_res1 = res(kernel_size, pad, depth[0])
+        self.gen_res0 = res(5, pad5, nprocessing)
+        self.gen_mu = nn.Sequential(head(X4, 0.1), UnSqueeze2d(2))
+        if conditional_gen_std:   # imagenetcrop_train.py:306-315
+            self.gen_std = nn.Sequential(head(X4, 0.1), UnSqueeze2d(2))
+        else:                     # mnist_train.py:306-308
+            self.gen_std = nn.Parameter(torch.zeros(*self.xs))
+
+    # ----------------------------------------------------------------------------------------
+    def compress(self, compress=True):
+        self.compressing = compress
+
+    def fold(self):
+        """Cache the weight-normalised conv weights (call after loading a checkpoint, in eval)."""
+        for m in self.modules():
+            if isinstance(m, WnConv2d):
+                m.fold()
+        return self
+
+    def unfold(self):
+        for m in self.modules():
+            if isinstance(m, WnConv2d):
+                m.unfold()
+        return self
+
+    @property
+    def xdim(self):
+        return int(np.prod(self.xs))
+
+    @property
+    def zdim_flat(self):
+        return int(np.prod(self.zdim))
+
+    # the conv stacks proper, on a [n, C, H, W] float32 batch -------------------------------
+    def _infer_stack(self, i, h):
+        if i == 0:
+            h = self.infer_res1(self.infer_res0(self.infer_in(h)))
+            mu = self.infer_mu(h)
+            scale = 0.1 + 0.9 * self.sigmoid(self.infer_std(h) + 2.)
+        else:
+            h = self.deepinfer_res[i - 1](self.deepinfer_in[i - 1](h))
+            mu = self.deepinfer_mu[i - 1](h)
+            scale = 0.1 + 0.9 * self.sigmoid(self.deepinfer_std[i - 1](h) + 2.)
+        return mu, scale
+
+    def _gen_stack(self, i, h):
+        if i == 0:
+            h = self.gen_res0(self.gen_res1(self.gen_in(h)))
+            mu = self.gen_mu(h)
+            std = self.gen_std(h) if self.conditional_gen_std else self.gen_std
+            scale = ((2. / 255.) / 8.) + softplus(std)
+        else:
+            h = self.deepgen_res[i - 1](self.deepgen_in[i - 1](h))
+            mu = self.deepgen_mu[i - 1](h)
+            scale = 0.1 + 0.9 * softplus(self.deepgen_std[i - 1](h) + np.log(np.exp(1.) - 1.))
+        return mu, scale
+
+    def _chunked(self, fn, h, out_shape):
+        """Run fn on fixed-shape micro-batches so results are independent of the chain count."""
+        nb = self.nn_batch
+        n = h.shape[0]
+        if not nb or n == nb:
+            mu, sc = fn(h)
+            return mu, sc.expand_as(mu)
+        mus, scs = [], []
+        for s in range(0, n, nb):
+            part = h[s:s + nb]
+            k = part.shape[0]
+            if k < nb:
+                part = torch.cat([part, part.new_zeros((nb - k,) + tuple(part.shape[1:]))], 0)
+            mu, sc = fn(part)
+            mus.append(mu[:k])
+            scs.append(sc.expand_as(mu)[:k])
+        return torch.cat(mus, 0), torch.cat(scs, 0)
+
+    # ----------------------------------------------------------------------------------------
+    def infer(self, i):
+        def distribution(given):
+            h = given
+            if self.compressing:
+                flat1d = h.dim() == 1
+                in_dtype = h.dtype
+                h = h.float().view((-1,) + (self.xs if i == 0 else self.zdim))
+                mu, scale = self._chunked(lambda t: self._infer_stack(i, t), h, None)
+                mu, scale = mu.reshape(mu.shape[0], -1), scale.reshape(scale.shape[0], -1)
+                if flat1d:  # reference behaviour: batch of one, flattened, back in the input dtype
+                    assert mu.shape[0] == 1
+                    return mu.view(-1).to(in_dtype), scale.view(-1).to(in_dtype)
+                return mu, scale
+            if i == 0:
+                h = (h - 127.5) / 127.5
+            return self._infer_stack(i, h)
+        return distribution
+
+    def generate(self, i):
+        def distribution(given):
+            h = given
+            if self.compressing:
+                flat1d = h.dim() == 1
+                in_dtype = h.dtype
+                h = h.float().view((-1,) + self.zdim)
+                mu, scale = self._chunked(lambda t: self._gen_stack(i, t), h, None)
+                mu, scale = mu.reshape(mu.shape[0], -1), scale.reshape(scale.shape[0], -1).contiguous()
+                if flat1d:
+                    assert mu.shape[0] == 1
+                    return mu.view(-1).to(in_dtype), scale.view(-1).to(in_dtype)
+                return mu, scale
+            return self._gen_stack(i, h)
+        return distribution
+
+    # ELBO terms for the `elbos` metric of the CLIs (mnist_train.py:441-490) ------------------
+    def loss(self, x):
+        from . import rand as random
+        B = x.shape[0]
+        logenc = torch.zeros((self.nz, B, self.zdim[0]), device=x.device)
+        logdec = torch.zeros((self.nz, B, self.zdim[0]), device=x.device)
+        zsamples = torch.zeros((self.nz, B, self.zdim_flat), device=x.device)
+        z = None
+        for i in range(self.nz):
+            mu, scale = self.infer(i)(given=x if i == 0 else z)
+            z_next = random.transform(random.logistic_eps(mu.shape, device=mu.device), mu, scale)
+            zsamples[i] = z_next.flatten(1)
+            logenc[i] += torch.sum(random.logistic_logp(mu, scale, z_next), dim=2)
+            mu, scale = self.generate(i)(given=z_next)
+            if i == 0:
+                logrecon = torch.sum(random.discretized_logistic_logp(mu, scale, x), dim=1)
+            else:
+                logdec[i - 1] += torch.sum(random.logistic_logp(mu, scale, z), dim=2)
+            z = z_next
+        one, zero = torch.ones(1, device=x.device), torch.zeros(1, device=x.device)
+        logdec[self.nz - 1] += torch.sum(random.logistic_logp(zero, one, z), dim=2)
+        logenc = torch.mean(logenc, dim=1) * self.bitsscale
+        logdec = torch.mean(logdec, dim=1) * self.bitsscale
+        logrecon = torch.mean(logrecon) * self.bitsscale
+        return logrecon, logdec, logenc, zsamples
+
+
+# dataset presets of the reference CLIs ----------------------------------------------------------
+def preset(dataset, nz, **kw):
+    """Model configured like <dataset>_compress.py (widths: mnist_compress.py:81-88,
+    cifar_compress.py:80-87, imagenet_compress.py:83-90, imagenetcrop_compress.py:100)."""
+    if dataset == "mnist":
+        w = {8: 61, 4: 62, 2: 63}.get(nz, 64)
+        return Model(xs=(1, 32, 32), nz=nz, zchannels=1, nprocessing=4, kernel_size=3, resdepth=8, reswidth=w, **kw)
+    if dataset == "cifar":
+        w = {8: 252, 4: 254, 2: 255}.get(nz, 256)
+        return Model(xs=(3, 32, 32), nz=nz, zchannels=8, nprocessing=4, kernel_size=3, resdepth=8, reswidth=w, **kw)
+    if dataset == "imagenet":
+        w = {8: 252, 4: 254, 2: 255}.get(nz, 256)
+        return Model(xs=(3, 32, 32), nz=nz, zchannels=8, nprocessing=4, kernel_size=3, resdepth=8, reswidth=w, **kw)
+    if dataset == "imagenetcrop":
+        return Model(xs=(3, 32, 32), nz=nz, zchannels=8, nprocessing=4, kernel_size=3, resdepth=8, reswidth=256,
+                     conditional_gen_std=True, **kw)
+    raise ValueError(dataset)

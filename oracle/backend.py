@@ -1,0 +1,107 @@
+"""Oracle-backed stand-in for bitswap_amd.codec.HipBackend -- TEST INFRASTRUCTURE ONLY.
+
+Lets tests/ and bench.py's cpu_baseline leg run the package's schedule code (codec.py) on the
+CPU with the C restatement of the reference doing the arithmetic.  Never constructed by the
+product: bitswap_amd imports nothing from oracle/.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import oracle as O
+
+
+class _Tables:
+    """Lazy 'cdf rows' handle: the oracle rebuilds each row inside layer_pop/layer_push."""
+
+    def __init__(self, endpoints, mu, scale, quantbits, shared=False):
+        self.e, self.mu, self.scale, self.q, self.shared = endpoints, mu, scale, quantbits, shared
+
+    def __getitem__(self, i):
+        return _Tables(self.e, self.mu[i:i + 1], self.scale[i:i + 1], self.q, shared=True)
+
+
+class OracleState:
+    def __init__(self, states, cap):
+        self.stacks = [O.Stack(s, cap=cap) for s in states]
+        self.B = len(states)
+        self.rc = np.zeros(self.B, dtype=np.int32)
+
+    @property
+    def len(self):
+        return torch.tensor([int(s.len[0]) for s in self.stacks], dtype=torch.int32)
+
+    @property
+    def status(self):
+        return torch.from_numpy(self.rc)
+
+    def to_lists(self):
+        return [s.tolist() for s in self.stacks]
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self, mode=O.MODE_DET, threads=1):
+        self.mode, self.threads = mode, threads
+        self.device = torch.device("cpu")
+        self.pool = ThreadPoolExecutor(threads) if threads > 1 else None
+
+    def _map(self, fn, n):
+        if self.pool is None:
+            return [fn(b) for b in range(n)]
+        return list(self.pool.map(fn, range(n)))
+
+    @staticmethod
+    def _np(t):
+        return np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t)
+
+    def new_state(self, states, cap):
+        return OracleState(states, cap)
+
+    def tables(self, endpoints, mu, scale, quantbits, bits, out=None):
+        return _Tables(self._np(endpoints).astype(np.float64), self._np(mu).astype(np.float64),
+                       self._np(scale).astype(np.float64), quantbits)
+
+    def pop(self, state, t, K, bits, centres=None):
+        def one(b):
+            if state.rc[b]:
+                return np.zeros(t.e.shape[0], dtype=np.int32)
+            i = 0 if t.shared else b
+            sym, rc = O.layer_pop(state.stacks[b], t.e, t.mu[i], t.scale[i], bits, t.q, self.mode)
+            state.rc[b] = rc
+            if rc:
+                sym[:] = 0   # sticky failure (e.g. too few initial bits); reported by check()
+            return sym
+        sym = torch.from_numpy(np.stack(self._map(one, state.B)))
+        z = self.centres(centres, sym) if centres is not None else None
+        return sym, z
+
+    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits):
+        e, mu, scale = self._np(endpoints).astype(np.float64), self._np(mu).astype(np.float64), self._np(scale).astype(np.float64)
+        sym = self._np(sym).astype(np.int32)
+
+        def one(b):
+            if not state.rc[b]:
+                state.rc[b] = O.layer_push(state.stacks[b], e, mu[b], scale[b], sym[b], bits, quantbits, self.mode)
+        self._map(one, state.B)
+
+    def push_table(self, state, t, sym, K, bits):
+        sym = self._np(sym).astype(np.int32)
+
+        def one(b):
+            if not state.rc[b]:
+                i = 0 if t.shared else b
+                state.rc[b] = O.layer_push(state.stacks[b], t.e, t.mu[i], t.scale[i], sym[b], bits, t.q, self.mode)
+        self._map(one, state.B)
+
+    def centres(self, centres, sym):
+        idx = torch.as_tensor(sym).long()
+        rows = torch.arange(idx.shape[1]).unsqueeze(0).expand_as(idx)
+        return centres[rows, idx].float()
+
+    def check(self, state, what):
+        if state.rc.any():
+            b = int(np.nonzero(state.rc)[0][0])
+            raise RuntimeError(f"{what}: chain {b}: oracle status {int(state.rc[b])}")
