@@ -125,7 +125,7 @@ class BitSwapCodec:
         xb = ImageBins(torch.float64, dev, self.X)
         self.xend, self.xcen = xb.endpoints(), xb.centres()   # expanded views, row stride 0
         self.tl = timeline or Timeline(False)
-        self._cdf_buf = None
+        self._cdf_bufs = {}
         # the prior p(z_L) = Logistic(0,1) table does not depend on the image: build it once
         # (the reference rebuilds it for every image, mnist_compress.py:246-251)
         one = torch.ones((1, self.Z), dtype=torch.float32, device=dev)
@@ -135,20 +135,25 @@ class BitSwapCodec:
     # ------------------------------------------------------------------------------------------
     def new_states(self, nchains, nblocks, nwords=10000, seed=100, states=None):
         states = states if states is not None else initial_states(nchains, nwords, seed)
-        worst = int(self.X * 9.5 / 32) + 64   # words a block can add on incompressible data
-        cap = max(len(s) for s in states) + nblocks * worst + 4 * self.Z
+        # capacity: 32 bits/dim per block covers any sane model (raw pixels cost 8); a chain that
+        # still outgrows it is flagged BS_ST_OVERFLOW by the kernels, never silently corrupted
+        cap = max(len(s) for s in states) + nblocks * (self.X + 64) + 4 * self.Z
         return self.backend.new_state(states, cap)
 
-    def _cdf(self, B):
-        ld = hip.aligned_ld(self.K)
-        if self._cdf_buf is None or self._cdf_buf.shape[0] != B:
-            self._cdf_buf = torch.empty((B, self.Z, ld), dtype=torch.int32, device=self.device)
-        return self._cdf_buf
+    def _cdf(self, B, D, K):
+        """Reusable cdf-row buffer per table shape (the largest, [B, Z, K+4] u32, is ~0.84 GB at
+        B=100, Z=2048, K=1024: resident for the whole run instead of re-allocated per layer)."""
+        key = (B, D, K)
+        buf = self._cdf_bufs.get(key)
+        if buf is None:
+            buf = torch.empty((B, D, hip.aligned_ld(K)), dtype=torch.int32, device=self.device)
+            self._cdf_bufs[key] = buf
+        return buf
 
     def _pop_layer(self, state, endpoints, centres, mu, scale, quantbits, K, key):
         with self.tl.span("tables_" + key):
             cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
-                                      out=self._cdf(mu.shape[0]) if K == self.K else None)
+                                      out=self._cdf(mu.shape[0], mu.shape[1], K))
         with self.tl.span("pop_" + key):
             return self.backend.pop(state, cdf, K, self.bits, centres=centres)
 
