@@ -280,16 +280,53 @@ __global__ __launch_bounds__(256) void k_table_rows_generic(const double* __rest
 
 // ------------------------------------------------------------------------------------------
 // k_rans_pop: one wavefront per chain.  NV = uint4 loads per lane per row (K = 256*NV), rows
-// 16-byte aligned; the next row is fetched while the current one is searched.
+// 16-byte aligned.  Rows are streamed PF deep into registers (the table lives in HBM: at B=100,
+// Z=2048, K=1024 it is 0.84 GB, far beyond L2), the symbol is the popcount of 4*NV 64-wide ballots,
+// c_s / c_{s+1} come out of the row registers by scalar-indexed VGPR read + v_readlane (no dependent
+// memory access), the next two stack words wait in scalar registers, and the 64-bit head never
+// leaves the scalar unit.
 // ------------------------------------------------------------------------------------------
 template <int NV>
+struct RowRegs {
+    typedef uint32_t vec_t __attribute__((ext_vector_type(4 * NV)));
+    vec_t v;
+    __device__ __forceinline__ void load(const uint32_t* row, int lane) {
+        const uint4* r = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint4 t = r[i * 64 + lane];
+            v[4 * i + 0] = t.x;
+            v[4 * i + 1] = t.y;
+            v[4 * i + 2] = t.z;
+            v[4 * i + 3] = t.w;
+        }
+    }
+    // entry j of the row: uint4 index q = j/4 lives in lane q%64, load i = q/64, component j%4
+    __device__ __forceinline__ uint32_t entry(int j) const {
+        const int e = ((j >> 8) << 2) | (j & 3);
+        return (uint32_t)__builtin_amdgcn_readlane((int)v[e], (j >> 2) & 63);
+    }
+    __device__ __forceinline__ int count_le(uint32_t m) const {
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 4 * NV; ++e) cnt += __popcll(__ballot(v[e] <= m));
+        return cnt;
+    }
+};
+
+template <int NV, int PF>
 __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
                                                  int32_t* __restrict__ len, int64_t cap,
                                                  const uint32_t* __restrict__ cdf, int64_t chain_stride, int64_t ld,
                                                  int D, int bits, int32_t* __restrict__ sym_out,
                                                  const double* __restrict__ centres, int64_t c_stride,
                                                  float* __restrict__ centre_out, int32_t* __restrict__ status) {
+    // D is a multiple of 64 here (host dispatch).  The main loop contains NO conditional memory
+    // operation: row prefetches are unconditional (clamped addresses), stack words are fetched one
+    // 64-row chunk ahead, decoded symbols go to LDS and are written out in a coalesced epilogue.
+    // That keeps hipcc's s_waitcnt vmcnt(N) counted (PF-1 rows stay in flight) instead of vmcnt(0).
     constexpr int K = NV * 256;
+    extern __shared__ int32_t sh_sym[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     if (status[b] != BS_ST_OK) return;
@@ -300,54 +337,73 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
     const uint64_t mask = (1ull << bits) - 1;
     int st = BS_ST_OK;
 
-    uint4 cur[NV], nxt[NV];
-    {
-        const uint4* r = reinterpret_cast<const uint4*>(tab + (int64_t)(D - 1) * ld);
+    auto stack_window = [&](int top, int off) -> uint32_t {  // lane l <- stk[top-1-off-l] (0 if below the stack)
+        const int i = top - 1 - off - lane;
+        return stk[max(i, 0)];
+    };
+    // words this chunk may consume (at most 64): loaded against `wtop`, the word count at load time
+    int wtop = n;
+    uint32_t wa = stack_window(wtop, 0), wb = stack_window(wtop, 64);
+    // materialise the first window now (one exposed latency per launch): otherwise its loads count as
+    // 'possibly still in flight' at every window read of the main loop and turn the counted waits into ~vmcnt(0)
+    asm volatile("" : "+v"(wa), "+v"(wb));
+
+    RowRegs<NV> buf[PF];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) nxt[i] = r[i * 64 + lane];
+    for (int u = 0; u < PF; ++u) {
+        buf[u].load(tab + (int64_t)max(D - 1 - u, 0) * ld, lane);
+        // keep issue order == consumption order: the counted vmcnt of the main loop must also be valid
+        // on the first trip, when these loads (not the in-loop refills) are the ones in flight
+        __builtin_amdgcn_sched_barrier(0);
     }
-    int mysym = 0;
-    for (int d = D - 1; d >= 0; --d) {
+
+    for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
+        // fetch the window the NEXT chunk will read; it has a whole chunk to arrive
+        const int ntop = n;
+        const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
+        int mysym = 0;
+        for (int g = 64 / PF - 1; g >= 0; --g) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
-        if (d > 0) {
-            const uint4* r = reinterpret_cast<const uint4*>(tab + (int64_t)(d - 1) * ld);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) nxt[i] = r[i * 64 + lane];
-        }
-        const uint32_t m = (uint32_t)(h & mask);
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            cnt += __popcll(__ballot(cur[i].x <= m));
-            cnt += __popcll(__ballot(cur[i].y <= m));
-            cnt += __popcll(__ballot(cur[i].z <= m));
-            cnt += __popcll(__ballot(cur[i].w <= m));
-        }
-        const int s = cnt - 1;  // c_0 = 0 <= m always, so s >= 0
-        const uint32_t* row = tab + (int64_t)d * ld;
-        const uint32_t cs = row[s];
-        const uint32_t cs1 = row[s + 1];
-        const uint64_t f = (uint64_t)(cs1 - cs);
-        h = f * (h >> bits) + (uint64_t)(m - cs);
-        if (h < (1ull << 32)) {
-            if (n <= 0) { st = BS_ST_UNDERFLOW; break; }
-            h = (h << 32) | (uint64_t)stk[--n];
-        }
-        if (lane == (d & 63)) mysym = s;
-        if ((d & 63) == 0) {
-            const int dd = d + lane;
-            if (dd < D) {
-                const int64_t o = (int64_t)b * D + dd;
-                sym_out[o] = mysym;
-                if (centres) centre_out[o] = (float)centres[(int64_t)dd * c_stride + mysym];
+            for (int u = 0; u < PF; ++u) {
+                const int d = c64 * 64 + g * PF + (PF - 1 - u);
+                const uint32_t m = (uint32_t)(h & mask);
+                const int s = buf[u].count_le(m) - 1;  // c_0 = 0 <= m always, so s >= 0
+                const uint32_t cs = buf[u].entry(s);
+                const uint32_t cs1 = (s + 1 < K) ? buf[u].entry(s + 1) : (1u << bits);
+                // this row's registers are free again: fetch the row PF steps ahead (clamped, unconditional)
+                buf[u].load(tab + (int64_t)max(d - PF, 0) * ld, lane);
+                const uint64_t f = (uint64_t)(cs1 - cs);
+                h = f * (h >> bits) + (uint64_t)(m - cs);
+                if (h < (1ull << 32)) {
+                    if (n <= 0) {
+                        st = BS_ST_UNDERFLOW;  // keep going on garbage (reads stay in bounds); reported below
+                    } else {
+                        const int o = wtop - n;  // 0..127 within this chunk's window
+                        const uint32_t w = (o < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)wa, o & 63)
+                                                    : (uint32_t)__builtin_amdgcn_readlane((int)wb, o & 63);
+                        h = (h << 32) | (uint64_t)w;
+                        --n;
+                    }
+                }
+                mysym = (lane == (d & 63)) ? s : mysym;
             }
         }
+        sh_sym[c64 * 64 + lane] = mysym;
+        wtop = ntop;
+        wa = na;
+        wb = nb;
     }
     if (lane == 0) {
         head[b] = h;
         len[b] = n;
         if (st != BS_ST_OK) status[b] = st;
+    }
+    __syncthreads();
+    for (int dd = lane; dd < D; dd += 64) {
+        const int sy = sh_sym[dd];
+        const int64_t o = (int64_t)b * D + dd;
+        sym_out[o] = sy;
+        if (centres) centre_out[o] = (float)centres[(int64_t)dd * c_stride + sy];
     }
 }
 
@@ -403,15 +459,22 @@ __global__ __launch_bounds__(64) void k_rans_pop_generic(uint64_t* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // k_rans_push: one lane per chain
 // ------------------------------------------------------------------------------------------
+// One push.  h / f and h % f through a float64 reciprocal: after the renormalisation h < 2^(64-bits+32-32)...
+// precisely h < 2^33 * f (bits = 31), so q = h / f < 2^33 and RN(h) * RN(1/f) is within 3 ulp of h / f,
+// i.e. within 1e-5 of it in absolute terms: trunc() is q-1, q or q+1 and one remainder check fixes it.
 __device__ __forceinline__ bool push_step(uint64_t& h, uint32_t* stk, int& n, int64_t cap, uint32_t fv, uint32_t cv,
-                                          int bits) {
+                                          double rf, int bits) {
     const uint64_t f = fv;
     if (h >= (f << (64 - bits))) {  // ((2^32 >> bits) << 32) * f, mnist_compress.py:52
         if (n >= cap) return false;
         stk[n++] = (uint32_t)h;
         h >>= 32;
     }
-    h = ((h / f) << bits) + (h % f) + (uint64_t)cv;
+    uint64_t q = (uint64_t)((double)h * rf);
+    int64_t r = (int64_t)(h - q * f);
+    if (r < 0) { --q; r += (int64_t)f; }
+    else if (r >= (int64_t)f) { ++q; r -= (int64_t)f; }
+    h = (q << bits) + (uint64_t)r + (uint64_t)cv;
     return true;
 }
 
@@ -427,9 +490,21 @@ __global__ __launch_bounds__(64) void k_rans_push(uint64_t* __restrict__ head, u
     const uint32_t* f = fs + (int64_t)b * D;
     const uint32_t* c = cs + (int64_t)b * D;
     int st = BS_ST_OK;
-    for (int d = 0; d < D; ++d) {
-        if (!push_step(h, stk, n, cap, f[d], c[d], bits)) { st = BS_ST_OVERFLOW; break; }
+    constexpr int U = 4;  // reciprocals of the next U symbols are independent of the head: overlap them
+    int d = 0;
+    for (; d + U <= D && st == BS_ST_OK; d += U) {
+        uint32_t fv[U], cv[U];
+        double rf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { fv[u] = f[d + u]; cv[u] = c[d + u]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) rf[u] = 1.0 / (double)fv[u];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (st == BS_ST_OK && !push_step(h, stk, n, cap, fv[u], cv[u], rf[u], bits)) st = BS_ST_OVERFLOW;
     }
+    for (; d < D && st == BS_ST_OK; ++d)
+        if (!push_step(h, stk, n, cap, f[d], c[d], 1.0 / (double)f[d], bits)) st = BS_ST_OVERFLOW;
     head[b] = h;
     len[b] = n;
     if (st != BS_ST_OK) status[b] = st;
@@ -454,7 +529,7 @@ __global__ __launch_bounds__(64) void k_rans_push_table(uint64_t* __restrict__ h
         const uint32_t* row = tab + (int64_t)d * ld;
         const uint32_t c0 = row[s], c1 = row[s + 1];
         if (c1 <= c0) { st = BS_ST_BADTABLE; break; }
-        if (!push_step(h, stk, n, cap, c1 - c0, c0, bits)) { st = BS_ST_OVERFLOW; break; }
+        if (!push_step(h, stk, n, cap, c1 - c0, c0, 1.0 / (double)(c1 - c0), bits)) { st = BS_ST_OVERFLOW; break; }
     }
     head[b] = h;
     len[b] = n;
@@ -669,10 +744,12 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, cons
         return BS_EINVAL;
     if (B == 0 || D == 0) return BS_OK;
     hipStream_t st = S(stream);
-    const bool vec = aligned16(cdf) && (ld % 4 == 0) && (chain_stride % 4 == 0);
+    // fast path: 16-byte aligned rows, whole 64-row chunks, symbols of one chain fit in LDS
+    const bool vec = aligned16(cdf) && (ld % 4 == 0) && (chain_stride % 4 == 0) && (D % 64 == 0) && (D <= 16384);
     dim3 grid(B), block(64);
 #define BS_POP(NV)                                                                                                   \
-    hipLaunchKernelGGL(k_rans_pop<NV>, grid, block, 0, st, head, stack, len, cap, cdf, chain_stride, ld, D, bits,   \
+    hipLaunchKernelGGL((k_rans_pop<NV, (NV >= 8 ? 4 : 8)>), grid, block, (size_t)D * 4, st, head, stack, len, cap,  \
+                       cdf, chain_stride, ld, D, bits,                                                              \
                        sym_out, centres, c_stride, centre_out, status)
     if (vec && K == 256) BS_POP(1);
     else if (vec && K == 512) BS_POP(2);
