@@ -1,0 +1,229 @@
+"""Command-line drivers mirroring the reference's scripts.
+
+`<dataset>_compress.py --gpu G --nz N --quantbits Q --bitswap S` (mnist_compress.py:368-386 and
+its cifar/imagenet siblings) run `experiments` x `ndatapoints` images (100 x 100 in the reference,
+:102-103) and write the same artefacts: per-experiment pickled bitstreams under
+`bitstreams/<ds>/nz<N>/<Scheme>/` (:265-267) and the four metric arrays under `plots/<ds><N>/`
+(:363-366).  Internals are new: the 100 experiments are 100 chains coded in lock-step on the GPU
+(codec.BitSwapCodec), sharded over ranks when launched under torchrun.
+
+Offline there are no datasets or checkpoints: `--data file.npy` supplies uint8 images
+[N,H,W,C] / [N,C,H,W], `--params file` a reference checkpoint, `--synthetic` uses the seeded
+synthetic stand-ins of bitswap_amd.workload.
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import container, dist, tiling, workload
+from .bins import discretize
+from .codec import BitSwapCodec, initial_states
+from .model import elbo_bits, preset
+
+SCHEME = {1: "Bit-Swap", 0: "BB-ANS"}
+TITLE = {"mnist": "MNIST", "cifar": "CIFAR-10", "imagenet": "ImageNet (32x32)", "imagenetcrop": "ImageNet (unscaled)"}
+
+
+def seed_everything():
+    """mnist_compress.py:94-99"""
+    np.random.seed(100)
+    random.seed(50)
+    torch.manual_seed(50)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(50)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False   # the reference sets True; a fixed algorithm is safer for the decoder
+
+
+def load_images(dataset, path, synthetic, xs, n):
+    """uint8 images as flat CHW rows [N, C*H*W]."""
+    if path:
+        a = np.load(path)
+        if a.ndim == 3:
+            a = a[:, None]
+        if a.shape[-1] in (1, 3) and a.shape[1] not in (1, 3):
+            a = a.transpose(0, 3, 1, 2)
+        if dataset == "mnist" and a.shape[-1] == 28:       # transforms.Pad(2), mnist_compress.py:128
+            a = np.pad(a, ((0, 0), (0, 0), (2, 2), (2, 2)))
+        return torch.from_numpy(np.ascontiguousarray(a)).view(a.shape[0], -1)
+    if synthetic:
+        return workload.synthetic_blocks(n, xs, seed=100)
+    raise FileNotFoundError(
+        f"no test images: the {dataset} dataset cannot be downloaded here -- pass --data <uint8 .npy> or --synthetic")
+
+
+def load_model(dataset, nz, device, params, synthetic, nn_batch=None):
+    path = params or f"model/params/{dataset}/nz{nz}"
+    if os.path.exists(path):
+        m = preset(dataset, nz, nn_batch=nn_batch)
+        m.load_state_dict(torch.load(path, map_location="cpu"))
+        return m.to(device).eval().fold()
+    if synthetic:
+        return workload.synthetic_model(dataset, nz, device, nn_batch=nn_batch)
+    raise FileNotFoundError(f"checkpoint {path} not found -- pass --params <file> or --synthetic")
+
+
+def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndatapoints=100, decompress=False,
+             synthetic=False, data=None, params=None, outdir=".", backend=None, small=None, verbose=True):
+    """One (dataset, nz, quantbits, scheme) experiment set.  Returns dict of the metric arrays on
+    rank 0 (None on other ranks)."""
+    rank, world = dist.init()
+    dev = torch.device("cpu") if backend is not None else torch.device("cuda", gpu if world == 1 else rank % max(1, torch.cuda.device_count()))
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    if verbose and rank == 0:
+        print(f"{SCHEME[int(bool(bitswap))]} - {TITLE[dataset]} - {nz} latent layers - {quantbits} bits quantization")
+    seed_everything()
+
+    if small:
+        model = workload.synthetic_model(dataset, nz, dev, small=small)
+    else:
+        model = load_model(dataset, nz, dev, params, synthetic)
+    images = load_images(dataset, data, synthetic or bool(small), model.xs, max(experiments * ndatapoints, 512))
+    bins_data = images[: min(len(images), 4096)].view((-1,) + tuple(model.xs))
+    zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, dataset, data=bins_data,
+                            ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"),
+                            save=not (synthetic or small))
+
+    # (experiments, ndatapoints) test images per experiment, without replacement (:133-137)
+    idx_path = os.path.join(outdir, "bitstreams", dataset, "indices.npy")
+    if os.path.exists(idx_path):
+        randindices = np.load(idx_path)
+    else:
+        randindices = np.random.choice(len(images), size=(experiments, ndatapoints),
+                                       replace=len(images) < experiments * ndatapoints)
+        if rank == 0:
+            os.makedirs(os.path.dirname(idx_path), exist_ok=True)
+            np.save(idx_path, randindices)
+
+    mine = dist.shard_chains(experiments, world, rank)
+    inits = initial_states(experiments, 10000, seed=100)        # experiment ei gets the ei-th draw (:158)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap), backend=backend)
+    x = images[torch.from_numpy(randindices[mine].reshape(-1))].view(len(mine), ndatapoints, -1).to(torch.int32)
+    state = codec.new_states(len(mine), ndatapoints, states=[inits[c] for c in mine])
+
+    t0 = time.perf_counter()
+    state, met = codec.compress(x.to(dev), state=state)
+    t_send = time.perf_counter() - t0
+    elbos = np.zeros((len(mine), ndatapoints))
+    for xi in range(ndatapoints):                                # ELBO metric (:170-174), off the coding path
+        xb = x[:, xi].to(dev).float().view((-1,) + tuple(model.xs))
+        elbos[:, xi] = (elbo_bits(model, xb) / model.xdim).cpu().numpy()
+    sent = state.to_lists()
+
+    scheme = SCHEME[int(bool(bitswap))]
+    sdir = os.path.join(outdir, "bitstreams", dataset, f"nz{nz}", scheme)
+    os.makedirs(sdir, exist_ok=True)
+    for c, s in zip(mine, sent):
+        container.save_state(os.path.join(sdir, f"{scheme}_{quantbits}bits_nz{nz}_experiment{c + 1}"), s)
+
+    t_recv = 0.0
+    if decompress:
+        t0 = time.perf_counter()
+        out = codec.decompress(state, ndatapoints)
+        t_recv = time.perf_counter() - t0
+        assert torch.equal(out.cpu(), x), "decoded datapoint does not match"            # (:319,354)
+        assert state.to_lists() == [inits[c] for c in mine], "initial state not restored"  # (:358)
+
+    rows = {k: dist.gather_rows(v, mine, experiments) for k, v in
+            dict(nets=met["nets"], elbos=elbos, cmas=met["cma"], total=met["total"]).items()}
+    words = dist.gather_streams([container.pack(s, 0, ndatapoints, 32, 32)[:-3] for s in sent], mine, experiments)
+    tot = dist.allreduce_sum([float(met["total"][:, -1].sum()), float(len(mine) * ndatapoints * model.xdim),
+                              t_send + t_recv])
+    if rank != 0:
+        return None
+    nets, el = rows["nets"], rows["elbos"]
+    if verbose:
+        print(f"N:{nets.mean():.4f}±{nets.std():.2f}, E:{el.mean():.4f}±{el.std():.2f}, D:{nets.mean() - el.mean():.6f}")
+        px = experiments * ndatapoints * 1024
+        print(f"sender {t_send:.2f}s" + (f", receiver {t_recv:.2f}s, lossless, {px / (t_send + t_recv):.0f} pixels/s (enc+dec)"
+                                        if decompress else f", {px / t_send:.0f} pixels/s (enc)") +
+              f", {world} GPU(s), {sum(len(w) for w in words) * 4} bytes gathered")
+    pdir = os.path.join(outdir, "plots", f"{dataset}{nz}")
+    os.makedirs(pdir, exist_ok=True)
+    tag = "bitswap" if bitswap else "bbans"
+    for k, v in rows.items():
+        np.save(os.path.join(pdir, f"{tag}_{quantbits}bits_{k}"), v)          # (:363-366)
+    rows["bits_per_dim"] = tot[0] / tot[1]
+    return rows
+
+
+def dataset_main(dataset, default_nz, nz_loop=None):
+    """argparse front end shared by the four <dataset>_compress.py scripts (flags :369-373)."""
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpu', default=0, type=int)
+    p.add_argument('--nz', default=default_nz, type=int)
+    p.add_argument('--quantbits', default=10, type=int)
+    p.add_argument('--bitswap', default=1, type=int)
+    # extras (not in the reference)
+    p.add_argument('--decompress', default=0, type=int, help="also run the receiver and assert losslessness")
+    p.add_argument('--experiments', default=100, type=int)
+    p.add_argument('--ndatapoints', default=100, type=int)
+    p.add_argument('--synthetic', action='store_true', help="seeded synthetic weights/images (no datasets offline)")
+    p.add_argument('--data', default=None, help="uint8 .npy test images")
+    p.add_argument('--params', default=None, help="reference checkpoint (state_dict)")
+    p.add_argument('--outdir', default=".")
+    args = p.parse_args()
+    print(args)
+    for nz in (nz_loop or [args.nz]):      # imagenet_compress.py:382 ignores --nz and runs [2, 4]
+        compress(args.quantbits, nz, args.bitswap, args.gpu, dataset=dataset, experiments=args.experiments,
+                 ndatapoints=args.ndatapoints, decompress=bool(args.decompress), synthetic=args.synthetic,
+                 data=args.data, params=args.params, outdir=args.outdir)
+
+
+# ---------------------------------------------------------------------------------------------
+# single-image path: imagenetcrop_compress.compress / demo_compress.compress / demo_decompress.decompress
+# ---------------------------------------------------------------------------------------------
+def crop_setup(gpu, nz=4, quantbits=10, synthetic=False, params=None, outdir=".", backend=None, small=None):
+    dev = torch.device("cpu") if backend is not None else torch.device("cuda", max(gpu, 0))
+    if small:
+        model = workload.synthetic_model("imagenetcrop", nz, dev, small=small)
+    else:
+        model = load_model("imagenetcrop", nz, dev, params, synthetic)
+    data = workload.synthetic_blocks(512, model.xs, seed=100).view((-1,) + tuple(model.xs))
+    zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, "imagenetcrop", data=data,
+                            ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"),
+                            save=not (synthetic or small))
+    return model, zend, zcen, dev
+
+
+def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_quirk=False, setup=None, backend=None,
+                    trim=True):
+    """images_blocks: list of [n_i, 32, 32, 3] uint8 block arrays (one per image; every image is a
+    chain, imagenetcrop_compress.py:279-300).  Chains of different length run in lock-step and
+    drop out as they finish.  Returns (list of state lists, list of min_words, bits/dim per image)."""
+    model, zend, zcen, dev = setup
+    flat = [(tiling.blocks_to_hwc_flat(b) if hwc_quirk else tiling.blocks_to_chw_flat(b)) for b in images_blocks]
+    order = sorted(range(len(flat)), key=lambda i: -len(flat[i]))
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap), backend=backend)
+    results = [None] * len(flat)
+    # group chains of equal block count (lock-step needs equal lengths); singletons are fine
+    groups = {}
+    for i in order:
+        groups.setdefault(len(flat[i]), []).append(i)
+    for n, ids in groups.items():
+        np.random.seed(100)   # every image starts from the same 'random' stack (imagenetcrop_compress.py:249,122)
+        init = initial_states(1, 10000, seed=100)[0]
+        x = torch.from_numpy(np.stack([flat[i] for i in ids]).astype(np.int32))
+        state = codec.new_states(len(ids), n, states=[list(init) for _ in ids])
+        state.min_len = state.len.clone()
+        state, met = codec.compress(x.to(dev), state=state)
+        mins = state.min_len.cpu().tolist()
+        for k, i in enumerate(ids):
+            results[i] = (state.to_lists()[k], int(mins[k]) if trim else 0, float(met["cma"][k, -1]))
+    return results
+
+
+def decompress_image(state, nblocks, quantbits=10, nz=4, gpu=0, setup=None, backend=None, hwc_quirk=False):
+    """demo_decompress.decompress (:69-148): -> [nblocks, 32, 32, 3] uint8 blocks."""
+    model, zend, zcen, dev = setup
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=True, backend=backend)
+    st = codec.backend.new_state([list(state)], len(state) + nblocks * (model.xdim + 64) + 4 * model.zdim_flat)
+    out = codec.decompress(st, nblocks)[0].cpu().numpy()
+    if hwc_quirk:
+        return out.reshape(nblocks, 32, 32, 3).astype(np.uint8), st.to_lists()[0]
+    return tiling.chw_flat_to_blocks(out), st.to_lists()[0]

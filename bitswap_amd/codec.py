@@ -155,7 +155,17 @@ class BitSwapCodec:
             cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
                                       out=self._cdf(mu.shape[0], mu.shape[1], K))
         with self.tl.span("pop_" + key):
-            return self.backend.pop(state, cdf, K, self.bits, centres=centres)
+            out = self.backend.pop(state, cdf, K, self.bits, centres=centres)
+        self._track_min(state)
+        return out
+
+    @staticmethod
+    def _track_min(state):
+        """Fewest words each chain ever held (the demo container trims the untouched initial
+        words, demo_compress.py:133,159-160).  Enabled by giving the state a `min_len` tensor."""
+        ml = getattr(state, "min_len", None)
+        if ml is not None:
+            torch.minimum(ml, state.len.to(ml.device), out=ml)
 
     def _push_layer(self, state, endpoints, mu, scale, sym, quantbits, key):
         with self.tl.span("push_" + key):
@@ -212,6 +222,7 @@ class BitSwapCodec:
         with self.tl.span("pop_prior"):
             # prior table [Z, ld] is shared by every chain (chain stride 0)
             zsymtop, z = self.backend.pop(state, self.prior_cdf, self.K, self.bits, centres=self.zcen[-1])
+        self._track_min(state)
         if self.bitswap:
             for zi in reversed(range(nz)):
                 mu, sc = self._net(m.generate(zi), z)

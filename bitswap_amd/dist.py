@@ -1,0 +1,119 @@
+"""Multi-GPU: chains shard, nothing else does.
+
+Each chain (one of the reference's 100 "experiments", mnist_compress.py:147-161, or one image of
+imagenetcrop_compress.py:279-300) owns its rANS state, so ranks never exchange anything while
+coding.  The single exchange is the gather of the finished bitstreams (and two scalars for
+bits/dim) at the end: RCCL over xGMI when the process group is `nccl`, gloo on CPU for tests.
+One process per GPU, torch.distributed.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+
+def init(backend=None):
+    """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torchrun).  Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    if not td.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+    return td.get_rank(), td.get_world_size()
+
+
+def shard_chains(nchains, world, rank, weights=None):
+    """Chain indices owned by `rank`.  Equal-length chains: round-robin (c % world).  With `weights`
+    (blocks per chain, config 4): longest-processing-time-first onto the least loaded rank."""
+    if weights is None:
+        return [c for c in range(nchains) if c % world == rank]
+    order = sorted(range(nchains), key=lambda c: (-weights[c], c))
+    load = [0] * world
+    owner = [0] * nchains
+    for c in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[c] = r
+        load[r] += weights[c]
+    return [c for c in range(nchains) if owner[c] == rank]
+
+
+def _device():
+    return torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+
+
+def gather_streams(local, chain_ids, nchains, dst=0):
+    """local: list of uint32 numpy arrays (one finished bitstream per owned chain, any lengths),
+    chain_ids: their global chain indices.  Returns on `dst` a list of nchains arrays (None
+    elsewhere).  Two collectives: all_gather of the per-chain word counts, gather of the padded
+    payloads."""
+    if not td.is_initialized() or td.get_world_size() == 1:
+        out = [None] * nchains
+        for c, a in zip(chain_ids, local):
+            out[c] = np.asarray(a, dtype=np.uint32)
+        return out
+    world, rank, dev = td.get_world_size(), td.get_rank(), _device()
+    per = (nchains + world - 1) // world
+    meta = torch.full((per, 2), -1, dtype=torch.int64, device=dev)     # (chain id, words)
+    for k, (c, a) in enumerate(zip(chain_ids, local)):
+        meta[k, 0], meta[k, 1] = c, len(a)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    td.all_gather(metas, meta)
+    maxwords = max(int(m[:, 1].clamp(min=0).sum()) for m in metas)
+    flat = np.zeros(maxwords, dtype=np.uint32)
+    if local:
+        cat = np.concatenate([np.asarray(a, dtype=np.uint32) for a in local])
+        flat[: len(cat)] = cat
+    payload = torch.from_numpy(flat.view(np.int32)).to(dev)
+    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+    td.gather(payload, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = [None] * nchains
+    for r in range(world):
+        words = bufs[r].cpu().numpy().view(np.uint32)
+        off = 0
+        for c, nwords in metas[r].cpu().tolist():
+            if c < 0:
+                continue
+            out[c] = words[off: off + nwords].copy()
+            off += nwords
+    return out
+
+
+def allreduce_sum(values):
+    """Sum a short list of floats over ranks (total bits, total dims)."""
+    if not td.is_initialized() or td.get_world_size() == 1:
+        return list(values)
+    t = torch.tensor(values, dtype=torch.float64, device=_device())
+    td.all_reduce(t)
+    return t.cpu().tolist()
+
+
+def gather_rows(local, chain_ids, nchains, dst=0):
+    """Gather per-chain float rows (metrics [n_local, ndatapoints]) to `dst` in chain order."""
+    local = np.asarray(local, dtype=np.float64)
+    if not td.is_initialized() or td.get_world_size() == 1:
+        out = np.zeros((nchains,) + local.shape[1:])
+        out[chain_ids] = local
+        return out
+    world, rank, dev = td.get_world_size(), td.get_rank(), _device()
+    per = (nchains + world - 1) // world
+    buf = torch.zeros((per,) + local.shape[1:], dtype=torch.float64, device=dev)
+    ids = torch.full((per,), -1, dtype=torch.int64, device=dev)
+    if len(chain_ids):
+        buf[: len(chain_ids)] = torch.from_numpy(local).to(dev)
+        ids[: len(chain_ids)] = torch.tensor(chain_ids, device=dev)
+    bufs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    idl = [torch.empty_like(ids) for _ in range(world)]
+    td.all_gather(idl, ids)
+    td.gather(buf, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = np.zeros((nchains,) + local.shape[1:])
+    for r in range(world):
+        for k, c in enumerate(idl[r].cpu().tolist()):
+            if c >= 0:
+                out[c] = bufs[r][k].cpu().numpy()
+    return out

@@ -319,6 +319,22 @@ class Model(nn.Module):
         return logrecon, logdec, logenc, zsamples
 
 
+def elbo_bits(model, x):
+    """Per-image negative ELBO in bits, [B]: what the reference computes with a batch of one as
+    `-logrecon + sum(-logdec + logenc)` (mnist_compress.py:170-174) for its `elbos` metric."""
+    was = model.compressing
+    model.compress(False)
+    try:
+        with torch.no_grad():
+            out = []
+            for i in range(x.shape[0]):   # loss() averages over the batch: keep the reference's per-image call
+                logrecon, logdec, logenc, _ = model.loss(x[i:i + 1])
+                out.append(-logrecon + torch.sum(-logdec + logenc))
+            return torch.stack(out)
+    finally:
+        model.compress(was)
+
+
 # dataset presets of the reference CLIs ----------------------------------------------------------
 def preset(dataset, nz, **kw):
     """Model configured like <dataset>_compress.py (widths: mnist_compress.py:81-88,
