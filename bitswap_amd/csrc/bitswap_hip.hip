@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_logistic(const double* __restrict__ end
         } else {
             const int s = sym[row];
             const bool ok = (s >= 0) && (s < K);
-            if (!ok && lane == 0) status[b] = BS_ST_BADSYMBOL;
+            if (!ok && lane == 0 && status[b] == BS_ST_OK) status[b] = BS_ST_BADSYMBOL;  // first error sticks
             const int ss = ok ? s : 0;
             if (lane == ss / NPL) {
                 const int idx = ss % NPL;
@@ -329,7 +329,13 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
     extern __shared__ int32_t sh_sym[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
-    if (status[b] != BS_ST_OK) return;
+    if (status[b] != BS_ST_OK) {  // failed chain: skipped, but its outputs stay well-defined
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
     uint64_t h = head[b];
     int n = len[b];
     const uint32_t* stk = stack + (int64_t)b * cap;
@@ -418,7 +424,13 @@ __global__ __launch_bounds__(64) void k_rans_pop_generic(uint64_t* __restrict__ 
                                                          int32_t* __restrict__ status) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
-    if (status[b] != BS_ST_OK) return;
+    if (status[b] != BS_ST_OK) {
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
     uint64_t h = head[b];
     int n = len[b];
     const uint32_t* stk = stack + (int64_t)b * cap;
