@@ -33,8 +33,26 @@ class HipBackend:
     def new_state(self, states, cap):
         return hip.RansState.from_lists(states, cap=cap, device=self.device)
 
+    @staticmethod
+    def table_layout(K):
+        """cdf rows are an internal hand-off between two of our kernels: use the wave-native layout
+        whenever the pop kernel has it (K = 256..2048), the reference's linear rows otherwise."""
+        return hip.LAYOUT_WAVE if hip.wave_supported(K) else hip.LAYOUT_LINEAR
+
+    def table_buffer(self, B, D, K):
+        ld = hip.wave_ld(K) if self.table_layout(K) == hip.LAYOUT_WAVE else hip.aligned_ld(K)
+        return torch.empty((B, D, ld), dtype=torch.int32, device=self.device)
+
     def tables(self, endpoints, mu, scale, quantbits, bits, out=None):
-        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out)
+        K = endpoints.shape[1] + 1
+        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=self.table_layout(K))
+
+    def shared_table(self, endpoints, mu, scale, quantbits, bits):
+        """One table row set [D, ld] shared by every chain (the prior)."""
+        t = self.tables(endpoints, mu, scale, quantbits, bits)
+        p = t[0]
+        p.bs_layout = t.bs_layout
+        return p
 
     def pop(self, state, cdf, K, bits, centres=None):
         return hip.rans_pop(state, cdf, K, bits, centres=centres)
@@ -129,7 +147,7 @@ class BitSwapCodec:
         # the prior p(z_L) = Logistic(0,1) table does not depend on the image: build it once
         # (the reference rebuilds it for every image, mnist_compress.py:246-251)
         one = torch.ones((1, self.Z), dtype=torch.float32, device=dev)
-        self.prior_cdf = self.backend.tables(self.zend[-1], torch.zeros_like(one), one, self.q, self.bits)[0]
+        self.prior_cdf = self.backend.shared_table(self.zend[-1], torch.zeros_like(one), one, self.q, self.bits)
         model.compress(True)
 
     # ------------------------------------------------------------------------------------------
@@ -146,7 +164,7 @@ class BitSwapCodec:
         key = (B, D, K)
         buf = self._cdf_bufs.get(key)
         if buf is None:
-            buf = torch.empty((B, D, hip.aligned_ld(K)), dtype=torch.int32, device=self.device)
+            buf = self.backend.table_buffer(B, D, K)
             self._cdf_bufs[key] = buf
         return buf
 

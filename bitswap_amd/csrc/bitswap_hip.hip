@@ -14,7 +14,8 @@
 //                              coalesced 16-byte loads (next row prefetched into registers while
 //                              the current one is searched), symbol = popcount of 64-wide ballots;
 //                              the 64-bit head lives in scalar registers.
-//   k_rans_push / _table       one lane per chain, serial 64-bit division per symbol.
+//   k_rans_push / _table       one wavefront per chain: lane-parallel (f, c, 1/f) prefetch per 64-symbol
+//                              chunk, wave-uniform serial part with the head on the scalar unit.
 //
 // Reference lines are cited in include/bitswap_hip.h next to each entry point.
 #include <hip/hip_runtime.h>
@@ -66,6 +67,20 @@ __device__ __forceinline__ double lane_shift_up_f64(double v) {
 // compiled with -ffp-contract=off so nothing else is fused.  oracle/bitswap_oracle.c carries
 // an independent C restatement that must agree bit for bit.
 // ------------------------------------------------------------------------------------------
+// Correctly rounded 1/x for x in [1, 2^1011): hardware seed, two Newton steps, one residual correction
+// -- the sequence hipcc emits for an IEEE f64 division minus the v_div_scale / v_div_fixup range
+// handling, which this argument range never needs.  The spec demands RN(1/x); parity with the
+// oracle's `1.0 / x` is asserted bit for bit (tests/test_hip_parity.py::test_sigmoid_bit_exact_vs_oracle).
+__device__ __forceinline__ double recip_1_to_huge(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    const double r = fma(-x, y, 1.0);
+    return fma(r, y, y);
+}
+
 __device__ __forceinline__ double det_sigmoid(double t) {
     double a = -t;
     a = fmin(fmax(a, -700.0), 700.0);
@@ -85,7 +100,7 @@ __device__ __forceinline__ double det_sigmoid(double t) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     const double e = ldexp(p, (int)kd);
-    return 1.0 / (1.0 + e);
+    return recip_1_to_huge(1.0 + e);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -121,7 +136,18 @@ __device__ __forceinline__ uint32_t bump_and_scan(uint32_t (&f)[NPL], int lane, 
 // ------------------------------------------------------------------------------------------
 // k_logistic: fused logistic CDF -> integer table, NPL = K/64 bins per lane
 // ------------------------------------------------------------------------------------------
-template <int NPL, typename PT, bool DECODE, bool VEC>
+// output modes of k_logistic
+enum { M_ENCODE = 0, M_LINEAR = 1, M_LINEAR_VEC = 2, M_WAVE = 3 };
+
+// BS_LAYOUT_WAVE: dword offset of cdf entry j (K = 64*NPL entries) inside a row.  Register r = j/64 of
+// the popping wavefront holds entries 64r..64r+63 across its lanes; uint4 load i of lane l returns
+// registers 4i..4i+3, so entry j sits at ((r/4)*64 + l)*4 + r%4 with l = j%64.
+__device__ __forceinline__ int wave_offset(int j) {
+    const int r = j >> 6, l = j & 63;
+    return (((r >> 2) << 6) + l) * 4 + (r & 3);
+}
+
+template <int NPL, typename PT, int MODE>
 __global__ __launch_bounds__(256) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
                                                   const PT* __restrict__ mu, const PT* __restrict__ scale,
                                                   const int32_t* __restrict__ sym, int B, int D, int bits,
@@ -166,9 +192,19 @@ __global__ __launch_bounds__(256) void k_logistic(const double* __restrict__ end
         bool bad;
         uint32_t c = bump_and_scan<NPL>(f, lane, bits, bad);
 
-        if (DECODE) {
+        if (MODE == M_WAVE) {
+            // wave-native rows for k_rans_pop_wave: K entries permuted as wave_offset(), then the 64
+            // pivots c_{NPL*l} (this lane's starting value) at [K, K+64)
+            uint32_t* o = out0 + row * ld;
+            o[K + lane] = c;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                o[wave_offset(lane * NPL + i)] = c;
+                c += f[i];
+            }
+        } else if (MODE != M_ENCODE) {
             uint32_t* o = out0 + row * ld + lane * NPL;
-            if (VEC) {
+            if (MODE == M_LINEAR_VEC) {
 #pragma unroll
                 for (int i = 0; i < NPL; i += 4) {
                     uint4 v;
@@ -288,8 +324,14 @@ __global__ __launch_bounds__(256) void k_table_rows_generic(const double* __rest
 // ------------------------------------------------------------------------------------------
 template <int NV>
 struct RowRegs {
+    static constexpr int K = NV * 256;
     typedef uint32_t vec_t __attribute__((ext_vector_type(4 * NV)));
     vec_t v;
+    __device__ __forceinline__ void find(uint32_t m, int bits, int& s, uint32_t& cs, uint32_t& cs1) const {
+        s = count_le(m) - 1;  // c_0 = 0 <= m always, so s >= 0
+        cs = entry(s);
+        cs1 = (s + 1 < K) ? entry(s + 1) : (1u << bits);
+    }
     __device__ __forceinline__ void load(const uint32_t* row, int lane) {
         const uint4* r = reinterpret_cast<const uint4*>(row);
 #pragma unroll
@@ -314,7 +356,46 @@ struct RowRegs {
     }
 };
 
-template <int NV, int PF>
+// wave-native rows (BS_LAYOUT_WAVE): NPL = K/64 registers R[r] (lane l = c_{64r+l}) + the 64 pivots
+// c_{NPL*l}.  Two ballots find the symbol: pivots -> segment g (NPL consecutive entries, all inside
+// one register), that register -> position inside the segment.  ~20 instructions instead of ~65.
+template <int NPL>
+struct WaveRow {
+    static constexpr int K = NPL * 64;
+    typedef uint32_t vec_t __attribute__((ext_vector_type(NPL)));
+    vec_t R;
+    uint32_t pivot;
+    __device__ __forceinline__ void load(const uint32_t* row, int lane) {
+        const uint4* r = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+        for (int i = 0; i < NPL / 4; ++i) {
+            const uint4 t = r[i * 64 + lane];
+            R[4 * i + 0] = t.x;
+            R[4 * i + 1] = t.y;
+            R[4 * i + 2] = t.z;
+            R[4 * i + 3] = t.w;
+        }
+        pivot = row[K + lane];
+    }
+    __device__ __forceinline__ void find(uint32_t m, int bits, int& s, uint32_t& cs, uint32_t& cs1) const {
+        const int g = __popcll(__ballot(pivot <= m)) - 1;  // c_0 = 0 <= m: g >= 0
+        const int base = g * NPL;
+        const uint32_t x = R[base >> 6];
+        const unsigned long long bal = __ballot(x <= m);
+        const uint32_t seg = (uint32_t)(bal >> (base & 63)) & (NPL == 32 ? 0xffffffffu : ((1u << (NPL & 31)) - 1u));
+        s = base + __popc(seg) - 1;
+        cs = (uint32_t)__builtin_amdgcn_readlane((int)x, s & 63);
+        const int s1 = s + 1;
+        if (s1 == K) {
+            cs1 = 1u << bits;
+        } else {
+            const uint32_t x1 = R[s1 >> 6];
+            cs1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, s1 & 63);
+        }
+    }
+};
+
+template <class ROW, int PF>
 __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
                                                  int32_t* __restrict__ len, int64_t cap,
                                                  const uint32_t* __restrict__ cdf, int64_t chain_stride, int64_t ld,
@@ -325,7 +406,6 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
     // operation: row prefetches are unconditional (clamped addresses), stack words are fetched one
     // 64-row chunk ahead, decoded symbols go to LDS and are written out in a coalesced epilogue.
     // That keeps hipcc's s_waitcnt vmcnt(N) counted (PF-1 rows stay in flight) instead of vmcnt(0).
-    constexpr int K = NV * 256;
     extern __shared__ int32_t sh_sym[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -336,6 +416,9 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
         }
         return;
     }
+    // latency-critical serial wave: win instruction-issue arbitration against co-resident bulk
+    // kernels (the convs of another chain group run concurrently on other streams)
+    __builtin_amdgcn_s_setprio(3);
     uint64_t h = head[b];
     int n = len[b];
     const uint32_t* stk = stack + (int64_t)b * cap;
@@ -354,7 +437,7 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
     // 'possibly still in flight' at every window read of the main loop and turn the counted waits into ~vmcnt(0)
     asm volatile("" : "+v"(wa), "+v"(wb));
 
-    RowRegs<NV> buf[PF];
+    ROW buf[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
         buf[u].load(tab + (int64_t)max(D - 1 - u, 0) * ld, lane);
@@ -373,9 +456,9 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
             for (int u = 0; u < PF; ++u) {
                 const int d = c64 * 64 + g * PF + (PF - 1 - u);
                 const uint32_t m = (uint32_t)(h & mask);
-                const int s = buf[u].count_le(m) - 1;  // c_0 = 0 <= m always, so s >= 0
-                const uint32_t cs = buf[u].entry(s);
-                const uint32_t cs1 = (s + 1 < K) ? buf[u].entry(s + 1) : (1u << bits);
+                int s;
+                uint32_t cs, cs1;
+                buf[u].find(m, bits, s, cs, cs1);
                 // this row's registers are free again: fetch the row PF steps ahead (clamped, unconditional)
                 buf[u].load(tab + (int64_t)max(d - PF, 0) * ld, lane);
                 const uint64_t f = (uint64_t)(cs1 - cs);
@@ -469,83 +552,151 @@ __global__ __launch_bounds__(64) void k_rans_pop_generic(uint64_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rans_push: one lane per chain
+// k_rans_push: one wavefront per chain.  Per 64-symbol chunk the lanes fetch (f, c) of 64 symbols
+// with one coalesced load each (or gather them from cdf rows) and compute the 64 reciprocals 1/f
+// lane-parallel, one chunk ahead of use; the serial part then runs wave-uniform: the 64-bit head and
+// all integer work sit on the scalar unit, only the float64 quotient estimate touches the VALU.
+// Emitted words collect in a register window and leave as coalesced 256-byte stores.
 // ------------------------------------------------------------------------------------------
-// One push.  h / f and h % f through a float64 reciprocal: after the renormalisation h < 2^(64-bits+32-32)...
-// precisely h < 2^33 * f (bits = 31), so q = h / f < 2^33 and RN(h) * RN(1/f) is within 3 ulp of h / f,
-// i.e. within 1e-5 of it in absolute terms: trunc() is q-1, q or q+1 and one remainder check fixes it.
-__device__ __forceinline__ bool push_step(uint64_t& h, uint32_t* stk, int& n, int64_t cap, uint32_t fv, uint32_t cv,
-                                          double rf, int bits) {
-    const uint64_t f = fv;
-    if (h >= (f << (64 - bits))) {  // ((2^32 >> bits) << 32) * f, mnist_compress.py:52
-        if (n >= cap) return false;
-        stk[n++] = (uint32_t)h;
-        h >>= 32;
+struct FcSource {  // (f, c) arrays produced by k_logistic<M_ENCODE>
+    const uint32_t* f;
+    const uint32_t* c;
+    __device__ __forceinline__ bool fetch(int d, int D, uint32_t& fv, uint32_t& cv) const {
+        fv = 1u;
+        cv = 0u;
+        if (d < D) { fv = f[d]; cv = c[d]; }
+        return true;
     }
-    uint64_t q = (uint64_t)((double)h * rf);
-    int64_t r = (int64_t)(h - q * f);
-    if (r < 0) { --q; r += (int64_t)f; }
-    else if (r >= (int64_t)f) { ++q; r -= (int64_t)f; }
-    h = (q << bits) + (uint64_t)r + (uint64_t)cv;
-    return true;
+};
+
+struct TableSource {  // cdf rows + symbols (drop-in ANS.encode, shared prior table)
+    const uint32_t* tab;
+    const int32_t* sym;
+    int64_t ld;
+    int layout, K, bits;
+    __device__ __forceinline__ bool fetch(int d, int D, uint32_t& fv, uint32_t& cv, int& err) const {
+        fv = 1u;
+        cv = 0u;
+        if (d >= D) return true;
+        const int s = sym[d];
+        if (s < 0 || s >= K) { err = BS_ST_BADSYMBOL; return false; }
+        const uint32_t* row = tab + (int64_t)d * ld;
+        uint32_t c0, c1;
+        if (layout == BS_LAYOUT_WAVE) {
+            c0 = row[wave_offset(s)];
+            c1 = (s + 1 < K) ? row[wave_offset(s + 1)] : (1u << bits);
+        } else {
+            c0 = row[s];
+            c1 = row[s + 1];
+        }
+        if (c1 <= c0) { err = BS_ST_BADTABLE; return false; }
+        fv = c1 - c0;
+        cv = c0;
+        return true;
+    }
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// serial part shared by both sources.  h / f through a float64 reciprocal: after the renormalisation
+// h < 2^(64-bits) * f, so q = h / f < 2^33; RN(h) * RN(1/f) is within 3 ulp of h / f (< 3e-6 absolute),
+// hence trunc() is q-1, q or q+1 and one remainder check repairs it.
+template <bool TABLE>
+__device__ __forceinline__ void push_chain(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                           int32_t* __restrict__ len, int64_t cap, const FcSource& fc,
+                                           const TableSource& ts, int D, int bits, int32_t* __restrict__ status) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) return;
+    __builtin_amdgcn_s_setprio(3);
+    uint64_t h = head[b];
+    int n = len[b];
+    uint32_t* stk = stack + (int64_t)b * cap;
+    int st = BS_ST_OK;
+    uint32_t wbuf = 0;  // pending output words, word k in lane k
+    int wpos = 0;
+
+    uint32_t fv, cv;
+    int err = BS_ST_OK;
+    if (TABLE) ts.fetch(lane, D, fv, cv, err); else fc.fetch(lane, D, fv, cv);
+    const int nchunks = (D + 63) >> 6;
+    for (int ck = 0; ck < nchunks; ++ck) {
+        uint32_t fn, cn;
+        int errn = BS_ST_OK;
+        if (TABLE) ts.fetch((ck + 1) * 64 + lane, D, fn, cn, errn); else fc.fetch((ck + 1) * 64 + lane, D, fn, cn);
+        if (TABLE) {
+            const unsigned long long bad = __ballot(err != BS_ST_OK);
+            if (bad) {  // first offending symbol of the chunk decides; nothing of this chunk is coded
+                st = __builtin_amdgcn_readlane(err, __ffsll((long long)bad) - 1);
+                break;
+            }
+        }
+        const double rf = 1.0 / (double)fv;  // 64 reciprocals at once
+        const int cnt = min(64, D - ck * 64);
+        for (int i = 0; i < cnt; ++i) {
+            const uint64_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, i);
+            const uint64_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, i);
+            const double rfi = readlane_f64(rf, i);
+            if ((h >> (64 - bits)) >= f) {  // h >= ((2^32 >> bits) << 32) * f, mnist_compress.py:52
+                wbuf = (lane == wpos) ? (uint32_t)h : wbuf;
+                h >>= 32;
+                if (++wpos == 64) {
+                    if (n + 64 > cap) { st = BS_ST_OVERFLOW; break; }
+                    stk[n + lane] = wbuf;
+                    n += 64;
+                    wpos = 0;
+                }
+            }
+            uint64_t q = (uint64_t)((double)h * rfi);
+            int64_t r = (int64_t)(h - q * f);
+            if (r < 0) { --q; r += (int64_t)f; }
+            else if (r >= (int64_t)f) { ++q; r -= (int64_t)f; }
+            h = (q << bits) + (uint64_t)r + c;
+        }
+        if (st != BS_ST_OK) break;
+        fv = fn;
+        cv = cn;
+        err = errn;
+    }
+    if (st == BS_ST_OK && wpos > 0) {
+        if (n + wpos > cap) st = BS_ST_OVERFLOW;
+        else {
+            if (lane < wpos) stk[n + lane] = wbuf;
+            n += wpos;
+        }
+    }
+    if (lane == 0) {
+        if (st == BS_ST_OK) {
+            head[b] = h;
+            len[b] = n;
+        } else {
+            status[b] = st;
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_rans_push(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
                                                   int32_t* __restrict__ len, int64_t cap,
                                                   const uint32_t* __restrict__ fs, const uint32_t* __restrict__ cs,
                                                   int B, int D, int bits, int32_t* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B || status[b] != BS_ST_OK) return;
-    uint64_t h = head[b];
-    int n = len[b];
-    uint32_t* stk = stack + (int64_t)b * cap;
-    const uint32_t* f = fs + (int64_t)b * D;
-    const uint32_t* c = cs + (int64_t)b * D;
-    int st = BS_ST_OK;
-    constexpr int U = 4;  // reciprocals of the next U symbols are independent of the head: overlap them
-    int d = 0;
-    for (; d + U <= D && st == BS_ST_OK; d += U) {
-        uint32_t fv[U], cv[U];
-        double rf[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { fv[u] = f[d + u]; cv[u] = c[d + u]; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) rf[u] = 1.0 / (double)fv[u];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (st == BS_ST_OK && !push_step(h, stk, n, cap, fv[u], cv[u], rf[u], bits)) st = BS_ST_OVERFLOW;
-    }
-    for (; d < D && st == BS_ST_OK; ++d)
-        if (!push_step(h, stk, n, cap, f[d], c[d], 1.0 / (double)f[d], bits)) st = BS_ST_OVERFLOW;
-    head[b] = h;
-    len[b] = n;
-    if (st != BS_ST_OK) status[b] = st;
+    const FcSource fc{fs + (int64_t)blockIdx.x * D, cs + (int64_t)blockIdx.x * D};
+    const TableSource none{nullptr, nullptr, 0, 0, 0, 0};
+    push_chain<false>(head, stack, len, cap, fc, none, D, bits, status);
 }
 
 __global__ __launch_bounds__(64) void k_rans_push_table(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
                                                         int32_t* __restrict__ len, int64_t cap,
                                                         const uint32_t* __restrict__ cdf, int64_t chain_stride,
-                                                        int64_t ld, const int32_t* __restrict__ sym, int B, int D,
-                                                        int K, int bits, int32_t* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B || status[b] != BS_ST_OK) return;
-    uint64_t h = head[b];
-    int n = len[b];
-    uint32_t* stk = stack + (int64_t)b * cap;
-    const uint32_t* tab = cdf + (int64_t)b * chain_stride;
-    const int32_t* sy = sym + (int64_t)b * D;
-    int st = BS_ST_OK;
-    for (int d = 0; d < D; ++d) {
-        const int s = sy[d];
-        if (s < 0 || s >= K) { st = BS_ST_BADSYMBOL; break; }
-        const uint32_t* row = tab + (int64_t)d * ld;
-        const uint32_t c0 = row[s], c1 = row[s + 1];
-        if (c1 <= c0) { st = BS_ST_BADTABLE; break; }
-        if (!push_step(h, stk, n, cap, c1 - c0, c0, 1.0 / (double)(c1 - c0), bits)) { st = BS_ST_OVERFLOW; break; }
-    }
-    head[b] = h;
-    len[b] = n;
-    if (st != BS_ST_OK) status[b] = st;
+                                                        int64_t ld, int layout, const int32_t* __restrict__ sym, int B,
+                                                        int D, int K, int bits, int32_t* __restrict__ status) {
+    const FcSource none{nullptr, nullptr};
+    const TableSource ts{cdf + (int64_t)blockIdx.x * chain_stride, sym + (int64_t)blockIdx.x * D, ld, layout, K, bits};
+    push_chain<true>(head, stack, len, cap, none, ts, D, bits, status);
 }
 
 __global__ void k_gather_centres(const double* __restrict__ centres, int64_t c_stride,
@@ -607,37 +758,34 @@ inline int launch_rc() { return hipGetLastError() == hipSuccess ? BS_OK : BS_ELA
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int NPL, typename PT>
-int launch_logistic(bool decode, bool vec, const double* endpoints, int64_t e_stride, const void* mu,
-                    const void* scale, const int32_t* sym, int B, int D, int bits, int quantbits,
-                    uint32_t* out0, uint32_t* out1, int64_t ld, int32_t* status, hipStream_t st) {
+int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
+                    const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0, uint32_t* out1,
+                    int64_t ld, int32_t* status, hipStream_t st) {
     // chains per wavefront: amortise the endpoint fetch, but keep >= ~8 waves per SIMD in flight
     int nb = 4;
     while (nb > 1 && (int64_t)((D + 3) / 4) * ((B + nb - 1) / nb) < 4096) nb >>= 1;
     dim3 grid((D + 3) / 4, (B + nb - 1) / nb), block(256);
     const PT* m = static_cast<const PT*>(mu);
     const PT* s = static_cast<const PT*>(scale);
-    if (decode) {
-        if (vec && NPL >= 4)
-            hipLaunchKernelGGL((k_logistic<NPL, PT, true, (NPL >= 4)>), grid, block, 0, st, endpoints, e_stride, m, s,
-                               sym, B, D, bits, quantbits, nb, out0, out1, ld, status);
-        else
-            hipLaunchKernelGGL((k_logistic<NPL, PT, true, false>), grid, block, 0, st, endpoints, e_stride, m, s, sym,
-                               B, D, bits, quantbits, nb, out0, out1, ld, status);
-    } else {
-        hipLaunchKernelGGL((k_logistic<NPL, PT, false, false>), grid, block, 0, st, endpoints, e_stride, m, s, sym, B,
-                           D, bits, quantbits, nb, out0, out1, ld, status);
-    }
+#define BS_LAUNCH(MODE)                                                                                          \
+    hipLaunchKernelGGL((k_logistic<NPL, PT, MODE>), grid, block, 0, st, endpoints, e_stride, m, s, sym, B, D, bits, \
+                       quantbits, nb, out0, out1, ld, status)
+    if (mode == M_WAVE && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR));
+    else if (mode == M_LINEAR_VEC && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_LINEAR_VEC : M_LINEAR));
+    else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE);
+    else BS_LAUNCH(M_LINEAR);
+#undef BS_LAUNCH
     return launch_rc();
 }
 
 template <typename PT>
-int dispatch_logistic(int K, bool decode, bool vec, const double* endpoints, int64_t e_stride, const void* mu,
-                      const void* scale, const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0,
-                      uint32_t* out1, int64_t ld, int32_t* status, hipStream_t st) {
-#define BS_CASE(NPL)                                                                                              \
-    case 64 * NPL:                                                                                                \
-        return launch_logistic<NPL, PT>(decode, vec, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits, \
-                                        out0, out1, ld, status, st)
+int dispatch_logistic(int K, int mode, const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
+                      const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0, uint32_t* out1,
+                      int64_t ld, int32_t* status, hipStream_t st) {
+#define BS_CASE(NPL)                                                                                             \
+    case 64 * NPL:                                                                                               \
+        return launch_logistic<NPL, PT>(mode, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits, out0, \
+                                        out1, ld, status, st)
     switch (K) {
         BS_CASE(1);
         BS_CASE(2);
@@ -695,17 +843,27 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
 }
 
 int bs_logistic_tables(const double* endpoints, int64_t e_stride, const void* mu, const void* scale, int param_dtype,
-                       int B, int D, int K, int bits, int quantbits, uint32_t* cdf_out, int64_t ld, void* stream) {
-    if (!endpoints || !mu || !scale || !cdf_out || B < 0 || D < 0 || ld < K + 1 || bits < 1 || bits > 31 ||
-        quantbits < 0 || quantbits >= bits || e_stride < 0)
+                       int B, int D, int K, int bits, int quantbits, uint32_t* cdf_out, int64_t ld, int layout,
+                       void* stream) {
+    if (!endpoints || !mu || !scale || !cdf_out || B < 0 || D < 0 || bits < 1 || bits > 31 || quantbits < 0 ||
+        quantbits >= bits || e_stride < 0)
         return BS_EINVAL;
+    int mode;
+    if (layout == BS_LAYOUT_LINEAR) {
+        if (ld < K + 1) return BS_EINVAL;
+        mode = (aligned16(cdf_out) && (ld % 4 == 0)) ? M_LINEAR_VEC : M_LINEAR;
+    } else if (layout == BS_LAYOUT_WAVE) {
+        if (ld < K + 64 || K < 256) return BS_EINVAL;
+        mode = M_WAVE;
+    } else {
+        return BS_EINVAL;
+    }
     if (B == 0 || D == 0) return BS_OK;
-    const bool vec = aligned16(cdf_out) && (ld % 4 == 0);
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_logistic<float>(K, true, vec, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
+        return dispatch_logistic<float>(K, mode, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
                                         cdf_out, nullptr, ld, nullptr, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_logistic<double>(K, true, vec, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
+        return dispatch_logistic<double>(K, mode, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
                                          cdf_out, nullptr, ld, nullptr, S(stream));
     return BS_EINVAL;
 }
@@ -718,10 +876,10 @@ int bs_logistic_fc(const double* endpoints, int64_t e_stride, const void* mu, co
         return BS_EINVAL;
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_logistic<float>(K, false, false, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
+        return dispatch_logistic<float>(K, M_ENCODE, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
                                         f_out, c_out, 0, status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_logistic<double>(K, false, false, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
+        return dispatch_logistic<double>(K, M_ENCODE, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
                                          f_out, c_out, 0, status, S(stream));
     return BS_EINVAL;
 }
@@ -731,42 +889,50 @@ int bs_rans_push(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, con
     if (!head || !stack || !len || !f || !c || !status || B < 0 || D < 0 || cap < 0 || bits < 1 || bits > 31)
         return BS_EINVAL;
     if (B == 0 || D == 0) return BS_OK;
-    hipLaunchKernelGGL(k_rans_push, dim3((B + 63) / 64), dim3(64), 0, S(stream), head, stack, len, cap, f, c, B, D,
-                       bits, status);
+    hipLaunchKernelGGL(k_rans_push, dim3(B), dim3(64), 0, S(stream), head, stack, len, cap, f, c, B, D, bits, status);
     return launch_rc();
 }
 
 int bs_rans_push_table(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* cdf,
-                       int64_t chain_stride, int64_t ld, const int32_t* sym, int B, int D, int K, int bits,
+                       int64_t chain_stride, int64_t ld, int layout, const int32_t* sym, int B, int D, int K, int bits,
                        int32_t* status, void* stream) {
-    if (!head || !stack || !len || !cdf || !sym || !status || B < 0 || D < 0 || cap < 0 || K < 1 || ld < K + 1 ||
+    if (!head || !stack || !len || !cdf || !sym || !status || B < 0 || D < 0 || cap < 0 || K < 1 ||
         chain_stride < 0 || bits < 1 || bits > 31)
         return BS_EINVAL;
+    if (layout == BS_LAYOUT_LINEAR ? ld < K + 1 : (layout != BS_LAYOUT_WAVE || ld < K + 64 || K % 256 != 0))
+        return BS_EINVAL;
     if (B == 0 || D == 0) return BS_OK;
-    hipLaunchKernelGGL(k_rans_push_table, dim3((B + 63) / 64), dim3(64), 0, S(stream), head, stack, len, cap, cdf,
-                       chain_stride, ld, sym, B, D, K, bits, status);
+    hipLaunchKernelGGL(k_rans_push_table, dim3(B), dim3(64), 0, S(stream), head, stack, len, cap, cdf, chain_stride,
+                       ld, layout, sym, B, D, K, bits, status);
     return launch_rc();
 }
 
 int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* cdf, int64_t chain_stride,
-                int64_t ld, int B, int D, int K, int bits, int32_t* sym_out, const double* centres, int64_t c_stride,
-                float* centre_out, int32_t* status, void* stream) {
-    if (!head || !stack || !len || !cdf || !sym_out || !status || B < 0 || D < 0 || cap < 0 || K < 1 || ld < K + 1 ||
+                int64_t ld, int layout, int B, int D, int K, int bits, int32_t* sym_out, const double* centres,
+                int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
+    if (!head || !stack || !len || !cdf || !sym_out || !status || B < 0 || D < 0 || cap < 0 || K < 1 ||
         chain_stride < 0 || bits < 1 || bits > 31 || (centres && !centre_out) || c_stride < 0)
         return BS_EINVAL;
+    if (layout == BS_LAYOUT_LINEAR ? ld < K + 1 : (layout != BS_LAYOUT_WAVE || ld < K + 64)) return BS_EINVAL;
     if (B == 0 || D == 0) return BS_OK;
     hipStream_t st = S(stream);
-    // fast path: 16-byte aligned rows, whole 64-row chunks, symbols of one chain fit in LDS
-    const bool vec = aligned16(cdf) && (ld % 4 == 0) && (chain_stride % 4 == 0) && (D % 64 == 0) && (D <= 16384);
+    // fast paths: 16-byte aligned rows, whole 64-row chunks, symbols of one chain fit in LDS
+    const bool fast = aligned16(cdf) && (ld % 4 == 0) && (chain_stride % 4 == 0) && (D % 64 == 0) && (D <= 16384);
     dim3 grid(B), block(64);
-#define BS_POP(NV)                                                                                                   \
-    hipLaunchKernelGGL((k_rans_pop<NV, (NV >= 8 ? 4 : 8)>), grid, block, (size_t)D * 4, st, head, stack, len, cap,  \
-                       cdf, chain_stride, ld, D, bits,                                                              \
-                       sym_out, centres, c_stride, centre_out, status)
-    if (vec && K == 256) BS_POP(1);
-    else if (vec && K == 512) BS_POP(2);
-    else if (vec && K == 1024) BS_POP(4);
-    else if (vec && K == 2048) BS_POP(8);
+#define BS_POP(ROW, PF)                                                                                          \
+    hipLaunchKernelGGL((k_rans_pop<ROW, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, cdf,        \
+                       chain_stride, ld, D, bits, sym_out, centres, c_stride, centre_out, status)
+    if (layout == BS_LAYOUT_WAVE) {
+        if (!fast) return BS_EINVAL;  // the wave layout only exists for the fast path
+        if (K == 256) BS_POP(WaveRow<4>, 8);
+        else if (K == 512) BS_POP(WaveRow<8>, 8);
+        else if (K == 1024) BS_POP(WaveRow<16>, 8);
+        else if (K == 2048) BS_POP(WaveRow<32>, 4);
+        else return BS_EUNSUPPORTED;
+    } else if (fast && K == 256) BS_POP(RowRegs<1>, 8);
+    else if (fast && K == 512) BS_POP(RowRegs<2>, 8);
+    else if (fast && K == 1024) BS_POP(RowRegs<4>, 8);
+    else if (fast && K == 2048) BS_POP(RowRegs<8>, 4);
     else
         hipLaunchKernelGGL(k_rans_pop_generic, grid, block, 0, st, head, stack, len, cap, cdf, chain_stride, ld, D, K,
                            bits, sym_out, centres, c_stride, centre_out, status);

@@ -13,6 +13,7 @@ from . import build as _build
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
 PARAM_F32, PARAM_F64 = 0, 1
+LAYOUT_LINEAR, LAYOUT_WAVE = 0, 1
 
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
@@ -50,11 +51,11 @@ def load():
     L.bs_strerror.restype = C.c_char_p
     L.bs_strerror.argtypes = [i32]
     L.bs_table_rows_f64.argtypes = [p, i64, i32, i32, i32, p, p, i64, p, p]
-    L.bs_logistic_tables.argtypes = [p, i64, p, p, i32, i32, i32, i32, i32, i32, p, i64, p]
+    L.bs_logistic_tables.argtypes = [p, i64, p, p, i32, i32, i32, i32, i32, i32, p, i64, i32, p]
     L.bs_logistic_fc.argtypes = [p, i64, p, p, i32, p, i32, i32, i32, i32, i32, p, p, p, p]
     L.bs_rans_push.argtypes = [p, p, p, i64, p, p, i32, i32, i32, p, p]
-    L.bs_rans_push_table.argtypes = [p, p, p, i64, p, i64, i64, p, i32, i32, i32, i32, p, p]
-    L.bs_rans_pop.argtypes = [p, p, p, i64, p, i64, i64, i32, i32, i32, i32, p, p, i64, p, p, p]
+    L.bs_rans_push_table.argtypes = [p, p, p, i64, p, i64, i64, i32, p, i32, i32, i32, i32, p, p]
+    L.bs_rans_pop.argtypes = [p, p, p, i64, p, i64, i64, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
     L.bs_gather_centres.argtypes = [p, i64, p, i32, i32, i32, p, p]
     L.bs_selftest.argtypes = [C.POINTER(C.c_int64), p]
     L.bs_sigmoid_f64.argtypes = [p, i64, p, p]
@@ -107,6 +108,21 @@ def aligned_ld(K):
     return (K + 1 + 3) // 4 * 4
 
 
+def wave_ld(K):
+    """Row stride of BS_LAYOUT_WAVE rows: K permuted entries + 64 pivots."""
+    return K + 64
+
+
+def table_layout(cdf, K):
+    """Layout of a cdf tensor made by logistic_tables(): tensors carry it as the attribute
+    `bs_layout`; plain tensors (tests, ANS) are linear."""
+    return getattr(cdf, "bs_layout", LAYOUT_LINEAR)
+
+
+def wave_supported(K):
+    return K in (256, 512, 1024, 2048)
+
+
 def selftest():
     n = C.c_int64(-1)
     _check(load().bs_selftest(C.byref(n), _stream()), "bs_selftest")
@@ -135,18 +151,23 @@ def table_rows(pmf, bits=31, quantbits=8, ld=None, want_f=True):
     return f, cdf, status
 
 
-def logistic_tables(endpoints, mu, scale, bits=31, quantbits=10, ld=None, out=None):
-    """Fused CDF -> integer cdf rows.  endpoints [D,K-1] f64, mu/scale [B,D] -> cdf [B,D,ld] int32."""
+def logistic_tables(endpoints, mu, scale, bits=31, quantbits=10, ld=None, out=None, layout=LAYOUT_LINEAR):
+    """Fused CDF -> integer cdf rows.  endpoints [D,K-1] f64, mu/scale [B,D] -> cdf [B,D,ld] int32.
+    layout=LAYOUT_WAVE writes the wave-native hand-off format (ld = K+64) that rans_pop searches
+    with two ballots; the returned tensor remembers its layout (`bs_layout`)."""
     _need_cuda(endpoints, mu, scale)
     B, D = mu.shape
     K = endpoints.shape[1] + 1
     endpoints, es = _row_stride(endpoints, K - 1)
     mu, scale = mu.contiguous(), scale.contiguous()
-    ld = ld or aligned_ld(K)
+    if out is not None:
+        ld = out.shape[-1]
+    ld = ld or (wave_ld(K) if layout == LAYOUT_WAVE else aligned_ld(K))
     if out is None:
         out = torch.empty((B, D, ld), dtype=torch.int32, device=mu.device)
     _check(load().bs_logistic_tables(_ptr(endpoints), es, _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K, bits,
-                                     quantbits, _ptr(out), ld, _stream()), "bs_logistic_tables")
+                                     quantbits, _ptr(out), ld, layout, _stream()), "bs_logistic_tables")
+    out.bs_layout = layout
     return out
 
 
@@ -229,25 +250,30 @@ def rans_push(state, f, c, bits=31):
                                B, D, bits, _ptr(state.status), _stream()), "bs_rans_push")
 
 
-def rans_push_table(state, cdf, sym, K, bits=31):
+def rans_push_table(state, cdf, sym, K, bits=31, layout=None):
     """cdf [B,D,ld] (per chain) or [D,ld] (shared by all chains); sym [B,D] int32."""
     _need_cuda(cdf, sym)
+    layout = table_layout(cdf, K) if layout is None else layout
     sym = sym.contiguous()
     if sym.dtype != torch.int32:
         sym = sym.to(torch.int32)
     B, D = sym.shape
-    cdf = cdf.contiguous()
+    if not cdf.is_contiguous():
+        cdf = cdf.contiguous()
     ld = cdf.shape[-1]
     chain_stride = 0 if cdf.dim() == 2 else D * ld
     _check(load().bs_rans_push_table(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(cdf),
-                                     chain_stride, ld, _ptr(sym), B, D, K, bits, _ptr(state.status), _stream()),
+                                     chain_stride, ld, layout, _ptr(sym), B, D,
+                                     K, bits, _ptr(state.status), _stream()),
            "bs_rans_push_table")
 
 
-def rans_pop(state, cdf, K, bits=31, centres=None, B=None):
+def rans_pop(state, cdf, K, bits=31, centres=None, B=None, layout=None):
     """Pop D symbols per chain.  Returns (sym [B,D] int32, z [B,D] float32 | None)."""
     _need_cuda(cdf, centres)
-    cdf = cdf.contiguous()
+    layout = table_layout(cdf, K) if layout is None else layout
+    if not cdf.is_contiguous():
+        cdf = cdf.contiguous()
     ld = cdf.shape[-1]
     if cdf.dim() == 2:
         D, chain_stride, B = cdf.shape[0], 0, (B or state.B)
@@ -260,7 +286,7 @@ def rans_pop(state, cdf, K, bits=31, centres=None, B=None):
         centres, cs = _row_stride(centres, K)
         z = torch.empty((B, D), dtype=torch.float32, device=cdf.device)
     _check(load().bs_rans_pop(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(cdf),
-                              chain_stride, ld, B, D, K, bits, _ptr(sym), _ptr(centres), cs, _ptr(z),
+                              chain_stride, ld, layout, B, D, K, bits, _ptr(sym), _ptr(centres), cs, _ptr(z),
                               _ptr(state.status), _stream()), "bs_rans_pop")
     return sym, z
 

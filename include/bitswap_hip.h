@@ -58,6 +58,16 @@ extern "C" {
 #define BS_PARAM_F32 0
 #define BS_PARAM_F64 1
 
+/* layout of an integer cdf row
+ *   BS_LAYOUT_LINEAR  row[j] = c_j, j = 0..K (the reference's ANS.cdfs row), ld >= K+1
+ *   BS_LAYOUT_WAVE    internal hand-off format between bs_logistic_tables and bs_rans_pop /
+ *                     bs_rans_push_table (K = 256*n, ld >= K+64, 16-byte aligned rows): the K entries
+ *                     c_0..c_{K-1} permuted so that a 64-lane wavefront's 16-byte loads leave entries
+ *                     64r..64r+63 in register r across its lanes (entry j at dword ((j/256)*64 + j%64)*4
+ *                     + (j/64)%4), followed at [K, K+64) by the pivots c_{(K/64)*l}, l = 0..63. */
+#define BS_LAYOUT_LINEAR 0
+#define BS_LAYOUT_WAVE 1
+
 int bs_abi_version(void);
 int bs_cdf_spec(void);
 const char* bs_strerror(int code);
@@ -81,14 +91,14 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
  *              all equal, may pass e_stride = 0).
  *   mu, scale [B,D] of param_dtype (the reference's Model emits float32 and casts up,
  *              model/mnist_train.py:375-376; both are converted to f64 exactly).
- *   cdf_out [B,D,ld].
+ *   cdf_out [B,D,ld] in `layout` (BS_LAYOUT_LINEAR or BS_LAYOUT_WAVE).
  * The CDF is evaluated in float64 by the deterministic routine of DESIGN.md (BS_CDF_SPEC);
  * it agrees with torch.sigmoid to a few ulp, everything after it is exact integer work.
  * K must be 64*n, n in {1,2,4,8,16,32}.
  */
 int bs_logistic_tables(const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
                        int param_dtype, int B, int D, int K, int bits, int quantbits,
-                       uint32_t* cdf_out, int64_t ld, void* stream);
+                       uint32_t* cdf_out, int64_t ld, int layout, void* stream);
 
 /*
  * bs_logistic_fc -- same fused computation, "encode flavour": given the symbol of every
@@ -116,7 +126,7 @@ int bs_rans_push(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
  * the image-independent prior, mnist_compress.py:246-251).  sym [B,D].
  */
 int bs_rans_push_table(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
-                       const uint32_t* cdf, int64_t chain_stride, int64_t ld, const int32_t* sym,
+                       const uint32_t* cdf, int64_t chain_stride, int64_t ld, int layout, const int32_t* sym,
                        int B, int D, int K, int bits, int32_t* status, void* stream);
 
 /*
@@ -129,8 +139,8 @@ int bs_rans_push_table(uint64_t* head, uint32_t* stack, int32_t* len, int64_t ca
  * model/mnist_train.py:324,392.
  */
 int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
-                const uint32_t* cdf, int64_t chain_stride, int64_t ld, int B, int D, int K, int bits,
-                int32_t* sym_out, const double* centres, int64_t c_stride, float* centre_out,
+                const uint32_t* cdf, int64_t chain_stride, int64_t ld, int layout, int B, int D, int K,
+                int bits, int32_t* sym_out, const double* centres, int64_t c_stride, float* centre_out,
                 int32_t* status, void* stream);
 
 /*

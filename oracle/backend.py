@@ -60,6 +60,12 @@ class OracleBackend:
     def new_state(self, states, cap):
         return OracleState(states, cap)
 
+    def table_buffer(self, B, D, K):
+        return None
+
+    def shared_table(self, endpoints, mu, scale, quantbits, bits):
+        return self.tables(endpoints, mu, scale, quantbits, bits)[0]
+
     def tables(self, endpoints, mu, scale, quantbits, bits, out=None):
         return _Tables(self._np(endpoints).astype(np.float64), self._np(mu).astype(np.float64),
                        self._np(scale).astype(np.float64), quantbits)

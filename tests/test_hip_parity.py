@@ -301,3 +301,51 @@ def test_full_size_round_trip_property():
         # every cdf row is a valid table
         t = u32(cdf[:4])[:, :, : K + 1].astype(np.int64)
         assert np.all(t[:, :, 0] == 0) and np.all(t[:, :, -1] == 1 << 31) and np.all(np.diff(t, axis=2) >= 1)
+
+
+def unpermute_wave(rows, K):
+    """BS_LAYOUT_WAVE row [K+64] -> (c_0..c_{K-1}, pivots) following include/bitswap_hip.h."""
+    j = np.arange(K)
+    off = ((j // 256) * 64 + j % 64) * 4 + (j // 64) % 4
+    return rows[..., off], rows[..., K:K + 64]
+
+
+@pytest.mark.parametrize("K", [256, 512, 1024, 2048])
+def test_wave_layout_tables_and_pop(K):
+    """The wave-native hand-off format: same integers as the linear rows, permuted; popping from it
+    gives the same symbols and the same state words as popping from linear rows."""
+    h = hip()
+    q = int(np.log2(K))
+    rng = np.random.RandomState(K + 1)
+    D, B = 128, 5
+    lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
+    e = dev(np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)]))
+    mu = dev(rng.randn(B, D).astype(np.float32))
+    sc = dev(rng.uniform(0.1, 1, (B, D)).astype(np.float32))
+    lin = h.logistic_tables(e, mu, sc, 31, q)
+    wav = h.logistic_tables(e, mu, sc, 31, q, layout=h.LAYOUT_WAVE)
+    assert wav.shape[-1] == K + 64 and wav.bs_layout == h.LAYOUT_WAVE
+    c, piv = unpermute_wave(u32(wav), K)
+    assert np.array_equal(c, u32(lin)[:, :, :K])
+    assert np.array_equal(piv, u32(lin)[:, :, 0:K:K // 64])
+    states = [reference_init_state(4000, seed=7 + b) for b in range(B)]
+    s1 = h.RansState.from_lists(states, cap=6000, device=DEV)
+    s2 = h.RansState.from_lists(states, cap=6000, device=DEV)
+    cen = dev(rng.randn(D, K))
+    sym1, z1 = h.rans_pop(s1, lin, K, centres=cen)
+    sym2, z2 = h.rans_pop(s2, wav, K, centres=cen)
+    s1.check(); s2.check()
+    assert torch.equal(sym1, sym2) and torch.equal(z1, z2)
+    assert s1.to_lists() == s2.to_lists()
+    # push back through the wave table (shared-table form with chain 0's rows, and per-chain form)
+    h.rans_push_table(s2, wav, sym2, K)
+    s2.check()
+    assert s2.to_lists() == states
+    one = wav[0]
+    one.bs_layout = h.LAYOUT_WAVE
+    s3 = h.RansState.from_lists([states[0]] * 2, cap=6000, device=DEV)
+    sym3, _ = h.rans_pop(s3, one, K)
+    assert torch.equal(sym3[0], sym3[1])
+    h.rans_push_table(s3, one, sym3, K)
+    s3.check()
+    assert s3.to_lists() == [states[0]] * 2

@@ -67,10 +67,18 @@ def main():
         for _ in range(args.iters):
             tp.append(timeit(only_pop, 1, 0))
             tq.append(timeit(only_push, 1, 0))
+        # wave-native hand-off layout
+        wcdf = torch.empty((B, D, hip.wave_ld(K)), dtype=torch.int32, device=dev)
+        t_wtab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=wcdf, layout=hip.LAYOUT_WAVE), args.iters)
+        wcdf.bs_layout = hip.LAYOUT_WAVE
+        tw = []
+        for _ in range(args.iters):
+            tw.append(timeit(lambda: hip.rans_pop(st, wcdf, K), 1, 0))
+            hip.rans_push(st, fo[0], fo[1])
         st.check()
         rows = B * D
         alg = rows * ((K - 1) * 8 + 12)
-        res[name] = dict(B=B, D=D, K=K, tables_s=t_tab, fc_s=t_fc, pop_s=float(np.median(tp)), push_s=float(np.median(tq)),
+        res[name] = dict(B=B, D=D, K=K, tables_s=t_tab, tables_wave_s=t_wtab, pop_wave_s=float(np.median(tw)), fc_s=t_fc, pop_s=float(np.median(tp)), push_s=float(np.median(tq)),
                          tables_rows_per_s=rows / t_tab, tables_alg_GBps=alg / t_tab / 1e9,
                          fc_alg_GBps=alg / t_fc / 1e9, sigmoids_per_s_tables=rows * (K - 1) / t_tab)
     print(json.dumps(res, indent=1))
