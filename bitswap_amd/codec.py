@@ -12,6 +12,8 @@ constructs only `HipBackend` (HIP kernels through the C ABI, no fallback).  test
 cpu_baseline leg may pass the oracle-backed stand-in from oracle/backend.py to run the very same
 schedule code on the CPU.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -144,6 +146,10 @@ class BitSwapCodec:
         self.xend, self.xcen = xb.endpoints(), xb.centres()   # expanded views, row stride 0
         self.tl = timeline or Timeline(False)
         self._cdf_bufs = {}
+        # optional stream split (GroupedCodec): convs + table kernels on `bulk`, the serial rANS kernels
+        # on `serial`; None = everything on the caller's current stream
+        self.bulk = self.serial = None
+        self._ev_serial = None
         # the prior p(z_L) = Logistic(0,1) table does not depend on the image: build it once
         # (the reference rebuilds it for every image, mnist_compress.py:246-251)
         one = torch.ones((1, self.Z), dtype=torch.float32, device=dev)
@@ -168,13 +174,41 @@ class BitSwapCodec:
             self._cdf_bufs[key] = buf
         return buf
 
+    # ---- stream split helpers ---------------------------------------------------------------------
+    def _on(self, stream):
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def _serial_waits_bulk(self):
+        if self.serial is not None:
+            self.serial.wait_stream(self.bulk)
+
+    def _bulk_waits_serial(self):
+        """Before a conv stack that consumes symbols popped on the serial stream."""
+        if self.serial is not None and self._ev_serial is not None:
+            self.bulk.wait_event(self._ev_serial)
+
+    def _mark_serial(self):
+        if self.serial is not None:
+            self._ev_serial = self.serial.record_event()
+
+    def _share(self, tensors, stream):
+        """Tell the caching allocator that `tensors` are also used on `stream`."""
+        if stream is not None:
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(stream)
+
     def _pop_layer(self, state, endpoints, centres, mu, scale, quantbits, K, key):
-        with self.tl.span("tables_" + key):
+        with self._on(self.bulk), self.tl.span("tables_" + key):
             cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
                                       out=self._cdf(mu.shape[0], mu.shape[1], K))
-        with self.tl.span("pop_" + key):
-            out = self.backend.pop(state, cdf, K, self.bits, centres=centres)
-        self._track_min(state)
+        self._serial_waits_bulk()
+        with self._on(self.serial):
+            with self.tl.span("pop_" + key):
+                out = self.backend.pop(state, cdf, K, self.bits, centres=centres)
+            self._track_min(state)
+            self._share(out, self.bulk)
+        self._mark_serial()
         return out
 
     @staticmethod
@@ -186,33 +220,63 @@ class BitSwapCodec:
             torch.minimum(ml, state.len.to(ml.device), out=ml)
 
     def _push_layer(self, state, endpoints, mu, scale, sym, quantbits, key):
-        with self.tl.span("push_" + key):
-            self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits)
+        if self.serial is None:
+            with self.tl.span("push_" + key):
+                self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits)
+            return
+        with self._on(self.bulk), self.tl.span("fc_" + key):
+            f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, self.bits, quantbits)
+            self._share((f, c), self.serial)
+        self._serial_waits_bulk()
+        with self._on(self.serial), self.tl.span("push_" + key):
+            hip.rans_push(state, f, c, self.bits)
 
     def _net(self, fn, given):
-        with self.tl.span("net"), torch.no_grad():
+        self._bulk_waits_serial()
+        with self._on(self.bulk), self.tl.span("net"), torch.no_grad():
             mu, scale = fn(given)
-        return mu.contiguous(), scale.contiguous()
+            mu, scale = mu.contiguous(), scale.contiguous()
+        return mu, scale
 
     # ------------------------------------------------------------------------------------------
     def encode_block(self, state, x, rest_len=None):
         """Sender, one block per chain.  x [B, X] integer pixels.  If `rest_len` is a tensor it
         receives the word count right after the first bits-back pop(s) (restbits, :191-193,225-227)."""
+        for _ in self.encode_steps(state, x, rest_len):
+            pass
+
+    def decode_block(self, state):
+        """Receiver, one block per chain (exact mirror).  Returns x [B, X] int32."""
+        out = None
+        for out in self.decode_steps(state):
+            pass
+        return out
+
+    def _snap(self, dst, state):
+        with self._on(self.serial):
+            dst.copy_(state.len)
+
+    def encode_steps(self, state, x, rest_len=None):
+        """Generator form of encode_block: yields after every coding operation has been enqueued, so a
+        scheduler (GroupedCodec) can interleave the enqueue order of several chain groups."""
         m, nz = self.model, self.nz
-        x = x.to(self.device, torch.int32).contiguous()
-        given = self.backend.centres(self.xcen, x)            # xcentres[xrange, x] -> float32
+        with self._on(self.bulk):
+            x = x.to(self.device, torch.int32).contiguous()
+            given = self.backend.centres(self.xcen, x)            # xcentres[xrange, x] -> float32
         if self.bitswap:
             zsym = None
             for zi in range(nz):
                 mu, sc = self._net(m.infer(zi), given)
                 zsymtop, z = self._pop_layer(state, self.zend[zi], self.zcen[zi], mu, sc, self.q, self.K, "z")
                 if rest_len is not None and zi == 0:
-                    rest_len.copy_(state.len)
+                    self._snap(rest_len, state)
+                yield
                 mu, sc = self._net(m.generate(zi), z)
                 if zi == 0:
                     self._push_layer(state, self.xend, mu, sc, x, 8, "x")
                 else:
                     self._push_layer(state, self.zend[zi - 1], mu, sc, zsym, self.q, "z")
+                yield
                 zsym, given = zsymtop, z
         else:
             syms, zs = [], []
@@ -222,25 +286,32 @@ class BitSwapCodec:
                 syms.append(s)
                 zs.append(z)
                 given = z
+                yield
             if rest_len is not None:
-                rest_len.copy_(state.len)
+                self._snap(rest_len, state)
             for zi in range(nz):
                 mu, sc = self._net(m.generate(zi), zs[zi])
                 if zi == 0:
                     self._push_layer(state, self.xend, mu, sc, x, 8, "x")
                 else:
                     self._push_layer(state, self.zend[zi - 1], mu, sc, syms[zi - 1], self.q, "z")
+                yield
             zsymtop = syms[-1]
-        with self.tl.span("push_prior"):
+        with self._on(self.serial), self.tl.span("push_prior"):
             self.backend.push_table(state, self.prior_cdf, zsymtop, self.K, self.bits)
+        yield
 
-    def decode_block(self, state):
-        """Receiver, one block per chain (exact mirror).  Returns x [B, X] int32."""
+    def decode_steps(self, state):
+        """Generator form of decode_block; the last yielded value is x [B, X] int32."""
         m, nz = self.model, self.nz
-        with self.tl.span("pop_prior"):
-            # prior table [Z, ld] is shared by every chain (chain stride 0)
-            zsymtop, z = self.backend.pop(state, self.prior_cdf, self.K, self.bits, centres=self.zcen[-1])
-        self._track_min(state)
+        with self._on(self.serial):
+            with self.tl.span("pop_prior"):
+                # prior table [Z, ld] is shared by every chain (chain stride 0)
+                zsymtop, z = self.backend.pop(state, self.prior_cdf, self.K, self.bits, centres=self.zcen[-1])
+            self._track_min(state)
+            self._share((zsymtop, z), self.bulk)
+        self._mark_serial()
+        yield None
         if self.bitswap:
             for zi in reversed(range(nz)):
                 mu, sc = self._net(m.generate(zi), z)
@@ -249,10 +320,13 @@ class BitSwapCodec:
                 else:
                     sym, given = self._pop_layer(state, self.zend[zi - 1], self.zcen[zi - 1], mu, sc, self.q,
                                                  self.K, "z")
+                yield None
                 mu, sc = self._net(m.infer(zi), given)
                 self._push_layer(state, self.zend[zi], mu, sc, zsymtop, self.q, "z")
+                yield None
                 zsymtop, z = sym, given
-            return zsymtop
+            yield zsymtop
+            return
         syms, cens = [zsymtop], [z]
         for zi in reversed(range(nz)):
             mu, sc = self._net(m.generate(zi), cens[-1])
@@ -262,11 +336,13 @@ class BitSwapCodec:
                 s, c = self._pop_layer(state, self.zend[zi - 1], self.zcen[zi - 1], mu, sc, self.q, self.K, "z")
             syms.append(s)
             cens.append(c)
+            yield None
         # syms = [z_L, ..., z_1, x]; push z_L .. z_1 back under q(z_i | z_{i-1} or x)
         for k, zi in enumerate(reversed(range(nz))):
             mu, sc = self._net(m.infer(zi), cens[k + 1])
             self._push_layer(state, self.zend[zi], mu, sc, syms[k], self.q, "z")
-        return syms[-1]
+            yield None
+        yield syms[-1]
 
     # ------------------------------------------------------------------------------------------
     def compress(self, images, state=None, nwords=10000, seed=100):
@@ -282,7 +358,7 @@ class BitSwapCodec:
         lens = torch.zeros((n, B), dtype=torch.int32, device=state.len.device)
         for xi in range(n):
             self.encode_block(state, images[:, xi], rest_len if xi == 0 else None)
-            lens[xi].copy_(state.len)
+            self._snap(lens[xi], state)
         self.backend.check(state, "compress")
         lens, init_len, rest_len = lens.cpu().numpy().T.astype(np.int64), init_len.cpu().numpy(), rest_len.cpu().numpy()
         added = (lens - init_len[:, None]) * 32                      # totaladdedbits (:254)
@@ -304,18 +380,25 @@ class BitSwapCodec:
 class GroupedCodec:
     """Software pipelining across chain groups.
 
-    The serial rANS kernels keep one wavefront (pop) or one lane (push) busy per chain -- under 10 %
-    of an MI355X at 100 chains -- while the conv stacks want the whole chip.  Splitting the chains
-    into G groups, each with its own HIP stream, state and buffers, lets group A's pops/pushes run
-    underneath group B's convs.  Chains never interact, so results are identical to coding each
-    group on its own; with `nn_batch` set on the model they are also identical to the ungrouped run.
+    The serial rANS kernels keep one wavefront busy per chain -- a few percent of an MI355X at 100
+    chains -- while the conv stacks and the table kernels want the whole chip.  The chains are split
+    into G groups.  All groups share ONE bulk stream (convs, fused logistic/table kernels: they run one
+    after another at full width and never compete with each other) and each group has its own serial
+    stream for pop/push.  The enqueue order is interleaved at coding-operation granularity, so while
+    group A's pop runs on its serial stream the bulk stream is already executing group B's convs.
+    Chains never interact: results are identical to coding each group on its own.
     """
 
     def __init__(self, model, zendpoints, zcentres, groups=2, **kw):
         self.codecs = [BitSwapCodec(model, zendpoints, zcentres, **kw) for _ in range(groups)]
-        self.streams = [torch.cuda.Stream(device=zendpoints.device) for _ in range(groups)]
         self.device = zendpoints.device
         self.X, self.Z, self.K = self.codecs[0].X, self.codecs[0].Z, self.codecs[0].K
+        self.bulk = None
+        if groups > 1:
+            self.bulk = torch.cuda.Stream(device=self.device)
+            for c in self.codecs:
+                c.bulk = self.bulk
+                c.serial = torch.cuda.Stream(device=self.device)
 
     def split(self, n):
         g = len(self.codecs)
@@ -329,36 +412,67 @@ class GroupedCodec:
         return [c.new_states(sl.stop - sl.start, nblocks, states=states[sl])
                 for c, sl in zip(self.codecs, self.split(nchains))]
 
+    def _streams(self):
+        return [] if self.bulk is None else [self.bulk] + [c.serial for c in self.codecs]
+
     def _fork(self):
         cur = torch.cuda.current_stream(self.device)
-        for s in self.streams:
+        for s in self._streams():
             s.wait_stream(cur)
+        for c in self.codecs:
+            c._ev_serial = None
 
     def _join(self):
         cur = torch.cuda.current_stream(self.device)
-        for s in self.streams:
+        for s in self._streams():
             cur.wait_stream(s)
 
+    @staticmethod
+    def _round_robin(gens, skew=1):
+        """Advance the generators in turn; group g starts g*skew operations late so that one group's
+        serial kernel coincides with another group's conv stack."""
+        live = list(range(len(gens)))
+        last = [None] * len(gens)
+        tick = 0
+        while live:
+            for g in list(live):
+                if tick >= g * skew:
+                    try:
+                        last[g] = next(gens[g])
+                    except StopIteration:
+                        live.remove(g)
+            tick += 1
+        return last
+
     def encode_blocks(self, states, images, rest_lens=None):
-        """images [B, n, X]: n block steps of every group.  Streams are forked once and joined once, so
-        a group never waits for another one between blocks."""
+        """images [B, n, X]: n block steps of every group, enqueue order interleaved per coding op."""
         B, n, _ = images.shape
         sls = self.split(B)
         self._fork()
-        for xi in range(n):
-            for g, (c, st) in enumerate(zip(self.codecs, states)):
-                with torch.cuda.stream(self.streams[g]):
-                    c.encode_block(st, images[sls[g], xi], rest_lens[g] if (rest_lens is not None and xi == 0) else None)
+
+        def chain_of_blocks(g):
+            c, st = self.codecs[g], states[g]
+            for xi in range(n):
+                yield from c.encode_steps(st, images[sls[g], xi],
+                                          rest_lens[g] if (rest_lens is not None and xi == 0) else None)
+        self._round_robin([chain_of_blocks(g) for g in range(len(self.codecs))])
         self._join()
 
     def decode_blocks(self, states, n):
         """-> [B, n, X] int32, blocks in original order."""
         outs = [[None] * n for _ in self.codecs]
         self._fork()
-        for xi in reversed(range(n)):
-            for g, (c, st) in enumerate(zip(self.codecs, states)):
-                with torch.cuda.stream(self.streams[g]):
-                    outs[g][xi] = c.decode_block(st)
+
+        def chain_of_blocks(g):
+            c, st = self.codecs[g], states[g]
+            for xi in reversed(range(n)):
+                x = None
+                for x in c.decode_steps(st):
+                    yield
+                if x is not None and x.is_cuda:
+                    x.record_stream(torch.cuda.current_stream(self.device))
+                outs[g][xi] = x
+        self._round_robin([chain_of_blocks(g) for g in range(len(self.codecs))])
         self._join()
         return torch.cat([torch.stack(o, dim=1) for o in outs], dim=0)
 
