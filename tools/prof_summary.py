@@ -3,6 +3,7 @@
 
     python tools/prof_summary.py stats <dir> <out.txt>       # --kernel-trace --stats run
     python tools/prof_summary.py pmc <dir> <counter> <out.json>   # --pmc <counter> run
+    python tools/prof_summary.py traffic <fetch.json> <write.json> <workload> <traffic.json>
 """
 import csv
 import glob
@@ -57,8 +58,30 @@ def pmc(d, counter, out):
         print(n[:90], v)
 
 
+def traffic(fetch_json, write_json, workload, out):
+    """HBM bytes per launch of the roofline kernel (fused logistic -> cdf rows, decode flavour, K = 1024),
+    corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: counters are in KiB,
+    FETCH_SIZE under-reports wide coalesced reads by exactly 2x (doubled here), WRITE_SIZE taken as is."""
+    def per(path, counter):
+        d = json.load(open(path))
+        for k, v in d.items():
+            if "k_logistic<16, float, 3>" in k or "k_logistic<16, float, true" in k:
+                return v[f"{counter}_per_dispatch"] * 1024.0, v["dispatches"]
+        return None, 0
+    f, nf = per(fetch_json, "FETCH_SIZE")
+    w, nw = per(write_json, "WRITE_SIZE")
+    res = json.load(open(out)) if os.path.exists(out) else {}
+    res[workload] = {"k_logistic_decode_bytes_per_launch": None if f is None or w is None else int(2 * f + w),
+                     "fetch_bytes_raw": f, "fetch_correction": 2.0, "write_bytes": w, "dispatches": [nf, nw],
+                     "source": [os.path.basename(fetch_json), os.path.basename(write_json)]}
+    json.dump(res, open(out, "w"), indent=1)
+    print(res[workload])
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
