@@ -39,14 +39,16 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cifar8", choices=["mnist2", "cifar8", "imagenet4", "imagenetcrop4"])
-    ap.add_argument("--chains", type=int, default=100, help="chains per GPU (reference: 100 experiments)")
+    ap.add_argument("--chains", type=int, default=400,
+                    help="independent chains (rANS streams) per GPU; the reference runs 100 'experiments' one block at a time, "
+                         "an MI355X wants a few hundred in lock-step (conv efficiency grows with the batch, DESIGN.md 6)")
     ap.add_argument("--quantbits", type=int, default=10)
     ap.add_argument("--bitswap", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-blocks", type=int, default=1, help="blocks per chain in the CPU baseline sample")
+    ap.add_argument("--cpu-blocks", type=int, default=12, help="blocks per chain in the CPU baseline sample")
     ap.add_argument("--no-timeline", action="store_true", help="skip per-kernel events (roofline becomes null)")
     ap.add_argument("--groups", type=int, default=2,
                     help="chain groups per GPU on separate HIP streams (serial rANS of one group under the convs of another)")
@@ -167,7 +169,8 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(name, {}).get("k_logistic_decode_bytes_per_launch")
+                per_row = json.load(open(tp)).get(name, {}).get("k_logistic_decode_bytes_per_row")
+                traffic = None if per_row is None else int(per_row * rows)   # PMC bytes/row x rows of one launch
             except Exception:
                 traffic = None
         roof = {"kernel": "k_logistic<16,float,decode> (fused logistic CDF -> integer cdf rows)", "bound": "hbm",

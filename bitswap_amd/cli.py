@@ -61,7 +61,8 @@ def load_model(dataset, nz, device, params, synthetic, nn_batch=None):
     if os.path.exists(path):
         m = preset(dataset, nz, nn_batch=nn_batch)
         m.load_state_dict(torch.load(path, map_location="cpu"))
-        return m.to(device).eval().fold()
+        m = m.to(device).eval().fold()
+        return m.fuse() if torch.device(device).type == "cuda" else m
     if synthetic:
         return workload.synthetic_model(dataset, nz, device, nn_batch=nn_batch)
     raise FileNotFoundError(f"checkpoint {path} not found -- pass --params <file> or --synthetic")

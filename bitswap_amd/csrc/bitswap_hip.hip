@@ -67,16 +67,17 @@ __device__ __forceinline__ double lane_shift_up_f64(double v) {
 // compiled with -ffp-contract=off so nothing else is fused.  oracle/bitswap_oracle.c carries
 // an independent C restatement that must agree bit for bit.
 // ------------------------------------------------------------------------------------------
-// Correctly rounded 1/x for x in [1, 2^1011): hardware seed, two Newton steps, one residual correction
-// -- the sequence hipcc emits for an IEEE f64 division minus the v_div_scale / v_div_fixup range
-// handling, which this argument range never needs.  The spec demands RN(1/x); parity with the
-// oracle's `1.0 / x` is asserted bit for bit (tests/test_hip_parity.py::test_sigmoid_bit_exact_vs_oracle).
+// Correctly rounded 1/x for x in [1, 2^1011): hardware seed (|rel err| <= 2^-24.4 measured), ONE cubic
+// Newton step (-> 2^-73), one residual correction.  The spec demands RN(1/x), whatever the seed: this
+// sequence agrees with IEEE division on 1.7e10 arguments incl. the all-ones-mantissa hard cases
+// (tools/recip_check.hip), and parity with the oracle's `1.0 / x` is asserted bit for bit
+// (tests/test_hip_parity.py::test_sigmoid_bit_exact_vs_oracle).  v_rcp_f64 issues at quarter rate
+// (tools/instr_rate.hip): 4 + 5 issue slots here against 4 + 9 for hipcc's generic f64 division.
 __device__ __forceinline__ double recip_1_to_huge(double x) {
     double y = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
+    const double e = fma(-x, y, 1.0);
+    const double t = fma(e, e, e);
+    y = fma(y, t, y);
     const double r = fma(-x, y, 1.0);
     return fma(r, y, y);
 }
@@ -104,34 +105,60 @@ __device__ __forceinline__ double det_sigmoid(double t) {
 }
 
 // ------------------------------------------------------------------------------------------
-// integer tail shared by the table kernels: f[] (NPL consecutive bins per lane) -> remnant bump
-// on the first maximal bin -> exclusive prefix (returned: the lane's starting cumulative value)
+// integer tail shared by the table kernels.  A lane holds t[i] = trunc(pmf * M) of NPL consecutive bins
+// (the reference's frequency is f = t + 1, mnist_compress.py:30,33; the +1 is folded into the sums and
+// into the running cdf `c = c + t + 1`, one v_add3_u32).  On return the first maximal bin has absorbed the
+// remnant 2^bits - sum f (first max wins like torch.argmax, :36) and the result is the lane's starting
+// cumulative value.  Per bin this costs 1/2 add3 + 1/2 max3 + 1 compare on the VALU; which bin of the
+// winning lane is maximal is resolved on the scalar unit, and the bump is ONE scalar-indexed register add.
 // ------------------------------------------------------------------------------------------
 template <int NPL>
-__device__ __forceinline__ uint32_t bump_and_scan(uint32_t (&f)[NPL], int lane, int bits, bool& bad) {
-    uint32_t fsum = 0, best = 0;
-    int barg = 0;
+struct Bins {
+    typedef uint32_t vec_t __attribute__((ext_vector_type(NPL)));
+    vec_t t;
+};
+template <>
+struct Bins<1> {
+    struct vec_t {
+        uint32_t x;
+        __device__ __forceinline__ uint32_t& operator[](int) { return x; }
+        __device__ __forceinline__ const uint32_t& operator[](int) const { return x; }
+    };
+    vec_t t;
+};
+
+template <int NPL>
+__device__ __forceinline__ uint32_t bump_and_scan(Bins<NPL>& bn, int lane, int bits, bool& bad) {
+    uint32_t tsum = NPL, best = 0;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        fsum += f[i];
-        if (f[i] > best) { best = f[i]; barg = i; }
+        tsum += bn.t[i];
+        best = max(best, bn.t[i]);
     }
-    const uint32_t incl0 = wave_incl_scan_add(fsum);
+    const uint32_t incl0 = wave_incl_scan_add(tsum);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
     const uint32_t mx = wave_max_u32(best);
-    const unsigned long long who = __ballot(best == mx);
-    const int first = __ffsll((long long)who) - 1;
+    const int first = __ffsll((long long)__ballot(best == mx)) - 1;  // wave-uniform
+    // first maximal bin inside lane `first`: bit `first` of the 64-lane compare masks, descending so the
+    // smallest index is the one that sticks
+    int barg = 0;
+#pragma unroll
+    for (int i = NPL - 1; i >= 0; --i) {
+        const unsigned long long eq = __ballot(bn.t[i] == mx);
+        barg = ((eq >> first) & 1ull) ? i : barg;
+    }
+    barg = __builtin_amdgcn_readfirstlane(barg);
     const uint32_t rem = (1u << bits) - total;  // two's complement: may be "negative"
     const bool mine = lane == first;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-        if (mine && i == barg) f[i] += rem;
-    bad = mine && ((int32_t)(best + rem) < 1);
+    bn.t[barg] += mine ? rem : 0u;
+    bad = mine && ((int32_t)(mx + 1u + rem) < 1);
     // exclusive prefix of the bumped per-lane sums: lanes after `first` shift by rem
-    uint32_t excl = incl0 - fsum;
+    uint32_t excl = incl0 - tsum;
     if (lane > first) excl += rem;
     return excl;
 }
+
+__device__ __forceinline__ uint32_t trunc_u32(double x) { return (uint32_t)(int32_t)x; }
 
 // ------------------------------------------------------------------------------------------
 // k_logistic: fused logistic CDF -> integer table, NPL = K/64 bins per lane
@@ -148,13 +175,14 @@ __device__ __forceinline__ int wave_offset(int j) {
 }
 
 template <int NPL, typename PT, int MODE>
-__global__ __launch_bounds__(256) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
                                                   const PT* __restrict__ mu, const PT* __restrict__ scale,
                                                   const int32_t* __restrict__ sym, int B, int D, int bits,
                                                   int quantbits, int nb, uint32_t* __restrict__ out0,
                                                   uint32_t* __restrict__ out1, int64_t ld,
                                                   int32_t* __restrict__ status) {
     constexpr int K = NPL * 64;
+    __shared__ uint32_t stage[MODE == M_WAVE ? 4 * 64 * (NPL + 1) : 1];
     const int lane = threadIdx.x & 63;
     const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (d >= D) return;
@@ -168,12 +196,18 @@ __global__ __launch_bounds__(256) void k_logistic(const double* __restrict__ end
     for (int i = 0; i < NPL; ++i) e[i] = (lane * NPL + i < K - 1) ? er[i] : 0.0;
 
     const double M = (double)((1ll << bits) - (1ll << quantbits));
+    // (mu, scale) of the next chain are fetched while the current one is computed: the row is
+    // wave-uniform, so these are scalar loads whose latency would otherwise sit in front of every row
+    PT mu_n = mu[(int64_t)b0 * D + d], sc_n = scale[(int64_t)b0 * D + d];
     for (int b = b0; b < b1; ++b) {
         const int64_t row = (int64_t)b * D + d;
-        const double m_ = (double)mu[row];
-        const double rs = 1.0 / (double)scale[row];
+        const double m_ = (double)mu_n;
+        const double rs = 1.0 / (double)sc_n;
+        const int64_t nrow = (int64_t)min(b + 1, b1 - 1) * D + d;
+        mu_n = mu[nrow];
+        sc_n = scale[nrow];
 
-        uint32_t f[NPL];
+        Bins<NPL> bn;
         double c0 = det_sigmoid((e[0] - m_) * rs);
         if (NPL == 1 && lane == 63) c0 = 1.0;
         double prev = c0;
@@ -181,59 +215,75 @@ __global__ __launch_bounds__(256) void k_logistic(const double* __restrict__ end
         for (int i = 1; i < NPL; ++i) {
             double c = det_sigmoid((e[i] - m_) * rs);
             if (i == NPL - 1 && lane == 63) c = 1.0;
-            f[i] = (uint32_t)((int32_t)((c - prev) * M) + 1);
+            bn.t[i] = trunc_u32((c - prev) * M);
             prev = c;
         }
         double below = lane_shift_up_f64(prev);
         // reference: pmf[0] = cdf[0] (no subtraction), mnist_compress.py:185
         const double p0 = (lane == 0) ? c0 : c0 - below;
-        f[0] = (uint32_t)((int32_t)(p0 * M) + 1);
+        bn.t[0] = trunc_u32(p0 * M);
 
         bool bad;
-        uint32_t c = bump_and_scan<NPL>(f, lane, bits, bad);
+        uint32_t c = bump_and_scan<NPL>(bn, lane, bits, bad);
 
         if (MODE == M_WAVE) {
-            // wave-native rows for k_rans_pop_wave: K entries permuted as wave_offset(), then the 64
-            // pivots c_{NPL*l} (this lane's starting value) at [K, K+64)
+            // wave-native rows for k_rans_pop: the K entries permuted as wave_offset(), then the 64 pivots
+            // c_{NPL*l} (this lane's starting value) at [K, K+64).  The permutation is a 64 x NPL transpose:
+            // it goes through a wave-private LDS tile (entry j at j + j/NPL: conflict-free writes, reads with
+            // one 2-way conflict) so that the row leaves as NPL/4 fully coalesced 1-KB stores instead of
+            // NPL scattered dword stores (16 cache lines each).  No barrier: one wave, and the LDS queue of
+            // a wave is served in order.
+            uint32_t* sw = stage + (threadIdx.x >> 6) * (64 * (NPL + 1));
             uint32_t* o = out0 + row * ld;
             o[K + lane] = c;
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
-                o[wave_offset(lane * NPL + i)] = c;
-                c += f[i];
+                sw[lane * (NPL + 1) + i] = c;
+                c += bn.t[i] + 1u;
             }
+            asm volatile("" ::: "memory");
+            const uint32_t* sr = sw + lane + lane / NPL;
+#pragma unroll
+            for (int i = 0; i < NPL / 4; ++i) {
+                uint4 v;
+                v.x = sr[(64 + 64 / NPL) * (4 * i + 0)];
+                v.y = sr[(64 + 64 / NPL) * (4 * i + 1)];
+                v.z = sr[(64 + 64 / NPL) * (4 * i + 2)];
+                v.w = sr[(64 + 64 / NPL) * (4 * i + 3)];
+                reinterpret_cast<uint4*>(o)[i * 64 + lane] = v;
+            }
+            asm volatile("" ::: "memory");
         } else if (MODE != M_ENCODE) {
             uint32_t* o = out0 + row * ld + lane * NPL;
             if (MODE == M_LINEAR_VEC) {
 #pragma unroll
                 for (int i = 0; i < NPL; i += 4) {
                     uint4 v;
-                    v.x = c; c += f[i];
-                    v.y = c; c += f[i + 1];
-                    v.z = c; c += f[i + 2];
-                    v.w = c; c += f[i + 3];
+                    v.x = c; c += bn.t[i] + 1u;
+                    v.y = c; c += bn.t[i + 1] + 1u;
+                    v.z = c; c += bn.t[i + 2] + 1u;
+                    v.w = c; c += bn.t[i + 3] + 1u;
                     *reinterpret_cast<uint4*>(o + i) = v;
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < NPL; ++i) { o[i] = c; c += f[i]; }
+                for (int i = 0; i < NPL; ++i) { o[i] = c; c += bn.t[i] + 1u; }
             }
             if (lane == 63) out0[row * ld + K] = 1u << bits;
         } else {
-            const int s = sym[row];
+            // the symbol is wave-uniform (one row per wave): its lane and bin are scalars, so (f_s, c_s)
+            // come out of the registers by scalar index instead of a per-bin select
+            const int s = __builtin_amdgcn_readfirstlane(sym[row]);
             const bool ok = (s >= 0) && (s < K);
             if (!ok && lane == 0 && status[b] == BS_ST_OK) status[b] = BS_ST_BADSYMBOL;  // first error sticks
             const int ss = ok ? s : 0;
-            if (lane == ss / NPL) {
-                const int idx = ss % NPL;
-                uint32_t fo = 0, co = 0;
+            const int idx = ss % NPL;
+            Bins<NPL> cum;  // cum[i] = c_i of this lane's bins
 #pragma unroll
-                for (int i = 0; i < NPL; ++i) {
-                    if (i == idx) { fo = f[i]; co = c; }
-                    c += f[i];
-                }
-                out0[row] = fo;
-                out1[row] = co;
+            for (int i = 0; i < NPL; ++i) { cum.t[i] = c; c += bn.t[i] + 1u; }
+            if (lane == ss / NPL) {
+                out0[row] = bn.t[idx] + 1u;
+                out1[row] = cum.t[idx];
             }
         }
     }
@@ -253,19 +303,19 @@ __global__ __launch_bounds__(256) void k_table_rows(const double* __restrict__ p
     if (row >= rows) return;
     const double M = (double)((1ll << bits) - (1ll << quantbits));
     const double* p = pmf + row * K + lane * NPL;
-    uint32_t f[NPL];
+    Bins<NPL> bn;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) f[i] = (uint32_t)((int32_t)(p[i] * M) + 1);
+    for (int i = 0; i < NPL; ++i) bn.t[i] = trunc_u32(p[i] * M);
     bool bad;
-    uint32_t c = bump_and_scan<NPL>(f, lane, bits, bad);
+    uint32_t c = bump_and_scan<NPL>(bn, lane, bits, bad);
     if (status && __ballot(bad) != 0ull && lane == 0) status[row] = BS_ST_BADTABLE;
     uint32_t* co = cdf_out + row * ld + lane * NPL;
     uint32_t* fo = f_out ? f_out + row * K + lane * NPL : nullptr;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         co[i] = c;
-        if (fo) fo[i] = f[i];
-        c += f[i];
+        if (fo) fo[i] = bn.t[i] + 1u;
+        c += bn.t[i] + 1u;
     }
     if (lane == 63) cdf_out[row * ld + K] = 1u << bits;
 }
@@ -739,17 +789,21 @@ __global__ __launch_bounds__(64) void k_selftest(unsigned long long* failures) {
     uint32_t tot = 0;
     for (int i = 0; i < 4; ++i) f[i] = 1 + ((x >> (3 * i)) & 7u);
     if (lane == 9 || lane == 40) f[2] = 100;  // tie: first (lane 9, bin 2) must win
+    if (lane == 9) f[3] = 100;                // ... also against a later bin of the same lane
     __shared__ uint32_t fall[256];
     for (int i = 0; i < 4; ++i) fall[lane * 4 + i] = f[i];
     __syncthreads();
     for (int i = 0; i < 256; ++i) tot += fall[i];
     bool badrow;
-    uint32_t c = bump_and_scan<4>(f, lane, 20, badrow);
+    Bins<4> bn;
+    for (int i = 0; i < 4; ++i) bn.t[i] = f[i] - 1u;
+    uint32_t c = bump_and_scan<4>(bn, lane, 20, badrow);
     uint32_t rc = 0;
     for (int i = 0; i < lane * 4; ++i) rc += fall[i] + ((i == 9 * 4 + 2) ? ((1u << 20) - tot) : 0u);
     if (c != rc) bad++;
-    if (lane == 9 && f[2] != 100 + ((1u << 20) - tot)) bad++;
-    if (lane == 40 && f[2] != 100) bad++;
+    if (lane == 9 && bn.t[2] + 1u != 100 + ((1u << 20) - tot)) bad++;
+    if (lane == 9 && bn.t[3] + 1u != 100) bad++;
+    if (lane == 40 && bn.t[2] + 1u != 100) bad++;
     if (bad) atomicAdd(failures, bad);
 }
 

@@ -1,0 +1,132 @@
+// net_epilogue.hip -- fused pointwise epilogues between the MIOpen convolutions of the conv stacks.
+//
+// The convolutions of Model.infer / Model.generate stay PyTorch-ROCm (MIOpen) calls.  What sits
+// between them in the reference -- bias add, ELU, residual add (utils/torch/modules.py:216-241) and
+// the scale heads (model/mnist_train.py:349,368,426) -- is HBM-bound pointwise work that torch runs as
+// 3-5 separate launches per ResNet layer.  Here each conv is followed by exactly one pass over its
+// output: one 16-byte load per operand, one 16-byte store per result.  NCHW float32, contiguous.
+//
+// These kernels are deterministic and batch-invariant by construction (every output element depends
+// on its own inputs only), which is all the decoder needs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bitswap_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expm1f(v); }
+
+// softplus as the reference writes it: -logsigmoid(-x) (modules.py:112-114) = max(x, 0) + log1p(exp(-|x|))
+__device__ __forceinline__ float softplus_ref(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoid_f32(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// one thread = 4 consecutive elements of one (n, c) plane (HW % 4 == 0)
+template <bool HAS_RES, bool WANT_SUM, bool WANT_ACT>
+__global__ __launch_bounds__(256) void k_bias_res_elu(const float* __restrict__ x, const float* __restrict__ bias,
+                                                      const float* __restrict__ res, float* __restrict__ sum_out,
+                                                      float* __restrict__ act_out, int64_t n4, int C, int hw4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i / hw4) % C);
+    const float b = bias ? bias[c] : 0.0f;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x += b; v.y += b; v.z += b; v.w += b;
+    if (HAS_RES) {
+        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (WANT_SUM) reinterpret_cast<float4*>(sum_out)[i] = v;
+    if (WANT_ACT) {
+        float4 a;
+        a.x = elu1(v.x); a.y = elu1(v.y); a.z = elu1(v.z); a.w = elu1(v.w);
+        reinterpret_cast<float4*>(act_out)[i] = a;
+    }
+}
+
+// scalar tail version for planes whose size is not a multiple of 4
+template <bool HAS_RES, bool WANT_SUM, bool WANT_ACT>
+__global__ __launch_bounds__(256) void k_bias_res_elu_1(const float* __restrict__ x, const float* __restrict__ bias,
+                                                        const float* __restrict__ res, float* __restrict__ sum_out,
+                                                        float* __restrict__ act_out, int64_t n, int C, int hw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)((i / hw) % C);
+    float v = x[i] + (bias ? bias[c] : 0.0f);
+    if (HAS_RES) v += res[i];
+    if (WANT_SUM) sum_out[i] = v;
+    if (WANT_ACT) act_out[i] = elu1(v);
+}
+
+// heads: x [N, 2C, HW] = one conv with the mu and the std filters stacked; mu = x[:, :C] + b,
+// scale = transform(x[:, C:] + b)
+__global__ __launch_bounds__(256) void k_head_params(const float* __restrict__ x, const float* __restrict__ bias,
+                                                     float* __restrict__ mu, float* __restrict__ scale, int64_t n,
+                                                     int C, int hw, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index into [N, C, HW]
+    if (i >= n) return;
+    const int64_t plane = i / hw;
+    const int p = (int)(i - plane * hw);
+    const int c = (int)(plane % C);
+    const int64_t nb = plane / C;
+    const float* xr = x + (nb * 2 * C) * hw;
+    const float m = xr[(int64_t)c * hw + p] + bias[c];
+    const float s = xr[(int64_t)(C + c) * hw + p] + bias[C + c];
+    mu[i] = m;
+    float sc;
+    if (mode == BS_HEAD_SIGMOID) sc = 0.1f + 0.9f * sigmoid_f32(s + 2.0f);                // mnist_train.py:349,368
+    else sc = 0.1f + 0.9f * softplus_ref(s + 0.54132485461291810f /* log(e - 1) */);     // mnist_train.py:426
+    scale[i] = sc;
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_rc() { return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <bool R, bool SUM, bool ACT>
+int launch_bre(const float* x, const float* bias, const float* res, float* sum_out, float* act_out, int64_t N, int C,
+               int HW, hipStream_t st) {
+    const int64_t total = N * C * HW;
+    const bool vec = (HW % 4 == 0) && aligned16(x) && (!R || aligned16(res)) && (!SUM || aligned16(sum_out)) &&
+                     (!ACT || aligned16(act_out));
+    if (vec) {
+        const int64_t n4 = total / 4;
+        hipLaunchKernelGGL((k_bias_res_elu<R, SUM, ACT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, bias,
+                           res, sum_out, act_out, n4, C, HW / 4);
+    } else {
+        hipLaunchKernelGGL((k_bias_res_elu_1<R, SUM, ACT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x,
+                           bias, res, sum_out, act_out, total, C, HW);
+    }
+    return launch_rc();
+}
+
+}  // namespace
+
+extern "C" {
+
+int bs_bias_residual_elu_f32(const float* x, const float* bias, const float* res, float* sum_out, float* act_out,
+                             int64_t N, int C, int HW, void* stream) {
+    if (!x || (!sum_out && !act_out) || N < 0 || C < 1 || HW < 1) return BS_EINVAL;
+    if (N == 0) return BS_OK;
+    hipStream_t st = S(stream);
+    const bool r = res != nullptr, s = sum_out != nullptr, a = act_out != nullptr;
+    if (r && s && a) return launch_bre<true, true, true>(x, bias, res, sum_out, act_out, N, C, HW, st);
+    if (r && s) return launch_bre<true, true, false>(x, bias, res, sum_out, act_out, N, C, HW, st);
+    if (r && a) return launch_bre<true, false, true>(x, bias, res, sum_out, act_out, N, C, HW, st);
+    if (s && a) return launch_bre<false, true, true>(x, bias, res, sum_out, act_out, N, C, HW, st);
+    if (s) return launch_bre<false, true, false>(x, bias, res, sum_out, act_out, N, C, HW, st);
+    return launch_bre<false, false, true>(x, bias, res, sum_out, act_out, N, C, HW, st);
+}
+
+int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scale, int64_t N, int C, int HW, int mode,
+                       void* stream) {
+    if (!x || !bias || !mu || !scale || N < 0 || C < 1 || HW < 1 || (mode != BS_HEAD_SIGMOID && mode != BS_HEAD_SOFTPLUS))
+        return BS_EINVAL;
+    const int64_t total = N * C * HW;
+    if (total == 0) return BS_OK;
+    hipLaunchKernelGGL(k_head_params, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), x, bias, mu, scale,
+                       total, C, HW, mode);
+    return launch_rc();
+}
+
+}  // extern "C"

@@ -18,8 +18,9 @@ LAYOUT_LINEAR, LAYOUT_WAVE = 0, 1
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres",
-    "bs_selftest", "bs_sigmoid_f64",
+    "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32",
 ]
+HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
 
 class BitswapHipError(RuntimeError):
@@ -59,6 +60,8 @@ def load():
     L.bs_gather_centres.argtypes = [p, i64, p, i32, i32, i32, p, p]
     L.bs_selftest.argtypes = [C.POINTER(C.c_int64), p]
     L.bs_sigmoid_f64.argtypes = [p, i64, p, p]
+    L.bs_bias_residual_elu_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
+    L.bs_head_params_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, p]
     for n in SYMBOLS:
         if n != "bs_strerror":
             getattr(L, n).restype = i32
@@ -304,3 +307,31 @@ def gather_centres(centres, sym):
     _check(load().bs_gather_centres(_ptr(centres), cs, _ptr(sym), B, D, K, _ptr(out), _stream()),
            "bs_gather_centres")
     return out
+
+
+# ---- conv-stack epilogues (net_epilogue.hip) ---------------------------------------------------------
+def bias_residual_elu(x, bias=None, res=None, want_sum=False, want_act=True, inplace=True):
+    """s = x + bias[c] (+ res) on an NCHW float32 tensor -> (s | None, ELU(s) | None).
+    With inplace=True the (single) requested output overwrites x (a conv result nobody else reads)."""
+    _need_cuda(x, bias, res)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    assert res is None or (res.is_contiguous() and res.shape == x.shape and res.dtype == torch.float32)
+    N, Cc, H, W = x.shape
+    s_out = (x if inplace else torch.empty_like(x)) if want_sum else None
+    a_out = (x if (inplace and not want_sum) else torch.empty_like(x)) if want_act else None
+    _check(load().bs_bias_residual_elu_f32(_ptr(x), _ptr(bias), _ptr(res), _ptr(s_out), _ptr(a_out), N, Cc, H * W,
+                                           _stream()), "bs_bias_residual_elu_f32")
+    return s_out, a_out
+
+
+def head_params(x, bias, mode):
+    """x [N,2C,H,W] (mu and std filters stacked) -> mu, scale [N, C*H*W] float32."""
+    _need_cuda(x, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[1] % 2 == 0
+    N, C2, H, W = x.shape
+    Cc = C2 // 2
+    mu = torch.empty((N, Cc * H * W), dtype=torch.float32, device=x.device)
+    scale = torch.empty_like(mu)
+    _check(load().bs_head_params_f32(_ptr(x), _ptr(bias), _ptr(mu), _ptr(scale), N, Cc, H * W, mode, _stream()),
+           "bs_head_params_f32")
+    return mu, scale

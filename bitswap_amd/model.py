@@ -16,6 +16,11 @@ What is different, MI355X-first:
   * `nn_batch`: convs always run on micro-batches of one fixed shape (zero padded), so a
     sample's (mu, scale) bits do not depend on how many chains are coded together -- the
     decoder must reproduce the encoder's parameters bit for bit.
+  * `fuse()`: on a HIP device in compress mode the pointwise work between the convolutions (bias,
+    ELU, residual add, the scale heads) runs as ONE launch per convolution
+    (bitswap_amd/csrc/net_epilogue.hip) and the mu/std head pair is a single convolution with
+    stacked filters.  Sender and receiver must both use it (or both not): the parameters differ
+    from the unfused path in the last float32 bits.
 """
 import numpy as np
 import torch
@@ -138,6 +143,8 @@ class Model(nn.Module):
         self.tag = tag
         self.best_elbo = np.inf
         self.nn_batch = nn_batch
+        self.fused = False
+        self._heads = {}
         self.conditional_gen_std = conditional_gen_std
         pad5, pad = 2, (kernel_size - 1) // 2
         assert kernel_size % 2 == 1
@@ -215,8 +222,87 @@ class Model(nn.Module):
     def zdim_flat(self):
         return int(np.prod(self.zdim))
 
+    # ---- fused compress-mode path (HIP only) ------------------------------------------------------
+    def fuse(self, enable=True):
+        """Enable the fused epilogues for compress mode (needs fold(); tensors on a HIP device)."""
+        self.fused = bool(enable)
+        self._heads = {}
+        if enable:
+            assert all(m.dropout_p == 0.0 for m in self.modules() if isinstance(m, ResNetLayer)) or not self.training
+            self.fold()
+            with torch.no_grad():
+                def stack(a, b):
+                    a, b = (a[0] if isinstance(a, nn.Sequential) else a), (b[0] if isinstance(b, nn.Sequential) else b)
+                    return torch.cat([a._w, b._w], 0).contiguous(), torch.cat([a.b, b.b], 0).contiguous()
+                self._heads["infer0"] = stack(self.infer_mu, self.infer_std)
+                for i in range(self.nz - 1):
+                    self._heads[f"infer{i + 1}"] = stack(self.deepinfer_mu[i], self.deepinfer_std[i])
+                    self._heads[f"gen{i + 1}"] = stack(self.deepgen_mu[i], self.deepgen_std[i])
+                if not self.conditional_gen_std:
+                    self._gen_scale = (((2. / 255.) / 8.) + softplus(self.gen_std)).contiguous()
+        return self
+
+    @staticmethod
+    def _conv_nb(m, x):
+        return F.conv2d(x, m._w, None, stride=m.stride, padding=m.padding)
+
+    def _fused_in(self, seq, x):
+        """Sequential([Squeeze2d,] WnConv2d, act) -> ELU(conv(x) + b), one epilogue launch."""
+        from . import hip
+        mods = list(seq.children())
+        if isinstance(mods[0], Squeeze2d):
+            x = mods[0](x).contiguous()
+            mods = mods[1:]
+        return hip.bias_residual_elu(self._conv_nb(mods[0], x), mods[0].b)[1]
+
+    def _fused_res(self, seq, h):
+        """Sequential(ResNetBlock, act) on an activated input h (Pass: identity).  Per layer
+        x + conv2(act(conv1(act(x)))): two convs, two epilogue launches."""
+        from . import hip
+        if isinstance(seq, Pass):
+            return h
+        layers = list(seq[0].children())
+        a = hip.bias_residual_elu(h, None, inplace=False)[1]          # act(x) of the first layer
+        for k, L in enumerate(layers):
+            t = hip.bias_residual_elu(self._conv_nb(L.conv1, a), L.conv1.b)[1]
+            c2 = self._conv_nb(L.conv2, t)
+            if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
+                return hip.bias_residual_elu(c2, L.conv2.b, h)[1]
+            h, a = hip.bias_residual_elu(c2, L.conv2.b, h, want_sum=True, want_act=True)
+
+    def _fused_head(self, key, h, mode):
+        from . import hip
+        w, b = self._heads[key]
+        return hip.head_params(F.conv2d(h, w, None, stride=1, padding=(w.shape[-1] - 1) // 2), b, mode)
+
+    def _infer_stack_fused(self, i, h):
+        from . import hip
+        if i == 0:
+            h = self._fused_res(self.infer_res1, self._fused_res(self.infer_res0, self._fused_in(self.infer_in, h)))
+        else:
+            h = self._fused_res(self.deepinfer_res[i - 1], self._fused_in(self.deepinfer_in[i - 1], h))
+        return self._fused_head(f"infer{i}", h, hip.HEAD_SIGMOID)
+
+    def _gen_stack_fused(self, i, h):
+        from . import hip
+        if i == 0:
+            h = self._fused_res(self.gen_res0, self._fused_res(self.gen_res1, self._fused_in(self.gen_in, h)))
+            mu = self.gen_mu(h)
+            if self.conditional_gen_std:
+                scale = ((2. / 255.) / 8.) + softplus(self.gen_std(h))
+            else:
+                scale = self._gen_scale
+            return mu, scale
+        h = self._fused_res(self.deepgen_res[i - 1], self._fused_in(self.deepgen_in[i - 1], h))
+        return self._fused_head(f"gen{i}", h, hip.HEAD_SOFTPLUS)
+
+    def _use_fused(self, h):
+        return self.fused and self.compressing and h.is_cuda and not torch.is_grad_enabled()
+
     # the conv stacks proper, on a [n, C, H, W] float32 batch -------------------------------
     def _infer_stack(self, i, h):
+        if self._use_fused(h):
+            return self._infer_stack_fused(i, h.contiguous())
         if i == 0:
             h = self.infer_res1(self.infer_res0(self.infer_in(h)))
             mu = self.infer_mu(h)
@@ -228,6 +314,8 @@ class Model(nn.Module):
         return mu, scale
 
     def _gen_stack(self, i, h):
+        if self._use_fused(h):
+            return self._gen_stack_fused(i, h.contiguous())
         if i == 0:
             h = self.gen_res0(self.gen_res1(self.gen_in(h)))
             mu = self.gen_mu(h)

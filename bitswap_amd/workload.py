@@ -51,7 +51,9 @@ def synthetic_model(dataset, nz, device, seed=50, nn_batch=None, small=None):
                 p.add_(0.1 * torch.randn(p.shape, generator=g))
             elif n == "gen_std":
                 p.add_(-3.0 + 0.1 * torch.randn(p.shape, generator=g))   # pixel scale ~ 0.05, as trained models have
-    return m.to(device).eval().fold()
+    m = m.to(device).eval().fold()
+    # HIP device: one fused epilogue launch per convolution (csrc/net_epilogue.hip)
+    return m.fuse() if torch.device(device).type == "cuda" else m
 
 
 def synthetic_bins(model, dataset, nz, quantbits, device, ppb=2, seed=7):

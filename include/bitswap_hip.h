@@ -160,6 +160,30 @@ int bs_selftest(int64_t* failures_host, void* stream);
 /* bs_sigmoid_f64 -- out[i] = deterministic sigmoid(t[i]); exposes the CDF spec for parity tests */
 int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
 
+/*
+ * Conv-stack epilogues (bitswap_amd/csrc/net_epilogue.hip).  The convolutions of Model.infer /
+ * Model.generate (model/mnist_train.py:315-438) remain MIOpen calls; these two entry points replace
+ * the pointwise launches between them.  NCHW float32, contiguous; N images, C channels, HW pixels.
+ *
+ * bs_bias_residual_elu_f32 -- s = x + bias[c] (+ res); sum_out = s (nullable); act_out = ELU(s)
+ *   (nullable; at least one output).  Covers `act(conv(x))` of the input convs and
+ *   `x + conv2(act(conv1(act(x))))` of ResNetLayer (utils/torch/modules.py:216-241): the sum feeds the
+ *   next layer's skip connection, its ELU the next conv.  bias and res are nullable; outputs may alias x.
+ *
+ * bs_head_params_f32 -- x [N,2C,HW] is ONE convolution with the mu and the std filters stacked
+ *   (the reference runs two, mnist_train.py:346-349,365-368,423-426); bias [2C].
+ *   mu = x[:, :C] + bias[:C];  s = x[:, C:] + bias[C:];
+ *   BS_HEAD_SIGMOID : scale = 0.1 + 0.9 * sigmoid(s + 2)                 (inference heads)
+ *   BS_HEAD_SOFTPLUS: scale = 0.1 + 0.9 * softplus(s + log(e - 1))       (deep generative heads)
+ *   mu, scale [N,C,HW] float32.
+ */
+#define BS_HEAD_SIGMOID 0
+#define BS_HEAD_SOFTPLUS 1
+int bs_bias_residual_elu_f32(const float* x, const float* bias, const float* res, float* sum_out,
+                             float* act_out, int64_t N, int C, int HW, void* stream);
+int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scale, int64_t N, int C,
+                       int HW, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

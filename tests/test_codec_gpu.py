@@ -106,3 +106,41 @@ def test_cli_and_demo_container_on_gpu(tmp_path):
     out, rest = cli.decompress_image(st2, nb, quantbits=10, nz=2, setup=setup)
     assert np.array_equal(tiling.unextract_blocks(out, hh, ww), tiling.unextract_blocks(blocks, h, w))
     assert rest == reference_init_state()[min_words:]
+
+
+@pytest.mark.parametrize("name", ["mnist2", "imagenetcrop4"])
+def test_fused_epilogues_match_torch_modules(name):
+    """Model.fuse(): one epilogue launch per conv (net_epilogue.hip) against the plain torch modules
+    (bias / ELU / residual / scale heads as separate launches).  Same math, float32: agreement to a few
+    ulp of the activations, and the fused path is bitwise repeatable."""
+    from bitswap_amd import hip
+    model, _, _ = workload.build(name, DEV, quantbits=8, small=24)
+    assert model.fused
+    model.compress(True)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for i in range(model.nz):
+            x = torch.randint(0, 256, (7, model.xdim), generator=g).float().to(DEV) if i == 0 else \
+                torch.randn((7, model.zdim_flat), generator=g).to(DEV)
+            z = torch.randn((7, model.zdim_flat), generator=g).to(DEV)
+            for fn, inp in ((model.infer(i), (x - 127.5) / 127.5 if i == 0 else x), (model.generate(i), z)):
+                model.fused = True
+                mu_f, sc_f = fn(inp)
+                mu_f2, sc_f2 = fn(inp)
+                model.fused = False
+                mu_t, sc_t = fn(inp)
+                model.fused = True
+                assert torch.equal(mu_f, mu_f2) and torch.equal(sc_f, sc_f2)
+                assert mu_f.shape == mu_t.shape and sc_f.shape == sc_t.shape
+                assert torch.allclose(mu_f, mu_t, rtol=1e-4, atol=1e-5), float((mu_f - mu_t).abs().max())
+                assert torch.allclose(sc_f, sc_t, rtol=1e-4, atol=1e-6), float((sc_f - sc_t).abs().max())
+    # the pointwise kernels alone, odd plane size (scalar path) and 16-byte path
+    for shape in ((3, 5, 7, 9), (2, 6, 16, 16)):
+        x = torch.randn(shape, generator=g).to(DEV)
+        b = torch.randn(shape[1], generator=g).to(DEV)
+        r = torch.randn(shape, generator=g).to(DEV)
+        s, a = hip.bias_residual_elu(x.clone(), b, r, want_sum=True, want_act=True)
+        want = x + b.view(1, -1, 1, 1) + r
+        assert torch.allclose(s, want, atol=1e-6) and torch.allclose(a, torch.nn.functional.elu(want), atol=1e-6)
+        _, a = hip.bias_residual_elu(x.clone(), None, None)
+        assert torch.allclose(a, torch.nn.functional.elu(x), atol=1e-6)

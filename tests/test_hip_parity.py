@@ -35,7 +35,8 @@ def test_selftest_wave_primitives():
 def test_sigmoid_bit_exact_vs_oracle():
     rng = np.random.RandomState(0)
     t = np.concatenate([rng.uniform(-45, 45, 200000), rng.uniform(-1, 1, 50000), rng.uniform(-800, 800, 5000),
-                        [0.0, -0.0, 700.0, -700.0, 1e6, -1e6, 1e-300, -1e-300]])
+                        [0.0, -0.0, 700.0, -700.0, 1e6, -1e6, 1e-300, -1e-300, 1e12, -1e12, 1e300, -1e300,
+                         708.0, -708.0, 745.2, -745.2, 3.0e9, -3.0e9]])
     got = hip().sigmoid_f64(dev(t)).cpu().numpy()
     want = O.det_sigmoid(t)
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))

@@ -3,7 +3,7 @@
 
     python tools/prof_summary.py stats <dir> <out.txt>       # --kernel-trace --stats run
     python tools/prof_summary.py pmc <dir> <counter> <out.json>   # --pmc <counter> run
-    python tools/prof_summary.py traffic <fetch.json> <write.json> <workload> <traffic.json>
+    python tools/prof_summary.py traffic <fetch.json> <write.json> <workload> <traffic.json> <rows per launch>
 """
 import csv
 import glob
@@ -58,7 +58,7 @@ def pmc(d, counter, out):
         print(n[:90], v)
 
 
-def traffic(fetch_json, write_json, workload, out):
+def traffic(fetch_json, write_json, workload, out, rows_per_launch):
     """HBM bytes per launch of the roofline kernel (fused logistic -> cdf rows, decode flavour, K = 1024),
     corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: counters are in KiB,
     FETCH_SIZE under-reports wide coalesced reads by exactly 2x (doubled here), WRITE_SIZE taken as is."""
@@ -71,8 +71,10 @@ def traffic(fetch_json, write_json, workload, out):
     f, nf = per(fetch_json, "FETCH_SIZE")
     w, nw = per(write_json, "WRITE_SIZE")
     res = json.load(open(out)) if os.path.exists(out) else {}
+    rows = float(rows_per_launch)
     res[workload] = {"k_logistic_decode_bytes_per_launch": None if f is None or w is None else int(2 * f + w),
-                     "fetch_bytes_raw": f, "fetch_correction": 2.0, "write_bytes": w, "dispatches": [nf, nw],
+                     "k_logistic_decode_bytes_per_row": None if f is None or w is None else (2 * f + w) / rows,
+                     "rows_per_launch": int(rows), "fetch_bytes_raw": f, "fetch_correction": 2.0, "write_bytes": w, "dispatches": [nf, nw],
                      "source": [os.path.basename(fetch_json), os.path.basename(write_json)]}
     json.dump(res, open(out, "w"), indent=1)
     print(res[workload])
@@ -82,6 +84,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
