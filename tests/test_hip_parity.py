@@ -186,6 +186,57 @@ def test_rans_push_fc_equals_push_table(golden):
     assert st.to_lists()[0] == o.tolist()
 
 
+def test_push_division_corner_cases():
+    """ANS.encode's `head // f, head % f` (mnist_compress.py:55) over frequencies the float-reciprocal
+    estimate finds hardest: f = 1, f = 2^31 - K + 1 (one bin holds everything), powers of two and their
+    neighbours, with heads spread over [2^32, 2^64).  Word streams must equal the oracle's bigint-free
+    64-bit restatement, which is pinned to the reference's Python ints by the golden fixtures."""
+    h = hip()
+    rng = np.random.RandomState(42)
+    K, D, B = 4, 6000, 4
+    total = 1 << 31
+    pats = [[1, 1, 1], [total - 3, 1, 1], [1, total - 3, 1], [1 << 30, (1 << 30) - 2, 1], [(1 << 30) - 1, (1 << 30) - 1, 1],
+            [(1 << 16) + 1, (1 << 16) - 1, 12345], [3, 5, 7], [total // 3, total // 3, total // 3], [1 << 29, (3 << 29) - 2, 1]]
+    rows = np.zeros((D, K + 1), dtype=np.int64)
+    for d in range(D):
+        f3 = pats[rng.randint(len(pats))]
+        f = list(f3) + [total - sum(f3)]
+        perm = rng.permutation(4)
+        rows[d, 1:] = np.cumsum(np.array(f)[perm])
+    assert np.all(np.diff(rows, axis=1) >= 1) and np.all(rows[:, -1] == total)
+    sym = rng.randint(0, K, (B, D))
+    sym[1] = np.argmax(np.diff(rows, axis=1), axis=1)          # always the huge bin: no words leave for a long time
+    sym[2] = np.argmin(np.diff(rows, axis=1), axis=1)          # always the rarest bin: a word per symbol
+    states = [reference_init_state(50, seed=3 + b) for b in range(B)]
+    states[3][-1] = (1 << 64) - 12345                          # head near the top of its range
+    st = h.RansState.from_lists(states, cap=50 + D + 8, device=DEV)
+    r = np.arange(D)
+    f = np.stack([(rows[r, sym[b] + 1] - rows[r, sym[b]]) for b in range(B)]).astype(np.uint32).view(np.int32)
+    c = np.stack([rows[r, sym[b]] for b in range(B)]).astype(np.uint32).view(np.int32)
+    h.rans_push(st, dev(f), dev(c))
+    st.check()
+    got = st.to_lists()
+    for b in range(B):
+        o = O.Stack(states[b])
+        assert O.push(o, rows, sym[b]) == O.OK
+        assert got[b] == o.tolist(), b
+        # the reference's own arithmetic on Python ints (mnist_compress.py:49-56), verbatim
+        x = list(states[b])
+        for d in range(D):
+            cs, fs = int(rows[d, sym[b, d]]), int(rows[d, sym[b, d] + 1] - rows[d, sym[b, d]])
+            if x[-1] >= (((1 << 32) >> 31) << 32) * fs:   # lbound = 2^32: head >= 2^33 * f
+                x.append(x[-1] >> 32)
+                x[-2] = x[-2] & ((1 << 32) - 1)
+            x[-1] = ((x[-1] // fs) << 31) + (x[-1] % fs) + cs
+        assert got[b] == x, b
+    # and back: popping the linear table returns the symbols and the initial states
+    tab = np.zeros((D, h.aligned_ld(K)), dtype=np.uint32)
+    tab[:, : K + 1] = rows
+    back, _ = h.rans_pop(st, dev(tab.view(np.int32)), K, B=B)
+    st.check()
+    assert np.array_equal(back.cpu().numpy(), sym) and st.to_lists() == states
+
+
 def test_status_codes():
     h = hip()
     K, D = 256, 300
