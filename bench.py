@@ -90,8 +90,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo",
+                                timeout=datetime.timedelta(seconds=300))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the coding path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -130,6 +132,8 @@ def main():
     t0 = time.perf_counter()
     codec.encode_blocks(states, images[:, W:], rest_lens if W == 0 else None)
     len_sent = torch.cat([st.len for st in states]).clone()
+    # the finished bitstreams (what a sender would ship): device-side snapshot, gathered after the clock stops
+    sent = [(st.stack.clone(), st.len.clone(), st.head.clone()) for st in states]
     decoded = codec.decode_blocks(states, K)
     barrier()
     dt = time.perf_counter() - t0
@@ -145,7 +149,27 @@ def main():
     bits = (len_sent.cpu().numpy().astype(np.int64) - np.array([len(s) - 1 for s in init])) * 32
     bpd = float(bits.sum()) / (B * K * codec.X)
 
-    # ---- final gather of the bitstream sizes over RCCL (the path's only exchange, not timed)
+    # ---- the path's only exchange (not timed): gather of the finished bitstreams to rank 0 and two scalars
+    # for bits/dim -- RCCL over xGMI when world > 1 (bitswap_amd/dist.py), a local no-op otherwise
+    from bitswap_amd import dist as bdist
+    gather = None
+    try:
+        streams = []
+        for stack, ln, hd in sent:
+            stack, ln, hd = stack.cpu().numpy().view(np.uint32), ln.cpu().numpy(), hd.cpu().numpy().view(np.uint64)
+            for b in range(stack.shape[0]):   # stream = stack words + the 64-bit head as two words (demo container order)
+                streams.append(np.concatenate([stack[b, : ln[b]], np.array([hd[b] & 0xffffffff, hd[b] >> 32], dtype=np.uint32)]))
+        mine = [rank + world * c for c in range(B)]            # global chain ids, round-robin like shard_chains()
+        tg = time.perf_counter()
+        got = bdist.gather_streams(streams, mine, world * B)
+        tg = time.perf_counter() - tg
+        if rank == 0:
+            words = int(sum(len(a) for a in got))
+            gather = {"chains": len(got), "bytes": 4 * words, "ms": round(tg * 1e3, 2),
+                      "complete": all(a is not None for a in got),
+                      "own_streams_intact": all(np.array_equal(got[c], a) for c, a in zip(mine, streams))}
+    except Exception as e:   # never lose the bench line to the reporting exchange
+        gather = {"error": repr(e)}
     if dist is not None:
         tot = torch.tensor([float(bits.sum()), float(B * K * codec.X), float(ok)], device=dev, dtype=torch.float64)
         dist.all_reduce(tot)
@@ -180,7 +204,7 @@ def main():
     breakdown = {k: round(v[0] / dt, 4) for k, v in sorted(totals.items())} if totals else None
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
         try:
             cpu = cpu_baseline(args, name)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
@@ -199,7 +223,7 @@ def main():
                    "latent_dims": codec.Z, "pixel_dims": codec.X, "conv_dtype": "f32",
                    "weights": "seeded random init (no checkpoints offline)"},
         "lossless": ok, "bits_per_dim": round(bpd, 4), "stream_time_fraction": breakdown,
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "stream_gather": gather,
     }
     print(json.dumps(out))
     if dist is not None:
