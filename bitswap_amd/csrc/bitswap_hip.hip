@@ -227,15 +227,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         uint32_t c = bump_and_scan<NPL>(bn, lane, bits, bad);
 
         if (MODE == M_WAVE) {
-            // wave-native rows for k_rans_pop: the K entries permuted as wave_offset(), then the 64 pivots
-            // c_{NPL*l} (this lane's starting value) at [K, K+64).  The permutation is a 64 x NPL transpose:
+            // wave-native rows for k_rans_pop_wave: the K entries permuted as wave_offset(), then 64 pivot
+            // words at [K, K+64) (see below).  The permutation is a 64 x NPL transpose:
             // it goes through a wave-private LDS tile (entry j at j + j/NPL: conflict-free writes, reads with
             // one 2-way conflict) so that the row leaves as NPL/4 fully coalesced 1-KB stores instead of
             // NPL scattered dword stores (16 cache lines each).  No barrier: one wave, and the LDS queue of
             // a wave is served in order.
             uint32_t* sw = stage + (threadIdx.x >> 6) * (64 * (NPL + 1));
             uint32_t* o = out0 + row * ld;
-            o[K + lane] = c;
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 sw[lane * (NPL + 1) + i] = c;
@@ -252,6 +251,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                 v.w = sr[(64 + 64 / NPL) * (4 * i + 3)];
                 reinterpret_cast<uint4*>(o)[i * 64 + lane] = v;
             }
+            // pivots: lane r < NPL gets c_{64r} (the first entry of register r), lane NPL gets c_K = 2^bits,
+            // the rest never compare <= m
+            uint32_t pv = 0xffffffffu;
+            if (lane < NPL) pv = sw[(64 + 64 / NPL) * lane];
+            if (lane == NPL) pv = 1u << bits;
+            o[K + lane] = pv;
             asm volatile("" ::: "memory");
         } else if (MODE != M_ENCODE) {
             uint32_t* o = out0 + row * ld + lane * NPL;
@@ -406,45 +411,6 @@ struct RowRegs {
     }
 };
 
-// wave-native rows (BS_LAYOUT_WAVE): NPL = K/64 registers R[r] (lane l = c_{64r+l}) + the 64 pivots
-// c_{NPL*l}.  Two ballots find the symbol: pivots -> segment g (NPL consecutive entries, all inside
-// one register), that register -> position inside the segment.  ~20 instructions instead of ~65.
-template <int NPL>
-struct WaveRow {
-    static constexpr int K = NPL * 64;
-    typedef uint32_t vec_t __attribute__((ext_vector_type(NPL)));
-    vec_t R;
-    uint32_t pivot;
-    __device__ __forceinline__ void load(const uint32_t* row, int lane) {
-        const uint4* r = reinterpret_cast<const uint4*>(row);
-#pragma unroll
-        for (int i = 0; i < NPL / 4; ++i) {
-            const uint4 t = r[i * 64 + lane];
-            R[4 * i + 0] = t.x;
-            R[4 * i + 1] = t.y;
-            R[4 * i + 2] = t.z;
-            R[4 * i + 3] = t.w;
-        }
-        pivot = row[K + lane];
-    }
-    __device__ __forceinline__ void find(uint32_t m, int bits, int& s, uint32_t& cs, uint32_t& cs1) const {
-        const int g = __popcll(__ballot(pivot <= m)) - 1;  // c_0 = 0 <= m: g >= 0
-        const int base = g * NPL;
-        const uint32_t x = R[base >> 6];
-        const unsigned long long bal = __ballot(x <= m);
-        const uint32_t seg = (uint32_t)(bal >> (base & 63)) & (NPL == 32 ? 0xffffffffu : ((1u << (NPL & 31)) - 1u));
-        s = base + __popc(seg) - 1;
-        cs = (uint32_t)__builtin_amdgcn_readlane((int)x, s & 63);
-        const int s1 = s + 1;
-        if (s1 == K) {
-            cs1 = 1u << bits;
-        } else {
-            const uint32_t x1 = R[s1 >> 6];
-            cs1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, s1 & 63);
-        }
-    }
-};
-
 template <class ROW, int PF>
 __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
                                                  int32_t* __restrict__ len, int64_t cap,
@@ -543,6 +509,153 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
         const int64_t o = (int64_t)b * D + dd;
         sym_out[o] = sy;
         if (centres) centre_out[o] = (float)centres[(int64_t)dd * c_stride + sy];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rans_pop_wave: BS_LAYOUT_WAVE rows, one wavefront per chain.
+//
+// A lone wavefront issues about one instruction every 3-4 ns whatever it is (tools/instr_latency.hip),
+// so the step is written for instruction count.  A row is NR = K/64 registers (register r, lane l =
+// c_{64r+l}) plus one pivot register (lane r = c_{64r}, lane NR = 2^bits, other lanes 0xffffffff):
+//   ballot(pivot <= m)      -> which register holds the symbol (scalar-indexed VGPR read)
+//   ballot(R[r] <= m)       -> its lane; the entries are strictly increasing, so the popcount IS the
+//                              position, no shifting or masking of the ballot
+//   c_s, c_{s+1}            -> two v_readlane of that same register (the pivot of the next register when
+//                              the symbol sits in lane 63)
+// Rows arrive through buffer loads whose only per-row address arithmetic is one scalar subtract; PF rows
+// stay in flight (counted vmcnt).  Stack words for a 64-symbol chunk wait in ONE register (lane k = the k-th
+// word the chunk will consume), realigned once per chunk with ds_bpermute, so a renormalisation is one
+// v_readlane.  The 64-bit head never leaves the scalar unit; decoded symbols go to a lane of a register
+// (one select per symbol), to LDS once per chunk, and to HBM with the centre gather in a coalesced epilogue.
+// ------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NR>
+struct WaveRow2 {
+    typedef uint32_t vec_t __attribute__((ext_vector_type(NR)));
+    vec_t R;
+    uint32_t pivot;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, uint32_t voff_row, uint32_t voff_piv, uint32_t soff) {
+#pragma unroll
+        for (int i = 0; i < NR / 4; ++i) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_row + i * 1024, soff, 0);
+            R[4 * i + 0] = t.x;
+            R[4 * i + 1] = t.y;
+            R[4 * i + 2] = t.z;
+            R[4 * i + 3] = t.w;
+        }
+        pivot = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_piv, soff, 0);
+    }
+};
+
+template <int NR, int PF>
+__global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                      int32_t* __restrict__ len, int64_t cap,
+                                                      const uint32_t* __restrict__ cdf, int64_t chain_stride,
+                                                      int64_t ld, int D, int bits, int32_t* __restrict__ sym_out,
+                                                      const double* __restrict__ centres, int64_t c_stride,
+                                                      float* __restrict__ centre_out, int32_t* __restrict__ status) {
+    // host dispatch guarantees: D % 64 == 0, rows 16-byte aligned, D * ld * 4 < 2^31
+    constexpr int K = NR * 64;
+    extern __shared__ int32_t sh_sym[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) {  // failed chain: skipped, but its outputs stay well-defined
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
+    // latency-critical serial wave: win instruction-issue arbitration against co-resident bulk kernels
+    __builtin_amdgcn_s_setprio(3);
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t ld4 = (uint32_t)ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cdf + (int64_t)b * chain_stride), 0, (int)((uint32_t)D * ld4), 0x00020000);
+    const uint32_t voff_row = (uint32_t)lane * 16u, voff_piv = (uint32_t)K * 4u + (uint32_t)lane * 4u;
+    const uint32_t mask = (1u << bits) - 1u;
+    int st = BS_ST_OK;
+
+    auto stack_window = [&](int top, int off) -> uint32_t {  // lane l <- stk[top-1-off-l] (clamped at the bottom)
+        const int i = top - 1 - off - lane;
+        return stk[max(i, 0)];
+    };
+    // the 128 words below `wtop`: whatever the previous chunk consumed (<= 64), the next 64 are in here
+    int wtop = n;
+    uint32_t wa = stack_window(wtop, 0), wb = stack_window(wtop, 64);
+    asm volatile("" : "+v"(wa), "+v"(wb));  // see k_rans_pop: keep these loads out of the counted waits
+
+    WaveRow2<NR> buf[PF];
+    uint32_t soff = (uint32_t)(D - 1) * ld4;  // byte offset of the row the NEXT refill fetches
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        buf[u].load(rs, voff_row, voff_piv, soff);
+        soff = (uint32_t)max((int)(soff - ld4), 0);  // clamped: the last PF refills re-read row 0, unused
+        __builtin_amdgcn_sched_barrier(0);           // issue order == consumption order (counted vmcnt)
+    }
+
+    int d = D - 1;
+    for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
+        // this chunk's words: realign the 128-word window by what the previous chunk consumed
+        const int idx = (wtop - n) + lane;  // 0..127
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wa);
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wb);
+        const uint32_t win = idx < 64 ? pa : pb;
+        // and fetch the window the NEXT chunk will realign; it has a whole chunk to arrive
+        const int ntop = n;
+        const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
+        int o = 0;  // words consumed in this chunk
+        uint32_t mysym = 0;
+        for (int g = 64 / PF - 1; g >= 0; --g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const uint32_t m = (uint32_t)h & mask;
+                const int r1 = __popcll(__ballot(buf[u].pivot <= m));  // 1..NR (c_0 = 0 <= m)
+                const uint32_t x = buf[u].R[r1 - 1];
+                const int pos = __popcll(__ballot(x <= m));            // 1..64
+                const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)x, pos - 1);
+                const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)x, pos & 63);
+                const uint32_t cnx = (uint32_t)__builtin_amdgcn_readlane((int)buf[u].pivot, r1);
+                const uint32_t f = (pos == 64 ? cnx : cin) - cs;
+                mysym = (lane == (d & 63)) ? (uint32_t)((r1 - 1) * 64 + pos - 1) : mysym;
+                // this row's registers are free again: fetch the row PF steps ahead
+                buf[u].load(rs, voff_row, voff_piv, soff);
+                soff = (uint32_t)max((int)(soff - ld4), 0);
+                h = (uint64_t)f * (h >> bits) + (uint64_t)(m - cs);
+                uint32_t hhi = (uint32_t)(h >> 32);
+                asm("" : "+s"(hhi));  // keep this a 32-bit scalar compare (hipcc otherwise builds a 64-bit VALU one)
+                if (hhi == 0u) {  // h < 2^32, mnist_compress.py:65
+                    h = (h << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, o);
+                    ++o;
+                }
+                --d;
+            }
+        }
+        sh_sym[c64 * 64 + lane] = (int32_t)mysym;
+        n -= o;
+        if (n < 0) {  // popped below the bottom: garbage from here on (reads stay in bounds), reported below
+            st = BS_ST_UNDERFLOW;
+            n = 0;
+        }
+        wtop = ntop;
+        wa = na;
+        wb = nb;
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+    __syncthreads();
+    for (int dd = lane; dd < D; dd += 64) {
+        const int sy = sh_sym[dd];
+        const int64_t oo = (int64_t)b * D + dd;
+        sym_out[oo] = sy;
+        if (centres) centre_out[oo] = (float)centres[(int64_t)dd * c_stride + sy];
     }
 }
 
@@ -1085,11 +1198,16 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, cons
                        chain_stride, ld, D, bits, sym_out, centres, c_stride, centre_out, status)
     if (layout == BS_LAYOUT_WAVE) {
         if (!fast) return BS_EINVAL;  // the wave layout only exists for the fast path
-        if (K == 256) BS_POP(WaveRow<4>, 8);
-        else if (K == 512) BS_POP(WaveRow<8>, 8);
-        else if (K == 1024) BS_POP(WaveRow<16>, 8);
-        else if (K == 2048) BS_POP(WaveRow<32>, 4);
+        if ((int64_t)D * ld * 4 >= (1ll << 31)) return BS_EINVAL;  // one chain's rows must fit a 32-bit buffer offset
+#define BS_POPW(NR, PF)                                                                                          \
+    hipLaunchKernelGGL((k_rans_pop_wave<NR, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, cdf,    \
+                       chain_stride, ld, D, bits, sym_out, centres, c_stride, centre_out, status)
+        if (K == 256) BS_POPW(4, 32);
+        else if (K == 512) BS_POPW(8, 16);
+        else if (K == 1024) BS_POPW(16, 16);
+        else if (K == 2048) BS_POPW(32, 8);
         else return BS_EUNSUPPORTED;
+#undef BS_POPW
     } else if (fast && K == 256) BS_POP(RowRegs<1>, 8);
     else if (fast && K == 512) BS_POP(RowRegs<2>, 8);
     else if (fast && K == 1024) BS_POP(RowRegs<4>, 8);

@@ -64,7 +64,8 @@ extern "C" {
  *                     bs_rans_push_table (K = 256*n, ld >= K+64, 16-byte aligned rows): the K entries
  *                     c_0..c_{K-1} permuted so that a 64-lane wavefront's 16-byte loads leave entries
  *                     64r..64r+63 in register r across its lanes (entry j at dword ((j/256)*64 + j%64)*4
- *                     + (j/64)%4), followed at [K, K+64) by the pivots c_{(K/64)*l}, l = 0..63. */
+ *                     + (j/64)%4), followed at [K, K+64) by the pivot words: word r = c_{64r} for
+ *                     r < K/64, word K/64 = c_K = 2^bits, the remaining words 0xffffffff. */
 #define BS_LAYOUT_LINEAR 0
 #define BS_LAYOUT_WAVE 1
 

@@ -379,7 +379,9 @@ def test_wave_layout_tables_and_pop(K):
     assert wav.shape[-1] == K + 64 and wav.bs_layout == h.LAYOUT_WAVE
     c, piv = unpermute_wave(u32(wav), K)
     assert np.array_equal(c, u32(lin)[:, :, :K])
-    assert np.array_equal(piv, u32(lin)[:, :, 0:K:K // 64])
+    nr = K // 64
+    assert np.array_equal(piv[..., :nr], u32(lin)[:, :, 0:K:64])          # word r = c_{64r}
+    assert np.all(piv[..., nr] == 1 << 31) and np.all(piv[..., nr + 1:] == 0xffffffff)
     states = [reference_init_state(4000, seed=7 + b) for b in range(B)]
     s1 = h.RansState.from_lists(states, cap=6000, device=DEV)
     s2 = h.RansState.from_lists(states, cap=6000, device=DEV)
