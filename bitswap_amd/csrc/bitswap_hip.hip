@@ -244,19 +244,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             const uint32_t* sr = sw + lane + lane / NPL;
 #pragma unroll
             for (int i = 0; i < NPL / 4; ++i) {
-                uint4 v;
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                v4u v;
                 v.x = sr[(64 + 64 / NPL) * (4 * i + 0)];
                 v.y = sr[(64 + 64 / NPL) * (4 * i + 1)];
                 v.z = sr[(64 + 64 / NPL) * (4 * i + 2)];
                 v.w = sr[(64 + 64 / NPL) * (4 * i + 3)];
-                reinterpret_cast<uint4*>(o)[i * 64 + lane] = v;
+                // streaming store: the row is read once, much later, by the pop kernel -- keep it from evicting
+                // the endpoint rows that the other chain groups of this XCD are about to re-read from L2
+                __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(o) + i * 64 + lane);
             }
             // pivots: lane r < NPL gets c_{64r} (the first entry of register r), lane NPL gets c_K = 2^bits,
             // the rest never compare <= m
             uint32_t pv = 0xffffffffu;
             if (lane < NPL) pv = sw[(64 + 64 / NPL) * lane];
             if (lane == NPL) pv = 1u << bits;
-            o[K + lane] = pv;
+            __builtin_nontemporal_store(pv, o + K + lane);
             asm volatile("" ::: "memory");
         } else if (MODE != M_ENCODE) {
             uint32_t* o = out0 + row * ld + lane * NPL;
@@ -539,13 +542,13 @@ struct WaveRow2 {
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, uint32_t voff_row, uint32_t voff_piv, uint32_t soff) {
 #pragma unroll
         for (int i = 0; i < NR / 4; ++i) {
-            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_row + i * 1024, soff, 0);
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_row + i * 1024, soff, 2);  // nt: read once
             R[4 * i + 0] = t.x;
             R[4 * i + 1] = t.y;
             R[4 * i + 2] = t.z;
             R[4 * i + 3] = t.w;
         }
-        pivot = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_piv, soff, 0);
+        pivot = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_piv, soff, 2);
     }
 };
 
