@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-timeline", action="store_true", help="skip per-kernel events (roofline becomes null)")
     ap.add_argument("--groups", type=int, default=2,
                     help="chain groups per GPU on separate HIP streams (serial rANS of one group under the convs of another)")
+    ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
+                    help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
     return ap.parse_args()
 
 
@@ -112,6 +114,8 @@ def main():
     tl = Timeline(enabled=not args.no_timeline)
     codec = GroupedCodec(model, zend, zcen, groups=args.groups, quantbits=args.quantbits, bitswap=bool(args.bitswap),
                          timeline=tl)
+    for c in codec.codecs:
+        c.tables_on = args.tables_on
     init = initial_states(B, 10000, seed=100 + rank)
     states = codec.new_states(B, n, states=init)
     rest_lens = [torch.zeros_like(st.len) for st in states]

@@ -150,6 +150,10 @@ class BitSwapCodec:
         # on `serial`; None = everything on the caller's current stream
         self.bulk = self.serial = None
         self._ev_serial = None
+        # where the table kernels run when the streams are split: "bulk" (behind the convs that produce their
+        # inputs) or "serial" (in front of the rANS kernel that consumes their output, next to the OTHER
+        # groups' convs)
+        self.tables_on = "bulk"
         # the prior p(z_L) = Logistic(0,1) table does not depend on the image: build it once
         # (the reference rebuilds it for every image, mnist_compress.py:246-251)
         one = torch.ones((1, self.Z), dtype=torch.float32, device=dev)
@@ -178,6 +182,14 @@ class BitSwapCodec:
     def _on(self, stream):
         return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
+    def _tables_stream(self, inputs):
+        """Stream of the table kernels; when it is the serial stream, order it after the convs first."""
+        if self.serial is None or self.tables_on == "bulk":
+            return self.bulk
+        self._serial_waits_bulk()
+        self._share(inputs, self.serial)
+        return self.serial
+
     def _serial_waits_bulk(self):
         if self.serial is not None:
             self.serial.wait_stream(self.bulk)
@@ -199,7 +211,8 @@ class BitSwapCodec:
                     t.record_stream(stream)
 
     def _pop_layer(self, state, endpoints, centres, mu, scale, quantbits, K, key):
-        with self._on(self.bulk), self.tl.span("tables_" + key):
+        ts = self._tables_stream((mu, scale))
+        with self._on(ts), self.tl.span("tables_" + key):
             cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
                                       out=self._cdf(mu.shape[0], mu.shape[1], K))
         self._serial_waits_bulk()
@@ -224,7 +237,8 @@ class BitSwapCodec:
             with self.tl.span("push_" + key):
                 self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits)
             return
-        with self._on(self.bulk), self.tl.span("fc_" + key):
+        ts = self._tables_stream((mu, scale, sym))
+        with self._on(ts), self.tl.span("fc_" + key):
             f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, self.bits, quantbits)
             self._share((f, c), self.serial)
         self._serial_waits_bulk()
