@@ -415,7 +415,57 @@ def make_model_and_chains():
     print("model_crop_small.npz")
 
 
+def make_rgb4_chain():
+    """A deeper, colour chain: xs = (3,32,32), nz = 4, Bit-Swap, 2 blocks -- pins the layer ordering for
+    zi > 1 (mnist_compress.py:176-205) and the 3072-dim pixel op; written to its own files so that the
+    other fixtures never change when this one is regenerated."""
+    torch.manual_seed(52)
+    rng = np.random.RandomState(12)
+    nz, quantbits = 4, 10
+    xs, zch = (3, 32, 32), 2
+    cfg = [xs[0], nz, zch, 1, 3, 4, 10]
+    model = RefModel(xs=xs, nz=nz, zchannels=zch, nprocessing=1, kernel_size=3, resdepth=4, reswidth=10,
+                     root_process=False)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(".b") or n.endswith("gen_std"):
+                p.add_(torch.randn_like(p) * 0.3)
+            if n.endswith(".gain"):
+                p.add_(torch.randn_like(p) * 0.2)
+    model.eval()
+    xdim, zdim = int(np.prod(xs)), zch * 16 * 16
+    images = synth_images(rng, 64, xs)
+    zend, zcen, mins, maxs = synth_bins(model, nz, zdim, quantbits, images, rng)
+    out = {"sd_" + k: v.numpy() for k, v in model.state_dict().items()}
+    out["cfg"] = np.array(cfg, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "model_rgb4_small.npz"), **out)
+    nblocks = 2
+    ops, sent, restbits, nets, cma = replay_chain(model, zend, zcen, images[:nblocks], nz, 1, quantbits, xdim, zdim,
+                                                  cap=30000)
+    o = {
+        "cfg": np.array(cfg + [quantbits, 1, nblocks], dtype=np.int64),
+        "images": images[:nblocks],
+        "z_top_endpoints": zend[nz - 1][0], "z_top_centres": zcen[nz - 1][0],
+        "z_mins": mins, "z_maxs": maxs,
+        "sent_words": words(sent), "restbits_len": np.int64(len(restbits)),
+        "nets": np.array(nets), "cma": np.array(cma),
+        "op_kind": np.array([p["kind"] for p in ops], dtype=np.int8),
+        "op_table": np.array([p["table"] for p in ops], dtype=np.int8),
+        "op_q": np.array([p["q"] for p in ops], dtype=np.int8),
+        "op_nwords": np.array([p["nwords"] for p in ops], dtype=np.int64),
+        "op_head": np.array([p["head"] for p in ops], dtype=np.uint64),
+    }
+    for i, p in enumerate(ops):
+        o[f"op{i}_mu"], o[f"op{i}_scale"], o[f"op{i}_sym"] = p["mu"], p["scale"], p["sym"].astype(np.int16)
+    np.savez_compressed(os.path.join(OUT, "chain_rgb4_small_bitswap.npz"), **o)
+    print("chain_rgb4_small_bitswap.npz ops", len(ops), "words", len(sent), "cma", cma)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rgb4":
+        make_rgb4_chain()
+        sys.exit(0)
     make_tables_and_rans()
     make_bins()
     make_model_and_chains()
+    make_rgb4_chain()

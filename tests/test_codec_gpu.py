@@ -144,3 +144,53 @@ def test_fused_epilogues_match_torch_modules(name):
         assert torch.allclose(s, want, atol=1e-6) and torch.allclose(a, torch.nn.functional.elu(want), atol=1e-6)
         _, a = hip.bias_residual_elu(x.clone(), None, None)
         assert torch.allclose(a, torch.nn.functional.elu(x), atol=1e-6)
+
+
+@pytest.mark.parametrize("bitswap", [1, 0])
+def test_grouped_codec_equals_plain_codec(bitswap):
+    """GroupedCodec (chain groups on separate HIP streams, enqueue order interleaved) is a scheduling
+    device only: every chain's stream equals the one the plain single-stream codec produces for the same
+    group composition, the receiver returns the blocks, and all states unwind."""
+    from bitswap_amd.codec import GroupedCodec
+    model, zend, zcen = workload.build("cifar8", DEV, quantbits=10, small=16)
+    B, n = 6, 3
+    images = workload.synthetic_blocks(B * n, model.xs, seed=21).view(B, n, -1).to(torch.int32).to(DEV)
+    init = initial_states(B, 12000)
+    gc = GroupedCodec(model, zend, zcen, groups=2, quantbits=10, bitswap=bool(bitswap))
+    states = gc.new_states(B, n, states=init)
+    gc.encode_blocks(states, images)
+    torch.cuda.synchronize()
+    gc.check(states)
+    got = gc.to_lists(states)
+    # the same two groups through the plain codec, one after the other on the default stream
+    plain = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap))
+    want = []
+    for sl in gc.split(B):
+        st = plain.new_states(sl.stop - sl.start, n, states=init[sl])
+        for xi in range(n):
+            plain.encode_block(st, images[sl, xi])
+        want += st.to_lists()
+    assert got == want
+    out = gc.decode_blocks(states, n)
+    torch.cuda.synchronize()
+    gc.check(states)
+    assert torch.equal(out, images) and gc.to_lists(states) == init
+
+
+def test_config3_shape_many_blocks_lossless():
+    """BASELINE configs[2] shape at reduced length: ImageNet32 nz=4 full-width model, 40 chains x 6 blocks
+    through the grouped codec; lossless, every state restored, bit accounting monotone."""
+    from bitswap_amd.codec import GroupedCodec
+    model, zend, zcen = workload.build("imagenet4", DEV, quantbits=10)
+    B, n = 40, 6
+    images = workload.synthetic_blocks(B * n, model.xs, seed=33).view(B, n, -1).to(torch.int32).to(DEV)
+    init = initial_states(B)
+    gc = GroupedCodec(model, zend, zcen, groups=2, quantbits=10, bitswap=True)
+    states = gc.new_states(B, n, states=init)
+    gc.encode_blocks(states, images)
+    lens = torch.cat([st.len for st in states]).cpu().numpy()
+    assert np.all(lens > 10000 - 1)                     # every chain grew
+    out = gc.decode_blocks(states, n)
+    torch.cuda.synchronize()
+    gc.check(states)
+    assert torch.equal(out, images) and gc.to_lists(states) == init

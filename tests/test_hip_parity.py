@@ -290,12 +290,12 @@ def test_ans_class_drop_in(golden):
         a.decode([3 << 32])
 
 
-@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
-def test_chain_replay_matches_reference_words(golden, sched):
+@pytest.mark.parametrize("chain", ["chain_mnist_small_bitswap", "chain_mnist_small_bbans", "chain_rgb4_small_bitswap"])
+def test_chain_replay_matches_reference_words(golden, chain):
     """Teacher-forced replay of the reference sender through the HIP kernels: same popped symbols,
     same per-operation state, same final word stream as the reference's Python run."""
     h = hip()
-    g = golden(f"chain_mnist_small_{sched}.npz")
+    g = golden(chain + ".npz")
     zend, xend, zcen = chain_tables(g)
     zend_d = [dev(z) for z in zend]
     xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)

@@ -101,22 +101,27 @@ def test_discretize_sampling_and_cache(tmp_path):
         bins.discretize(3, 7, torch.float64, "cpu", m, "toy", cache_dir=str(tmp_path))
 
 
-@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
-def test_codec_reproduces_reference_chain(golden, sched):
+@pytest.mark.parametrize("chain,model_file", [("chain_mnist_small_bitswap", "model_mnist_small"),
+                                              ("chain_mnist_small_bbans", "model_mnist_small"),
+                                              ("chain_rgb4_small_bitswap", "model_rgb4_small")])
+def test_codec_reproduces_reference_chain(golden, chain, model_file):
     """Our Model + our batched schedule + the oracle = the reference's own sender run
     (mnist_compress.py:164-263): identical word stream and bit accounting, then the receiver
-    (:277-358) returns the images and the initial state."""
-    g = golden(f"chain_mnist_small_{sched}.npz")
-    m = load_model(golden("model_mnist_small.npz")).fold()
+    (:277-358) returns the images and the initial state.  mnist: 1 channel, nz = 2, both schedules;
+    rgb4: 3 channels, nz = 4 (layer ordering for zi > 1, 3072-dim pixel op)."""
+    g = golden(chain + ".npz")
+    cfg = g["cfg"]
+    q, bitswap, nblocks = int(cfg[7]), bool(cfg[8]), int(cfg[9])
+    m = load_model(golden(model_file + ".npz")).fold()
     zend, _, zcen = chain_tables(g)
-    codec = BitSwapCodec(m, torch.from_numpy(zend), torch.from_numpy(zcen), quantbits=10,
-                         bitswap=(sched == "bitswap"), backend=OracleBackend(O.MODE_DET))
-    imgs = torch.from_numpy(g["images"].astype(np.int32)).view(1, 3, -1)
+    codec = BitSwapCodec(m, torch.from_numpy(zend), torch.from_numpy(zcen), quantbits=q,
+                         bitswap=bitswap, backend=OracleBackend(O.MODE_DET))
+    imgs = torch.from_numpy(g["images"].astype(np.int32)).view(1, nblocks, -1)
     state, met = codec.compress(imgs)
     assert state.to_lists()[0] == words_to_state(g["sent_words"])
     assert np.allclose(met["cma"][0], g["cma"]) and np.allclose(met["nets"][0], g["nets"])
     assert int(met["rest_len"][0]) + 1 == int(g["restbits_len"])
-    out = codec.decompress(state, 3)
+    out = codec.decompress(state, nblocks)
     assert torch.equal(out, imgs)
     assert state.to_lists()[0] == reference_init_state()
 

@@ -34,6 +34,7 @@ def timeit(fn, it=10):
 pool = torch.cuda.graph_pool_handle()
 side = torch.cuda.Stream()
 tot_e = tot_g = 0.0
+keep = []
 for kind in ("infer", "generate"):
     for i in (0, 1, 7):
         fn = getattr(model, kind)(i)
@@ -46,6 +47,7 @@ for kind in ("infer", "generate"):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, stream=side):
                 mu1, sc1 = fn(sin)
+            keep.append((g, sin, mu1, sc1))
             g.replay()
             torch.cuda.synchronize()
             same = torch.equal(mu0, mu1) and torch.equal(sc0, sc1.expand_as(mu1))
