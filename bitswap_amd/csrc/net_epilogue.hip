@@ -79,6 +79,46 @@ __global__ __launch_bounds__(256) void k_head_params(const float* __restrict__ x
     scale[i] = sc;
 }
 
+// x-expansion for the 5x5 convolutions-as-GEMMs (model.py, _conv5_gemm): out [N, C*5, H+4, W] with
+//   out[n, c*5 + dx, yy, x] = act(in[n, c, yy - 2, x + dx - 2] + bias[c])   (0 outside the image)
+// so that kernel row dy of the convolution is ONE strided-batched GEMM W_dy [Cout, C*5] x out[n, :, dy:dy+H, :]
+// (a [C*5, H*W] matrix with leading dimension (H+4)*W: the H rows starting at dy are contiguous).
+// One thread = 4 consecutive x of one output row (W % 4 == 0): one 16-byte store, <= 4 cached loads.
+__global__ __launch_bounds__(256) void k_expand_rows5(const float* __restrict__ in, const float* __restrict__ bias,
+                                                      float* __restrict__ out, int64_t total4, int C, int H, int W,
+                                                      int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int w4 = W / 4;
+    const int xq = (int)(i % w4);
+    int64_t r = i / w4;
+    const int yy = (int)(r % (H + 4));
+    r /= (H + 4);
+    const int dx = (int)(r % 5);
+    r /= 5;
+    const int c = (int)(r % C);
+    const int64_t n = r / C;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int y = yy - 2;
+    if (y >= 0 && y < H) {
+        const float b = bias ? bias[c] : 0.0f;
+        const float* row = in + ((n * C + c) * H + y) * (int64_t)W;
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = xq * 4 + k + dx - 2;
+            float e = 0.0f;
+            if (x >= 0 && x < W) {
+                e = row[x] + b;
+                if (act) e = elu1(e);
+            }
+            t[k] = e;
+        }
+        v = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+}
+
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int launch_rc() { return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -116,6 +156,16 @@ int bs_bias_residual_elu_f32(const float* x, const float* bias, const float* res
     if (s && a) return launch_bre<false, true, true>(x, bias, res, sum_out, act_out, N, C, HW, st);
     if (s) return launch_bre<false, true, false>(x, bias, res, sum_out, act_out, N, C, HW, st);
     return launch_bre<false, false, true>(x, bias, res, sum_out, act_out, N, C, HW, st);
+}
+
+int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W, int act,
+                        void* stream) {
+    if (!in || !out || N < 0 || C < 1 || H < 1 || W < 4 || (W % 4) != 0 || !aligned16(out)) return BS_EINVAL;
+    const int64_t total4 = N * C * 5 * (H + 4) * (W / 4);
+    if (total4 == 0) return BS_OK;
+    hipLaunchKernelGGL(k_expand_rows5, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, S(stream), in, bias, out,
+                       total4, C, H, W, act);
+    return launch_rc();
 }
 
 int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scale, int64_t N, int C, int HW, int mode,

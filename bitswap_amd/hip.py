@@ -18,7 +18,7 @@ LAYOUT_LINEAR, LAYOUT_WAVE = 0, 1
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres",
-    "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32",
+    "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
@@ -62,6 +62,7 @@ def load():
     L.bs_sigmoid_f64.argtypes = [p, i64, p, p]
     L.bs_bias_residual_elu_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     L.bs_head_params_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, p]
+    L.bs_expand_rows5_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, p]
     for n in SYMBOLS:
         if n != "bs_strerror":
             getattr(L, n).restype = i32
@@ -335,3 +336,15 @@ def head_params(x, bias, mode):
     _check(load().bs_head_params_f32(_ptr(x), _ptr(bias), _ptr(mu), _ptr(scale), N, Cc, H * W, mode, _stream()),
            "bs_head_params_f32")
     return mu, scale
+
+
+def expand_rows5(x, bias=None, act=True):
+    """[N,C,H,W] -> [N, C*5, H+4, W]: ELU(x + bias) zero-padded and shifted along x for the five kernel
+    columns (operand of the 5x5 conv-as-GEMM, see include/bitswap_hip.h)."""
+    _need_cuda(x, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, Cc * 5, H + 4, W), dtype=torch.float32, device=x.device)
+    _check(load().bs_expand_rows5_f32(_ptr(x), _ptr(bias), _ptr(out), N, Cc, H, W, 1 if act else 0, _stream()),
+           "bs_expand_rows5_f32")
+    return out

@@ -144,6 +144,7 @@ class Model(nn.Module):
         self.best_elbo = np.inf
         self.nn_batch = nn_batch
         self.fused = False
+        self.gemm5_min_batch = 24    # below this the batched GEMMs do not beat MIOpen (tools/conv_probe3.py)
         self._heads = {}
         self.conditional_gen_std = conditional_gen_std
         pad5, pad = 2, (kernel_size - 1) // 2
@@ -240,6 +241,10 @@ class Model(nn.Module):
                     self._heads[f"gen{i + 1}"] = stack(self.deepgen_mu[i], self.deepgen_std[i])
                 if not self.conditional_gen_std:
                     self._gen_scale = (((2. / 255.) / 8.) + softplus(self.gen_std)).contiguous()
+                # 5x5 ResNet convs as five GEMMs (one per kernel row): W_dy [Cout, Cin*5]
+                for m in self.modules():
+                    if isinstance(m, WnConv2d) and m.kernel_size == 5 and m.in_dim == m.out_dim and m.stride == 1:
+                        m._w5 = [m._w[:, :, dy, :].reshape(m.out_dim, m.in_dim * 5).contiguous() for dy in range(5)]
         return self
 
     @staticmethod
@@ -255,6 +260,35 @@ class Model(nn.Module):
             mods = mods[1:]
         return hip.bias_residual_elu(self._conv_nb(mods[0], x), mods[0].b)[1]
 
+    @staticmethod
+    def _conv5_gemm(m, ax):
+        """5x5 'same' convolution on the x-expanded operand ax [n, Cin*5, H+4, W] (hip.expand_rows5): kernel
+        row dy is one strided-batched GEMM on rocBLAS/hipBLASLt (MFMA), accumulated in place.  At 100-200
+        images this runs at ~103 TFLOP/s against 74-80 for MIOpen's decomposition of 5x5 into 3x3 Winograd
+        tiles (tools/conv_probe3.py).  No bias."""
+        n, k5, hp, w = ax.shape
+        h = hp - 4
+        out = torch.empty((n, m.out_dim, h * w), dtype=ax.dtype, device=ax.device)
+        for dy in range(5):
+            a = ax[:, :, dy:dy + h, :].flatten(2)                       # [n, Cin*5, H*W], row stride (H+4)*W
+            wd = m._w5[dy].unsqueeze(0).expand(n, m.out_dim, k5)
+            if dy == 0:
+                torch.bmm(wd, a, out=out)
+            else:
+                out.baddbmm_(wd, a)
+        return out.view(n, m.out_dim, h, w)
+
+    def _res5_gemm(self, layers, h):
+        """The 5x5 ResNet block on GEMMs: the ELU in front of every conv is applied while its operand is
+        expanded (bias of conv1 included), so a layer is 2 expansions + 10 GEMMs + 1 residual epilogue."""
+        from . import hip
+        for k, L in enumerate(layers):
+            c1 = self._conv5_gemm(L.conv1, hip.expand_rows5(h, None, act=True))
+            c2 = self._conv5_gemm(L.conv2, hip.expand_rows5(c1, L.conv1.b, act=True))
+            if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
+                return hip.bias_residual_elu(c2, L.conv2.b, h)[1]
+            h = hip.bias_residual_elu(c2, L.conv2.b, h, want_sum=True, want_act=False)[0]
+
     def _fused_res(self, seq, h):
         """Sequential(ResNetBlock, act) on an activated input h (Pass: identity).  Per layer
         x + conv2(act(conv1(act(x)))): two convs, two epilogue launches."""
@@ -262,6 +296,9 @@ class Model(nn.Module):
         if isinstance(seq, Pass):
             return h
         layers = list(seq[0].children())
+        if (layers[0].conv1.kernel_size == 5 and h.shape[0] >= self.gemm5_min_batch and h.shape[-1] % 4 == 0
+                and getattr(layers[0].conv1, "_w5", None) is not None):
+            return self._res5_gemm(layers, h)
         a = hip.bias_residual_elu(h, None, inplace=False)[1]          # act(x) of the first layer
         for k, L in enumerate(layers):
             t = hip.bias_residual_elu(self._conv_nb(L.conv1, a), L.conv1.b)[1]

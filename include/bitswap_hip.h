@@ -177,6 +177,12 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *   BS_HEAD_SIGMOID : scale = 0.1 + 0.9 * sigmoid(s + 2)                 (inference heads)
  *   BS_HEAD_SOFTPLUS: scale = 0.1 + 0.9 * softplus(s + log(e - 1))       (deep generative heads)
  *   mu, scale [N,C,HW] float32.
+ *
+ * bs_expand_rows5_f32 -- operand builder for the 5x5 convolutions run as GEMMs on rocBLAS/hipBLASLt
+ *   (bitswap_amd/model.py::_conv5_gemm): out [N, C*5, H+4, W],
+ *   out[n, c*5+dx, yy, x] = act(in[n, c, yy-2, x+dx-2] + bias[c]) inside the image, 0 outside;
+ *   act != 0 applies ELU, bias nullable.  Kernel row dy of the convolution is then one strided-batched
+ *   GEMM W_dy [Cout, C*5] x out[n, :, dy:dy+H, :] (leading dimension (H+4)*W).  W % 4 == 0.
  */
 #define BS_HEAD_SIGMOID 0
 #define BS_HEAD_SOFTPLUS 1
@@ -184,6 +190,8 @@ int bs_bias_residual_elu_f32(const float* x, const float* bias, const float* res
                              float* act_out, int64_t N, int C, int HW, void* stream);
 int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scale, int64_t N, int C,
                        int HW, int mode, void* stream);
+int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W,
+                        int act, void* stream);
 
 #ifdef __cplusplus
 }
