@@ -10,6 +10,7 @@ import torch
 
 from . import build as _build
 
+ABI_VERSION = 2   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
 PARAM_F32, PARAM_F64 = 0, 1
@@ -66,6 +67,9 @@ def load():
     for n in SYMBOLS:
         if n != "bs_strerror":
             getattr(L, n).restype = i32
+    if L.bs_abi_version() != ABI_VERSION:
+        raise BitswapHipError(f"{path} has ABI version {L.bs_abi_version()}, this binding needs {ABI_VERSION}: "
+                              "rebuild with `python -m bitswap_amd.build`")
     _lib = L
     return L
 

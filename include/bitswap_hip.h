@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 1
+/* 2: layout argument, BS_LAYOUT_WAVE pivot words, conv-stack epilogue entry points */
+#define BS_ABI_VERSION 2
 /* version of the deterministic logistic-CDF specification; streams written with
  * one CDF spec can only be decoded with the same one */
 #define BS_CDF_SPEC 1
