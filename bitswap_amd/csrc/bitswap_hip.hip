@@ -1,21 +1,24 @@
 // bitswap_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for the Bit-Swap / BB-ANS hot path.
 //
 // What runs where (see DESIGN.md for the roofline of each kernel):
-//   k_logistic<NPL,PT,DECODE>  one 64-lane wavefront per (latent dim d, group of chains); the
+//   k_logistic<NPL,PT,MODE>    one 64-lane wavefront per (latent dim d, group of chains); the
 //                              K-1 float64 bin endpoints of dim d stay in registers (NPL = K/64
 //                              consecutive bins per lane) and are reused for every chain of the
 //                              group; per chain: NPL deterministic float64 sigmoids per lane,
 //                              adjacent difference, trunc-multiply, wave-wide sum / first-argmax
-//                              (DPP), remnant bump, exclusive scan (DPP) -> integer cdf row
-//                              (decode flavour) or the (f, c) pair of one symbol (encode flavour).
+//                              (DPP + scalar unit), remnant bump, exclusive scan (DPP) -> integer cdf
+//                              row (decode flavour; wave-native rows go through an LDS transpose and
+//                              leave as streaming 1-KB stores) or the (f, c) pair of one symbol
+//                              (encode flavour).
 //   k_table_rows / _generic    the same integer tail for caller-supplied float64 pmf rows
 //                              (bit-exact ANS.__init__).
-//   k_rans_pop<NV>             one wavefront per chain; streams the chain's cdf rows with
-//                              coalesced 16-byte loads (next row prefetched into registers while
-//                              the current one is searched), symbol = popcount of 64-wide ballots;
-//                              the 64-bit head lives in scalar registers.
-//   k_rans_push / _table       one wavefront per chain: lane-parallel (f, c, 1/f) prefetch per 64-symbol
-//                              chunk, wave-uniform serial part with the head on the scalar unit.
+//   k_rans_pop_wave<NR,PF>     BS_LAYOUT_WAVE rows, one wavefront per chain: register-pivot two-ballot
+//                              search, PF rows in flight through buffer loads, the 64-bit head on the
+//                              scalar unit.
+//   k_rans_pop<ROW,PF> /       the reference's linear rows (drop-in ANS class, tests): 16-byte loads +
+//   k_rans_pop_generic         popcount of ballots / any K, any alignment.
+//   k_rans_push / _table       one wavefront per chain run as a 64-lane systolic array: lane i owns
+//                              symbol i of a 64-symbol chunk, the head moves up one lane per step.
 //
 // Reference lines are cited in include/bitswap_hip.h next to each entry point.
 #include <hip/hip_runtime.h>
@@ -1007,6 +1010,9 @@ __global__ __launch_bounds__(64) void k_selftest(unsigned long long* failures) {
     const double dv = (double)x * 0.25;
     const double up = lane_shift_up_f64(dv);
     if (lane > 0 && up != (double)sh[lane - 1] * 0.25) bad++;
+    // DPP wave_shr:1 hand-over of the systolic push: lane i <- lane i-1, lane 0 keeps its own value
+    const uint32_t below = from_lane_below(1000u + (uint32_t)lane, x);
+    if (below != (lane == 0 ? 1000u : sh[lane - 1])) bad++;
     // bump_and_scan on a 4-bins-per-lane row whose maximum repeats
     uint32_t f[4];
     uint32_t tot = 0;
