@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--quantbits", type=int, default=10)
     ap.add_argument("--bitswap", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-blocks", type=int, default=12, help="blocks per chain in the CPU baseline sample")
+    ap.add_argument("--cpu-blocks", type=int, default=20, help="blocks per chain in the CPU baseline sample")
     ap.add_argument("--no-timeline", action="store_true", help="skip per-kernel events (roofline becomes null)")
     ap.add_argument("--groups", type=int, default=2,
                     help="chain groups per GPU on separate HIP streams (serial rANS of one group under the convs of another)")

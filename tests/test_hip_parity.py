@@ -237,6 +237,47 @@ def test_push_division_corner_cases():
     assert np.array_equal(back.cpu().numpy(), sym) and st.to_lists() == states
 
 
+@pytest.mark.parametrize("bits", [16, 24, 28, 30])
+def test_other_ans_precisions_vs_oracle(bits):
+    """The ABI takes any precision 1..31 (the reference hard-codes 31, mnist_compress.py:76): tables, pop and
+    push at 16/24 bits (generic division path) and 28/30 bits (systolic fast path) against the oracle, whose
+    tables and rANS arithmetic follow ANS.__init__/encode/decode with `bits` as a parameter."""
+    h = hip()
+    rng = np.random.RandomState(bits)
+    K, D, q = 256, 192, 8
+    p = rng.dirichlet(np.full(K, 0.3), size=D)
+    f_o, cdf_o, rc = O.tables(p, bits, q)
+    assert rc == O.OK
+    f, cdf, st_rows = h.table_rows(dev(p), bits, q, ld=h.aligned_ld(K))
+    assert int(st_rows.abs().max()) == 0 and np.array_equal(u32(cdf)[:, : K + 1], cdf_o) and np.array_equal(u32(f), f_o)
+    states = [reference_init_state(600, seed=bits + b) for b in range(3)]
+    st = h.RansState.from_lists(states, cap=600 + D + 8, device=DEV)
+    sym, _ = h.rans_pop(st, cdf, K, bits=bits, B=3)
+    st.check()
+    want = []
+    for b in range(3):
+        o = O.Stack(states[b])
+        s_o, rc = O.pop(o, cdf_o, bits)
+        assert rc == O.OK and np.array_equal(sym[b].cpu().numpy(), s_o)
+        want.append(o.tolist())
+    assert st.to_lists() == want
+    data = rng.randint(0, K, (3, D)).astype(np.int32)
+    h.rans_push_table(st, cdf, dev(data), K, bits=bits)
+    st.check()
+    for b in range(3):
+        o = O.Stack(want[b])
+        assert O.push(o, cdf_o, data[b], bits) == O.OK
+        assert st.to_lists()[b] == o.tolist()
+    # (f, c) flavour of the same push
+    st2 = h.RansState.from_lists(want, cap=600 + D + 8, device=DEV)
+    r = np.arange(D)
+    fa = np.stack([cdf_o[r, data[b] + 1] - cdf_o[r, data[b]] for b in range(3)]).astype(np.uint32).view(np.int32)
+    ca = np.stack([cdf_o[r, data[b]] for b in range(3)]).astype(np.uint32).view(np.int32)
+    h.rans_push(st2, dev(fa), dev(ca), bits=bits)
+    st2.check()
+    assert st2.to_lists() == st.to_lists()
+
+
 def test_status_codes():
     h = hip()
     K, D = 256, 300
