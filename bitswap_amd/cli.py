@@ -179,12 +179,17 @@ def dataset_main(dataset, default_nz, nz_loop=None):
 # ---------------------------------------------------------------------------------------------
 # single-image path: imagenetcrop_compress.compress / demo_compress.compress / demo_decompress.decompress
 # ---------------------------------------------------------------------------------------------
-def crop_setup(gpu, nz=4, quantbits=10, synthetic=False, params=None, outdir=".", backend=None, small=None):
+def crop_setup(gpu, nz=4, quantbits=10, synthetic=False, params=None, outdir=".", backend=None, small=None,
+               nn_batch=16):
+    """Model + bins of the crop/demo scripts.  nn_batch: the conv stacks always run on micro-batches of
+    exactly this many blocks (zero padded), so a block's (mu, scale) bits do not depend on which other
+    images are coded next to it -- an image compressed in a lock-step batch of many can be decompressed
+    on its own (demo_decompress.py) and vice versa."""
     dev = torch.device("cpu") if backend is not None else torch.device("cuda", max(gpu, 0))
     if small:
-        model = workload.synthetic_model("imagenetcrop", nz, dev, small=small)
+        model = workload.synthetic_model("imagenetcrop", nz, dev, small=small, nn_batch=nn_batch)
     else:
-        model = load_model("imagenetcrop", nz, dev, params, synthetic)
+        model = load_model("imagenetcrop", nz, dev, params, synthetic, nn_batch=nn_batch)
     data = workload.synthetic_blocks(512, model.xs, seed=100).view((-1,) + tuple(model.xs))
     zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, "imagenetcrop", data=data,
                             ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"),
@@ -198,24 +203,20 @@ def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_qui
     chain, imagenetcrop_compress.py:279-300).  Chains of different length run in lock-step and
     drop out as they finish.  Returns (list of state lists, list of min_words, bits/dim per image)."""
     model, zend, zcen, dev = setup
-    flat = [(tiling.blocks_to_hwc_flat(b) if hwc_quirk else tiling.blocks_to_chw_flat(b)) for b in images_blocks]
-    order = sorted(range(len(flat)), key=lambda i: -len(flat[i]))
+    flat = [torch.from_numpy((tiling.blocks_to_hwc_flat(b) if hwc_quirk else tiling.blocks_to_chw_flat(b)).astype(np.int32))
+            for b in images_blocks]
     codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap), backend=backend)
+    np.random.seed(100)   # every image starts from the same 'random' stack (imagenetcrop_compress.py:249,122)
+    nmax = max(len(f) for f in flat)
+    one = initial_states(1, 10000, seed=100)[0]
+    state = codec.new_states(len(flat), nmax, states=[list(one) for _ in flat])
+    state.min_len = state.len.clone()
+    state, order, met = codec.compress_ragged(flat, state=state)
+    mins = state.min_len.cpu().tolist() if getattr(state, "min_len", None) is not None else [0] * len(flat)
+    lists = state.to_lists()
     results = [None] * len(flat)
-    # group chains of equal block count (lock-step needs equal lengths); singletons are fine
-    groups = {}
-    for i in order:
-        groups.setdefault(len(flat[i]), []).append(i)
-    for n, ids in groups.items():
-        np.random.seed(100)   # every image starts from the same 'random' stack (imagenetcrop_compress.py:249,122)
-        init = initial_states(1, 10000, seed=100)[0]
-        x = torch.from_numpy(np.stack([flat[i] for i in ids]).astype(np.int32))
-        state = codec.new_states(len(ids), n, states=[list(init) for _ in ids])
-        state.min_len = state.len.clone()
-        state, met = codec.compress(x.to(dev), state=state)
-        mins = state.min_len.cpu().tolist()
-        for k, i in enumerate(ids):
-            results[i] = (state.to_lists()[k], int(mins[k]) if trim else 0, float(met["cma"][k, -1]))
+    for k, i in enumerate(order):
+        results[i] = (lists[k], int(mins[k]) if trim else 0, float(met["cma"][k]))
     return results
 
 

@@ -169,14 +169,15 @@ class BitSwapCodec:
         return self.backend.new_state(states, cap)
 
     def _cdf(self, B, D, K):
-        """Reusable cdf-row buffer per table shape (the largest, [B, Z, K+4] u32, is ~0.84 GB at
-        B=100, Z=2048, K=1024: resident for the whole run instead of re-allocated per layer)."""
-        key = (B, D, K)
+        """Reusable cdf-row buffer per table shape (the largest, [B, Z, K+64] u32, is 1.8 GB at B=200,
+        Z=2048, K=1024: resident for the whole run instead of re-allocated per layer).  A smaller chain
+        count (ragged runs: chains drop out) takes a prefix of the buffer made for the largest one."""
+        key = (D, K)
         buf = self._cdf_bufs.get(key)
-        if buf is None:
+        if buf is None or buf.shape[0] < B:
             buf = self.backend.table_buffer(B, D, K)
             self._cdf_bufs[key] = buf
-        return buf
+        return buf if buf is None or buf.shape[0] == B else buf[:B]
 
     # ---- stream split helpers ---------------------------------------------------------------------
     def _on(self, stream):
@@ -381,6 +382,54 @@ class BitSwapCodec:
         nets = np.diff(np.concatenate([np.zeros((B, 1)), cumnet], axis=1), axis=1)   # (:258)
         cma = total / (X * np.arange(1, n + 1)[None, :])                             # (:260)
         return state, dict(nets=nets, cma=cma, total=total.astype(np.float64), rest_len=rest_len, init_len=init_len)
+
+    # ---- chains of different lengths (one image = one chain, imagenetcrop_compress.py:279-300) ---------
+    def compress_ragged(self, chains, state=None, nwords=10000, seed=100, same_init=True):
+        """chains: list of integer tensors [n_i, X].  All chains run in lock-step; with the chains sorted
+        by decreasing length the active set at block xi is a PREFIX of the batch, so the kernels simply see
+        fewer chains as the short ones finish (no masking, no padding work).  Returns (state, order,
+        metrics) where state/metrics rows follow `order` (indices into `chains`, longest first).
+        same_init: every chain starts from the same initial words, like the crop script (:249,122)."""
+        n = [int(c.shape[0]) for c in chains]
+        assert min(n) >= 1
+        order = sorted(range(len(chains)), key=lambda i: (-n[i], i))
+        ns = [n[i] for i in order]
+        B, nmax = len(chains), ns[0]
+        x = torch.zeros((B, nmax, self.X), dtype=torch.int32)
+        for k, i in enumerate(order):
+            x[k, : ns[k]] = torch.as_tensor(chains[i]).to(torch.int32)
+        x = x.to(self.device)
+        if state is None:
+            one = initial_states(1, nwords, seed)[0]
+            states = [list(one) for _ in range(B)] if same_init else initial_states(B, nwords, seed)
+            state = self.new_states(B, nmax, states=states)
+        init_len = state.len.clone()
+        rest_len = torch.zeros_like(state.len)
+        active = [sum(1 for m in ns if m > xi) for xi in range(nmax)]
+        for xi in range(nmax):
+            k = active[xi]
+            self.encode_block(state.prefix(k), x[:k, xi], rest_len if xi == 0 else None)
+        self.backend.check(state, "compress_ragged")
+        lens, init_len, rest_len = state.len.cpu().numpy().astype(np.int64), init_len.cpu().numpy(), rest_len.cpu().numpy()
+        nsa = np.array(ns, dtype=np.int64)
+        total = (lens - rest_len + 1) * 32                             # totalbits of the whole chain (:255)
+        return state, order, dict(total=total.astype(np.float64), cma=total / (self.X * nsa),
+                                  net=(lens - init_len) * 32 / (self.X * nsa), nblocks=nsa, rest_len=rest_len)
+
+    def decompress_ragged(self, state, nblocks):
+        """Receiver for compress_ragged: nblocks[k] blocks for chain k (non-increasing).  -> list of
+        [n_k, X] int32 tensors; state is unwound in place."""
+        ns = [int(v) for v in nblocks]
+        assert all(a >= b for a, b in zip(ns, ns[1:])), "chains must be sorted by decreasing length"
+        nmax = ns[0]
+        out = [[None] * m for m in ns]
+        for xi in reversed(range(nmax)):
+            k = sum(1 for m in ns if m > xi)
+            xb = self.decode_block(state.prefix(k))
+            for c in range(k):
+                out[c][xi] = xb[c]
+        self.backend.check(state, "decompress_ragged")
+        return [torch.stack(o, dim=0) for o in out]
 
     def decompress(self, state, nblocks):
         """-> images [B, nblocks, X] int32 (blocks in original order); state is unwound in place."""

@@ -214,6 +214,19 @@ class RansState:
         self.len = torch.zeros(B, dtype=torch.int32, device=device)
         self.status = torch.zeros(B, dtype=torch.int32, device=device)
 
+    def prefix(self, k):
+        """The first k chains as a RansState sharing this one's memory (chains sorted by decreasing
+        length drop out of a lock-step run from the back: codec.compress_ragged)."""
+        if k == self.B:
+            return self
+        v = object.__new__(RansState)
+        v.B, v.cap, v.device = int(k), self.cap, self.device
+        v.head, v.stack, v.len, v.status = self.head[:k], self.stack[:k], self.len[:k], self.status[:k]
+        ml = getattr(self, "min_len", None)
+        if ml is not None:
+            v.min_len = ml[:k]
+        return v
+
     @classmethod
     def from_lists(cls, states, cap=None, device="cuda"):
         """states: list of B Python lists [w0, ..., w_{n-1}, head]."""

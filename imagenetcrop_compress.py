@@ -5,6 +5,7 @@ Bit-Swap and BB-ANS.  Only --gpu in the reference; extras: --images DIR|.npy, --
 Images are independent chains: under torchrun they are sharded over the GPUs by block count."""
 import argparse
 import os
+import time
 
 import numpy as np
 
@@ -55,12 +56,18 @@ if __name__ == '__main__':
     gpu = args.gpu if world == 1 else rank
     setup = cli.crop_setup(gpu, nz=4, quantbits=10, synthetic=args.synthetic, params=args.params)
     res = {}
+    nblk = sum(len(blocks[i]) for i in mine)
     for name, bs in (("bbans", 0), ("bitswap", 1)):
+        t0 = time.perf_counter()
         out = cli.compress_images([blocks[i] for i in mine], quantbits=10, nz=4, bitswap=bs, gpu=gpu,
                                   hwc_quirk=True, setup=setup)
+        dt = time.perf_counter() - t0        # compress_images ends with a device->host copy of the streams
         bpd = dist.gather_rows(np.array([[o[2]] for o in out]), mine, len(blocks))
+        tot = dist.allreduce_sum([float(nblk)])
         if rank == 0:
             res[name] = bpd[:, 0]
+            print(f"{name}: rank 0 coded {len(mine)} images / {nblk} blocks in {dt:.2f} s "
+                  f"({nblk * 1024 / dt:.0f} pixels/s sender, this rank; {int(tot[0])} blocks on {world} GPU(s))")
     if rank == 0:
         print(f"bbans: {np.mean(res['bbans']):.2f} bits/dim")
         print(f"bitswap: {np.mean(res['bitswap']):.2f} bits/dim")

@@ -28,6 +28,16 @@ class OracleState:
         self.B = len(states)
         self.rc = np.zeros(self.B, dtype=np.int32)
 
+    def prefix(self, k):
+        """First k chains, sharing the stacks and the status array (mirror of RansState.prefix)."""
+        if k == self.B:
+            return self
+        v = object.__new__(OracleState)
+        v.stacks, v.B, v.rc = self.stacks[:k], int(k), self.rc[:k]
+        if getattr(self, "min_len", None) is not None:
+            v.min_len = self.min_len[:k]
+        return v
+
     @property
     def len(self):
         return torch.tensor([int(s.len[0]) for s in self.stacks], dtype=torch.int32)

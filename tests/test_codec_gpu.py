@@ -195,3 +195,23 @@ def test_config3_shape_many_blocks_lossless():
     torch.cuda.synchronize()
     gc.check(states)
     assert torch.equal(out, images) and gc.to_lists(states) == init
+
+
+def test_ragged_chains_on_gpu():
+    """config 4 shape: images of different sizes = chains of different lengths in one lock-step run on the
+    HIP kernels (prefix views of the state tensors); streams equal the chains coded alone (nn_batch keeps the
+    convs batch-invariant), the receiver returns every block."""
+    model, zend, zcen = workload.build("imagenetcrop4", DEV, quantbits=10, small=16, nn_batch=4)
+    lens = [3, 1, 5, 2, 5]
+    chains = [workload.synthetic_blocks(n, model.xs, seed=60 + i).to(torch.int32) for i, n in enumerate(lens)]
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
+    state, order, met = codec.compress_ragged(chains)
+    lists = state.to_lists()
+    assert met["nblocks"].tolist() == sorted(lens, reverse=True) and np.all(met["cma"] > 0)
+    for k, i in enumerate(order[:3]):
+        alone, _, _ = codec.compress_ragged([chains[i]])
+        assert alone.to_lists()[0] == lists[k]
+    out = codec.decompress_ragged(state, met["nblocks"])
+    for k, i in enumerate(order):
+        assert torch.equal(out[k].cpu(), chains[i])
+    assert state.to_lists() == [initial_states(1)[0]] * len(lens)

@@ -199,3 +199,27 @@ def test_demo_image_path_with_trimmed_container():
         out, rest = cli.decompress_image(st2, nb, quantbits=6, nz=2, setup=setup, backend=ob)
         assert np.array_equal(out, blk)
         assert rest == reference_init_state()[min_words:]           # what is left is the kept tail of the initial stack
+
+
+def test_ragged_lock_step_equals_chains_coded_alone():
+    """compress_ragged: chains of different length run in lock-step and drop out from the back of the
+    (length-sorted) batch.  With nn_batch the conv outputs do not depend on the batch composition, so every
+    chain's stream equals the one obtained by coding that chain on its own; the ragged receiver returns all
+    blocks and unwinds every state."""
+    ob = OracleBackend(O.MODE_DET)
+    model, zend, zcen = workload.build("imagenetcrop4", "cpu", quantbits=6, small=8, nn_batch=2)
+    lens = [2, 4, 1, 3]
+    chains = [workload.synthetic_blocks(n, model.xs, seed=40 + i).to(torch.int32) for i, n in enumerate(lens)]
+    codec = BitSwapCodec(model, zend, zcen, quantbits=6, bitswap=True, backend=ob)
+    state, order, met = codec.compress_ragged(chains)
+    assert [lens[i] for i in order] == [4, 3, 2, 1] and met["nblocks"].tolist() == [4, 3, 2, 1]
+    lists = state.to_lists()
+    for k, i in enumerate(order):
+        alone, _, m1 = codec.compress_ragged([chains[i]])
+        assert alone.to_lists()[0] == lists[k]
+        assert m1["total"][0] == met["total"][k]
+    out = codec.decompress_ragged(state, met["nblocks"])
+    for k, i in enumerate(order):
+        assert torch.equal(out[k], chains[i])
+    one = reference_init_state()
+    assert state.to_lists() == [one] * 4
