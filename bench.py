@@ -94,10 +94,13 @@ def main():
         import torch.distributed as dist
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo",
+        # BENCH_DIST_BACKEND=gloo lets the control flow be exercised with several ranks on ONE device
+        # (RCCL refuses two ranks per GPU); the driver never sets it
+        dist.init_process_group(os.environ.get("BENCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo"),
                                 timeout=datetime.timedelta(seconds=300))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the coding path has no CPU fallback)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.backends.cudnn.deterministic = True
