@@ -48,7 +48,8 @@ class WnConv2d(nn.Module):
         nn.init.normal_(self.v, 0.0, 0.05)
         (nn.init.zeros_ if loggain else nn.init.ones_)(self.gain)
         nn.init.zeros_(self.b)
-        self._w = None
+        self._w = None      # folded weight (fold())
+        self._w5 = None     # per-kernel-row GEMM operands of a 5x5 conv (Model.fuse())
 
     def weight(self):
         g = softplus(self.gain) if self.loggain else self.gain
@@ -60,14 +61,14 @@ class WnConv2d(nn.Module):
             self._w = self.weight().contiguous()
 
     def unfold(self):
-        self._w = None
+        self._w = self._w5 = None
 
     def forward(self, x):
         w = self._w if self._w is not None else self.weight()
         return F.conv2d(x, w, self.b, stride=self.stride, padding=self.padding)
 
     def _load_from_state_dict(self, *a, **k):
-        self._w = None
+        self._w = self._w5 = None
         return super()._load_from_state_dict(*a, **k)
 
 
