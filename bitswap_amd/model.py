@@ -200,6 +200,11 @@ class Model(nn.Module):
             self.gen_std = nn.Parameter(torch.zeros(*self.xs))
 
     # ----------------------------------------------------------------------------------------
+    def load_state_dict(self, *a, **k):
+        """New weights invalidate everything derived from the old ones: call fold()/fuse() again."""
+        self.fused, self._heads = False, {}
+        return super().load_state_dict(*a, **k)
+
     def compress(self, compress=True):
         self.compressing = compress
 
