@@ -19,7 +19,7 @@ LAYOUT_LINEAR, LAYOUT_WAVE = 0, 1
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres",
-    "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32",
+    "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
@@ -64,6 +64,8 @@ def load():
     L.bs_bias_residual_elu_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     L.bs_head_params_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, p]
     L.bs_expand_rows5_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, p]
+    L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, p]
+    L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, p]
     for n in SYMBOLS:
         if n != "bs_strerror":
             getattr(L, n).restype = i32
@@ -365,3 +367,27 @@ def expand_rows5(x, bias=None, act=True):
     _check(load().bs_expand_rows5_f32(_ptr(x), _ptr(bias), _ptr(out), N, Cc, H, W, 1 if act else 0, _stream()),
            "bs_expand_rows5_f32")
     return out
+
+
+def wino_in(x, bias=None, act=True, ms=4):
+    """[N,C,H,W] -> V [36, C, N*T]: Winograd input transform of ELU(x + bias) (see include/bitswap_hip.h)."""
+    _need_cuda(x, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, Cc, H, W = x.shape
+    V = torch.empty((36, Cc, N * (H // ms) * (W // ms)), dtype=torch.float32, device=x.device)
+    _check(load().bs_wino_in_f32(_ptr(x), _ptr(bias), _ptr(V), N, Cc, H, W, ms, 1 if act else 0, _stream()),
+           "bs_wino_in_f32")
+    return V
+
+
+def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, ms=4):
+    """M [36, C, N*T] -> (s | None, ELU(s) | None) as [N,C,H,W], s = A^T M A + bias[c] (+ res)."""
+    _need_cuda(M, bias, res)
+    N, Cc, H, W = shape
+    assert M.dtype == torch.float32 and M.is_contiguous() and tuple(M.shape) == (36, Cc, N * (H // ms) * (W // ms))
+    assert res is None or (res.is_contiguous() and tuple(res.shape) == tuple(shape) and res.dtype == torch.float32)
+    s_out = torch.empty(shape, dtype=torch.float32, device=M.device) if want_sum else None
+    a_out = torch.empty(shape, dtype=torch.float32, device=M.device) if want_act else None
+    _check(load().bs_wino_out_f32(_ptr(M), _ptr(bias), _ptr(res), _ptr(s_out), _ptr(a_out), N, Cc, H, W, ms,
+                                  _stream()), "bs_wino_out_f32")
+    return s_out, a_out

@@ -50,6 +50,7 @@ class WnConv2d(nn.Module):
         nn.init.zeros_(self.b)
         self._w = None      # folded weight (fold())
         self._w5 = None     # per-kernel-row GEMM operands of a 5x5 conv (Model.fuse())
+        self._wu = None     # Winograd-domain weights U [36, Cout, Cin] (Model.fuse())
 
     def weight(self):
         g = softplus(self.gain) if self.loggain else self.gain
@@ -61,14 +62,14 @@ class WnConv2d(nn.Module):
             self._w = self.weight().contiguous()
 
     def unfold(self):
-        self._w = self._w5 = None
+        self._w = self._w5 = self._wu = None
 
     def forward(self, x):
         w = self._w if self._w is not None else self.weight()
         return F.conv2d(x, w, self.b, stride=self.stride, padding=self.padding)
 
     def _load_from_state_dict(self, *a, **k):
-        self._w = self._w5 = None
+        self._w = self._w5 = self._wu = None
         return super()._load_from_state_dict(*a, **k)
 
 
@@ -145,7 +146,10 @@ class Model(nn.Module):
         self.best_elbo = np.inf
         self.nn_batch = nn_batch
         self.fused = False
-        self.gemm5_min_batch = 24    # below this the batched GEMMs do not beat MIOpen (tools/conv_probe3.py)
+        # ResNet convs of the fused path: "winograd" (transform-domain batched GEMM, 3x3 and 5x5), "gemm5" (5x5 as
+        # five row GEMMs, 3x3 on MIOpen) or "miopen"; below gemm_min_batch images MIOpen always runs them
+        self.conv_algo = "winograd"
+        self.gemm_min_batch = 24
         self._heads = {}
         self.conditional_gen_std = conditional_gen_std
         pad5, pad = 2, (kernel_size - 1) // 2
@@ -247,8 +251,13 @@ class Model(nn.Module):
                     self._heads[f"gen{i + 1}"] = stack(self.deepgen_mu[i], self.deepgen_std[i])
                 if not self.conditional_gen_std:
                     self._gen_scale = (((2. / 255.) / 8.) + softplus(self.gen_std)).contiguous()
-                # 5x5 ResNet convs as five GEMMs (one per kernel row): W_dy [Cout, Cin*5]
+                # ResNet convs (3x3 and 5x5, Cin == Cout) in the Winograd domain: U = G w G^T, [36, Cout, Cin]
+                from .winograd import transform_weights
                 for m in self.modules():
+                    if (isinstance(m, WnConv2d) and m.kernel_size in (3, 5) and m.in_dim == m.out_dim
+                            and m.stride == 1 and m.padding == m.kernel_size // 2):
+                        m._wu = transform_weights(m._w)
+                    # 5x5 as five GEMMs (one per kernel row), the alternative path: W_dy [Cout, Cin*5]
                     if isinstance(m, WnConv2d) and m.kernel_size == 5 and m.in_dim == m.out_dim and m.stride == 1:
                         m._w5 = [m._w[:, :, dy, :].reshape(m.out_dim, m.in_dim * 5).contiguous() for dy in range(5)]
         return self
@@ -295,6 +304,22 @@ class Model(nn.Module):
                 return hip.bias_residual_elu(c2, L.conv2.b, h)[1]
             h = hip.bias_residual_elu(c2, L.conv2.b, h, want_sum=True, want_act=False)[0]
 
+    def _res_wino(self, layers, h):
+        """A ResNet block in the Winograd domain (bitswap_amd/winograd.py): per conv one input transform
+        (carrying the ELU and conv1's bias), ONE batched GEMM of 36 [C x C] x [C x tiles] products on
+        rocBLAS/hipBLASLt, one output transform (carrying bias, residual add and the next ELU).  2.25x (3x3) /
+        2.78x (5x5) fewer multiplications than the direct convolution, all of them on the MFMA units."""
+        from . import hip
+        ms = 4 if layers[0].conv1.kernel_size == 3 else 2
+        shape = tuple(h.shape)
+        for k, L in enumerate(layers):
+            m1 = torch.bmm(L.conv1._wu, hip.wino_in(h, None, True, ms))               # conv1(ELU(h))
+            t = hip.wino_out(m1, shape, L.conv1.b, None, False, True, ms)[1]          # ELU(. + b1)
+            m2 = torch.bmm(L.conv2._wu, hip.wino_in(t, None, False, ms))
+            if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
+                return hip.wino_out(m2, shape, L.conv2.b, h, False, True, ms)[1]
+            h = hip.wino_out(m2, shape, L.conv2.b, h, True, False, ms)[0]
+
     def _fused_res(self, seq, h):
         """Sequential(ResNetBlock, act) on an activated input h (Pass: identity).  Per layer
         x + conv2(act(conv1(act(x)))): two convs, two epilogue launches."""
@@ -302,8 +327,11 @@ class Model(nn.Module):
         if isinstance(seq, Pass):
             return h
         layers = list(seq[0].children())
-        if (layers[0].conv1.kernel_size == 5 and h.shape[0] >= self.gemm5_min_batch and h.shape[-1] % 4 == 0
-                and getattr(layers[0].conv1, "_w5", None) is not None):
+        if (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
+                and h.shape[-1] % 4 == 0 and h.shape[-2] % 4 == 0):
+            return self._res_wino(layers, h)
+        if (self.conv_algo in ("winograd", "gemm5") and layers[0].conv1.kernel_size == 5
+                and h.shape[0] >= self.gemm_min_batch and h.shape[-1] % 4 == 0 and layers[0].conv1._w5 is not None):
             return self._res5_gemm(layers, h)
         a = hip.bias_residual_elu(h, None, inplace=False)[1]          # act(x) of the first layer
         for k, L in enumerate(layers):

@@ -184,6 +184,15 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *   out[n, c*5+dx, yy, x] = act(in[n, c, yy-2, x+dx-2] + bias[c]) inside the image, 0 outside;
  *   act != 0 applies ELU, bias nullable.  Kernel row dy of the convolution is then one strided-batched
  *   GEMM W_dy [Cout, C*5] x out[n, :, dy:dy+H, :] (leading dimension (H+4)*W).  W % 4 == 0.
+ *
+ * bs_wino_in_f32 / bs_wino_out_f32 -- the two ends of a Winograd-domain convolution whose middle is ONE
+ *   batched GEMM M[t] = U[t] x V[t], t = 0..35 (bitswap_amd/model.py::_conv_wino; U = G g G^T is computed
+ *   from the folded weights once).  ms = 4: F(4x4, 3x3), 'same' padding 1;  ms = 2: F(2x2, 5x5), padding 2;
+ *   both on the points {0, 1, -1, 2, -2, inf}.  H, W multiples of ms.
+ *     in : V [36, C, N*T] <- B^T d B of the 6x6 windows of act(in [N,C,H,W] + bias[c]); T = (H/ms)*(W/ms),
+ *          column = n*T + tile;  act != 0 applies ELU;  bias nullable.
+ *     out: s = A^T M A + bias[c] (+ res [N,C,H,W]) from M [36, C, N*T]; sum_out = s, act_out = ELU(s)
+ *          (each nullable, at least one), both [N,C,H,W].
  */
 #define BS_HEAD_SIGMOID 0
 #define BS_HEAD_SOFTPLUS 1
@@ -193,6 +202,10 @@ int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scal
                        int HW, int mode, void* stream);
 int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W,
                         int act, void* stream);
+int bs_wino_in_f32(const float* in, const float* bias, float* V, int64_t N, int C, int H, int W, int ms,
+                   int act, void* stream);
+int bs_wino_out_f32(const float* M, const float* bias, const float* res, float* sum_out, float* act_out,
+                    int64_t N, int C, int H, int W, int ms, void* stream);
 
 #ifdef __cplusplus
 }

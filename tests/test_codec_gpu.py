@@ -108,8 +108,38 @@ def test_cli_and_demo_container_on_gpu(tmp_path):
     assert rest == reference_init_state()[min_words:]
 
 
+@pytest.mark.parametrize("ks", [3, 5])
+def test_winograd_convs_match_torch(ks):
+    """The transform-domain convolution (k_wino_in -> one batched GEMM of 36 products -> k_wino_out) against
+    F.conv2d in float64: F(4x4,3x3) and F(2x2,5x5) on the points {0,+-1,+-2,inf}; fp32 error a few 1e-6 of the
+    output range; input-side bias+ELU and output-side bias+residual+ELU fused into the transforms."""
+    from bitswap_amd import hip, winograd
+    g = torch.Generator().manual_seed(ks)
+    n, C = 5, 24
+    x = torch.randn((n, C, 16, 16), generator=g).to(DEV)
+    w = (torch.randn((C, C, ks, ks), generator=g) / (C * ks * ks) ** 0.5).to(DEV)
+    b_in, b_out = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    res = torch.randn((n, C, 16, 16), generator=g).to(DEV)
+    ms = winograd.tile_stride(ks)
+    U = winograd.transform_weights(w)
+    a = torch.nn.functional.elu(x.double() + b_in.double().view(1, -1, 1, 1))
+    want = torch.nn.functional.conv2d(a, w.double(), padding=ks // 2) + b_out.double().view(1, -1, 1, 1) + res.double()
+    m = torch.bmm(U, hip.wino_in(x, b_in, True, ms))
+    s, act = hip.wino_out(m, tuple(x.shape), b_out, res, True, True, ms)
+    scale = float(want.abs().max())
+    assert float((s.double() - want).abs().max()) < 3e-5 * scale
+    assert float((act.double() - torch.nn.functional.elu(want)).abs().max()) < 3e-5 * scale
+    # plain conv (no bias, no activation, no residual) and bitwise repeatability
+    m2 = torch.bmm(U, hip.wino_in(x, None, False, ms))
+    y, _ = hip.wino_out(m2, tuple(x.shape), None, None, True, False, ms)
+    y2, _ = hip.wino_out(torch.bmm(U, hip.wino_in(x, None, False, ms)), tuple(x.shape), None, None, True, False, ms)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=ks // 2)
+    assert float((y.double() - ref).abs().max()) < 3e-5 * float(ref.abs().max()) and torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("algo", ["winograd", "gemm5", "miopen"])
 @pytest.mark.parametrize("name", ["mnist2", "imagenetcrop4"])
-def test_fused_epilogues_match_torch_modules(name):
+def test_fused_epilogues_match_torch_modules(name, algo):
     """Model.fuse(): one epilogue launch per conv (net_epilogue.hip) against the plain torch modules
     (bias / ELU / residual / scale heads as separate launches).  Same math, float32: agreement to a few
     ulp of the activations, and the fused path is bitwise repeatable."""
@@ -117,7 +147,7 @@ def test_fused_epilogues_match_torch_modules(name):
     model, _, _ = workload.build(name, DEV, quantbits=8, small=24)
     assert model.fused
     model.compress(True)
-    model.gemm5_min_batch = 1 if name == "mnist2" else 10 ** 9   # 5x5 blocks: GEMM path / MIOpen path
+    model.conv_algo, model.gemm_min_batch = algo, 1       # ResNet convs: Winograd-domain GEMM / row GEMMs / MIOpen
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
         for i in range(model.nz):
@@ -133,8 +163,8 @@ def test_fused_epilogues_match_torch_modules(name):
                 model.fused = True
                 assert torch.equal(mu_f, mu_f2) and torch.equal(sc_f, sc_f2)
                 assert mu_f.shape == mu_t.shape and sc_f.shape == sc_t.shape
-                assert torch.allclose(mu_f, mu_t, rtol=1e-4, atol=1e-5), float((mu_f - mu_t).abs().max())
-                assert torch.allclose(sc_f, sc_t, rtol=1e-4, atol=1e-6), float((sc_f - sc_t).abs().max())
+                assert torch.allclose(mu_f, mu_t, rtol=2e-4, atol=2e-5), float((mu_f - mu_t).abs().max())
+                assert torch.allclose(sc_f, sc_t, rtol=2e-4, atol=2e-6), float((sc_f - sc_t).abs().max())
     # the pointwise kernels alone, odd plane size (scalar path) and 16-byte path
     for shape in ((3, 5, 7, 9), (2, 6, 16, 16)):
         x = torch.randn(shape, generator=g).to(DEV)
