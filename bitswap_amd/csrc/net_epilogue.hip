@@ -120,34 +120,67 @@ __global__ __launch_bounds__(256) void k_expand_rows5(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Winograd-domain convolutions: F(4x4, 3x3) and F(2x2, 5x5) share the interpolation points
-// {0, 1, -1, 2, -2, inf}, hence the 6x6 input transform B^T d B; they differ in the tile stride
-// MS (= outputs per tile side: 4 / 2), the padding (1 / 2) and the output transform A^T M A.
-// The 36 element-wise products per tile become ONE batched GEMM on rocBLAS/hipBLASLt (MFMA):
-//     M[t] [Cout, N] = U[t] [Cout, Cin] x V[t] [Cin, N],  t = 0..35,  N = images * tiles
-// with 2.25x (3x3) / 2.78x (5x5) fewer multiplications than the direct convolution.  The two
-// transforms below are the HBM-bound ends of it; they also carry the pointwise work of the
-// ResNet layer (bias / ELU in front, bias / residual / ELU behind), so nothing else touches the
-// activations between two GEMMs.  fp32 throughout; error vs the direct fp32 convolution ~4e-6
-// relative (tests/test_codec_gpu.py::test_winograd_convs_match_torch).
+// Winograd-domain convolutions.  Three Cook-Toom algorithms (bitswap_amd/winograd.py):
+//     F(4x4, 3x3)  6x6 tiles, stride 4, pad 1    points {0, +-1, +-2, inf}           36 products / 16 outputs
+//     F(2x2, 5x5)  6x6 tiles, stride 2, pad 2    same points, same B^T             36 products /  4 outputs
+//     F(4x4, 5x5)  8x8 tiles, stride 4, pad 2    points {0, +-1, +-2, +-1/2, inf}  64 products / 16 outputs
+// The TS*TS element-wise products per tile become ONE batched GEMM on rocBLAS/hipBLASLt (MFMA):
+//     M[t] [Cout, N] = U[t] [Cout, Cin] x V[t] [Cin, N],  t = 0..TS*TS-1,  N = images * tiles
+// with 2.25x / 2.78x / 6.25x fewer multiplications than the direct convolution.  The two transforms
+// below are the HBM-bound ends of it; they also carry the pointwise work of the ResNet layer (bias / ELU
+// in front, bias / residual / ELU behind), so nothing else touches the activations between two GEMMs.
+// fp32 throughout; error vs the direct convolution a few 1e-6 of the output range
+// (tests/test_codec_gpu.py::test_winograd_convs_match_torch).  Formulas: tools/gen_wino.py.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino_bt6(const float d[6], float o[6]) {
-    o[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
-    o[1] = -4.0f * d[1] - 4.0f * d[2] + d[3] + d[4];
-    o[2] = 4.0f * d[1] - 4.0f * d[2] - d[3] + d[4];
-    o[3] = -2.0f * d[1] - d[2] + 2.0f * d[3] + d[4];
-    o[4] = 2.0f * d[1] - d[2] - 2.0f * d[3] + d[4];
-    o[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+template <int TS>
+__device__ __forceinline__ void wino_bt(const float (&d)[TS], float (&o)[TS]) {
+    if (TS == 6) {
+        o[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+        o[1] = -4.0f * d[1] - 4.0f * d[2] + d[3] + d[4];
+        o[2] = 4.0f * d[1] - 4.0f * d[2] - d[3] + d[4];
+        o[3] = -2.0f * d[1] - d[2] + 2.0f * d[3] + d[4];
+        o[4] = 2.0f * d[1] - d[2] - 2.0f * d[3] + d[4];
+        o[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+    } else {
+        o[0] = -d[0] + 5.25f * d[2] - 5.25f * d[4] + d[6];
+        o[1] = d[1] + d[2] - 4.25f * d[3] - 4.25f * d[4] + d[5] + d[6];
+        o[2] = -d[1] + d[2] + 4.25f * d[3] - 4.25f * d[4] - d[5] + d[6];
+        o[3] = 0.5f * d[1] + 0.25f * d[2] - 2.5f * d[3] - 1.25f * d[4] + 2.0f * d[5] + d[6];
+        o[4] = -0.5f * d[1] + 0.25f * d[2] + 2.5f * d[3] - 1.25f * d[4] - 2.0f * d[5] + d[6];
+        o[5] = 2.0f * d[1] + 4.0f * d[2] - 2.5f * d[3] - 5.0f * d[4] + 0.5f * d[5] + d[6];
+        o[6] = -2.0f * d[1] + 4.0f * d[2] + 2.5f * d[3] - 5.0f * d[4] - 0.5f * d[5] + d[6];
+        o[7] = -d[1] + 5.25f * d[3] - 5.25f * d[5] + d[(TS == 8) ? 7 : 0];
+    }
 }
 
-// in [N, C, H, W] -> V [36, C, N*T] (T = (H/MS)*(W/MS) tiles per image, column = n*T + ty*(W/MS) + tx):
-// V[t] = (B^T d B)[t/6][t%6] of the 6x6 window of act(in + bias) at rows ty*MS - PAD .. +5 (0 outside).
-// One thread per (channel, column): its 36 stores are coalesced across the wave.
-template <int MS>
+template <int TS, int MS>
+__device__ __forceinline__ void wino_at(const float (&m)[TS], float (&y)[MS]) {
+    if (TS == 6) {
+        y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+        if (MS == 2) {
+            y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4] + m[5];
+        } else {
+            y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4];
+            y[(MS == 4) ? 2 : 0] = m[1] + m[2] + 4.0f * m[3] + 4.0f * m[4];
+            y[(MS == 4) ? 3 : 0] = m[1] - m[2] + 8.0f * m[3] - 8.0f * m[4] + m[5];
+        }
+    } else {
+        constexpr int a6 = (TS == 8) ? 6 : 0, a7 = (TS == 8) ? 7 : 0;
+        y[0] = m[0] + m[1] + m[2] + m[3] + m[4] + m[5] + m[a6];
+        y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4] + 0.5f * m[5] - 0.5f * m[a6];
+        y[(MS == 4) ? 2 : 0] = m[1] + m[2] + 4.0f * m[3] + 4.0f * m[4] + 0.25f * m[5] + 0.25f * m[a6];
+        y[(MS == 4) ? 3 : 0] = m[1] - m[2] + 8.0f * m[3] - 8.0f * m[4] + 0.125f * m[5] - 0.125f * m[a6] + m[a7];
+    }
+}
+
+// in [N, C, H, W] -> V [TS*TS, C, N*T] (T = (H/MS)*(W/MS) tiles per image, column = n*T + ty*(W/MS) + tx):
+// V[t] = (B^T d B)[t/TS][t%TS] of the TS x TS window of act(in + bias) at rows ty*MS - PAD .. (0 outside).
+// One thread per (channel, column): its TS*TS stores are coalesced across the wave.
+template <int TS, int MS>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, const float* __restrict__ bias,
                                                  float* __restrict__ V, int64_t total, int C, int H, int W,
                                                  int64_t ncols, int act) {
-    constexpr int PAD = (6 - MS) / 2;
+    constexpr int PAD = (TS - MS) / 2;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int64_t col = i % ncols;
@@ -158,57 +191,39 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ in, c
     const int ty = tile / ntx, tx = tile - ty * ntx;
     const float b = bias ? bias[c] : 0.0f;
     const float* plane = in + (n * C + c) * (int64_t)H * W;
-    float d[6][6];
+    float t1[TS][TS];  // B^T d: the window is read column by column and transformed on the fly
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const int y = ty * MS - PAD + r;
+    for (int q = 0; q < TS; ++q) {
+        const int x = tx * MS - PAD + q;
+        float colv[TS], o[TS];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int x = tx * MS - PAD + q;
+        for (int r = 0; r < TS; ++r) {
+            const int y = ty * MS - PAD + r;
             float e = 0.0f;
             if (y >= 0 && y < H && x >= 0 && x < W) {
                 e = plane[y * W + x] + b;
                 if (act) e = elu1(e);
             }
-            d[r][q] = e;
+            colv[r] = e;
         }
-    }
-    float t1[6][6];  // B^T d  (transform the columns)
+        wino_bt<TS>(colv, o);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        float colv[6], o[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) colv[r] = d[r][q];
-        wino_bt6(colv, o);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) t1[r][q] = o[r];
+        for (int r = 0; r < TS; ++r) t1[r][q] = o[r];
     }
     float* out = V + (int64_t)c * ncols + col;
     const int64_t tstride = (int64_t)C * ncols;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {  // (B^T d) B  (transform the rows)
-        float o[6];
-        wino_bt6(t1[r], o);
+    for (int r = 0; r < TS; ++r) {  // (B^T d) B
+        float o[TS];
+        wino_bt<TS>(t1[r], o);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) out[(int64_t)(r * 6 + q) * tstride] = o[q];
+        for (int q = 0; q < TS; ++q) out[(int64_t)(r * TS + q) * tstride] = o[q];
     }
 }
 
-template <int MS>
-__device__ __forceinline__ void wino_at(const float m[6], float y[MS]) {
-    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
-    if (MS == 2) {
-        y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4] + m[5];
-    } else {
-        y[1] = m[1] - m[2] + 2.0f * m[3] - 2.0f * m[4];
-        y[2] = m[1] + m[2] + 4.0f * m[3] + 4.0f * m[4];
-        y[3] = m[1] - m[2] + 8.0f * m[3] - 8.0f * m[4] + m[5];
-    }
-}
-
-// M [36, C, N*T] -> s = A^T M A + bias[c] (+ res) as [N, C, H, W]; sum_out = s (nullable), act_out = ELU(s)
+// M [TS*TS, C, N*T] -> s = A^T M A + bias[c] (+ res) as [N, C, H, W]; sum_out = s (nullable), act_out = ELU(s)
 // (nullable).  One thread per (channel, column) = one MS x MS output tile.
-template <int MS>
+template <int TS, int MS>
 __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias,
                                                   const float* __restrict__ res, float* __restrict__ sum_out,
                                                   float* __restrict__ act_out, int64_t total, int C, int H, int W,
@@ -223,13 +238,13 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, c
     const int ty = tile / ntx, tx = tile - ty * ntx;
     const float* src = M + (int64_t)c * ncols + col;
     const int64_t tstride = (int64_t)C * ncols;
-    float t1[MS][6];  // A^T M  (columns)
+    float t1[MS][TS];  // A^T M  (columns)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        float colv[6], y[MS];
+    for (int q = 0; q < TS; ++q) {
+        float colv[TS], y[MS];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) colv[r] = src[(int64_t)(r * 6 + q) * tstride];
-        wino_at<MS>(colv, y);
+        for (int r = 0; r < TS; ++r) colv[r] = src[(int64_t)(r * TS + q) * tstride];
+        wino_at<TS, MS>(colv, y);
 #pragma unroll
         for (int r = 0; r < MS; ++r) t1[r][q] = y[r];
     }
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, c
 #pragma unroll
     for (int r = 0; r < MS; ++r) {
         float y[MS];
-        wino_at<MS>(t1[r], y);
+        wino_at<TS, MS>(t1[r], y);
         const int64_t o = base + (int64_t)r * W;
 #pragma unroll
         for (int q = 0; q < MS; ++q) {
@@ -299,28 +314,37 @@ int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t 
     return launch_rc();
 }
 
-int bs_wino_in_f32(const float* in, const float* bias, float* V, int64_t N, int C, int H, int W, int ms, int act,
-                   void* stream) {
-    if (!in || !V || N < 0 || C < 1 || (ms != 2 && ms != 4) || H < ms || W < ms || H % ms || W % ms) return BS_EINVAL;
+static bool wino_cfg_ok(int ts, int ms, int H, int W) {
+    return ((ts == 6 && (ms == 4 || ms == 2)) || (ts == 8 && ms == 4)) && H >= ms && W >= ms && H % ms == 0 && W % ms == 0;
+}
+
+int bs_wino_in_f32(const float* in, const float* bias, float* V, int64_t N, int C, int H, int W, int ts, int ms,
+                   int act, void* stream) {
+    if (!in || !V || N < 0 || C < 1 || !wino_cfg_ok(ts, ms, H, W)) return BS_EINVAL;
     const int64_t ncols = N * (H / ms) * (W / ms), total = ncols * C;
     if (total == 0) return BS_OK;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (ms == 4) hipLaunchKernelGGL(k_wino_in<4>, grid, block, 0, S(stream), in, bias, V, total, C, H, W, ncols, act);
-    else hipLaunchKernelGGL(k_wino_in<2>, grid, block, 0, S(stream), in, bias, V, total, C, H, W, ncols, act);
+#define BS_WIN(TS, MS) hipLaunchKernelGGL((k_wino_in<TS, MS>), grid, block, 0, S(stream), in, bias, V, total, C, H, W, ncols, act)
+    if (ts == 8) BS_WIN(8, 4);
+    else if (ms == 4) BS_WIN(6, 4);
+    else BS_WIN(6, 2);
+#undef BS_WIN
     return launch_rc();
 }
 
 int bs_wino_out_f32(const float* M, const float* bias, const float* res, float* sum_out, float* act_out, int64_t N,
-                    int C, int H, int W, int ms, void* stream) {
-    if (!M || (!sum_out && !act_out) || N < 0 || C < 1 || (ms != 2 && ms != 4) || H < ms || W < ms || H % ms || W % ms)
-        return BS_EINVAL;
+                    int C, int H, int W, int ts, int ms, void* stream) {
+    if (!M || (!sum_out && !act_out) || N < 0 || C < 1 || !wino_cfg_ok(ts, ms, H, W)) return BS_EINVAL;
     const int64_t ncols = N * (H / ms) * (W / ms), total = ncols * C;
     if (total == 0) return BS_OK;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (ms == 4)
-        hipLaunchKernelGGL(k_wino_out<4>, grid, block, 0, S(stream), M, bias, res, sum_out, act_out, total, C, H, W, ncols);
-    else
-        hipLaunchKernelGGL(k_wino_out<2>, grid, block, 0, S(stream), M, bias, res, sum_out, act_out, total, C, H, W, ncols);
+#define BS_WOUT(TS, MS)                                                                                       \
+    hipLaunchKernelGGL((k_wino_out<TS, MS>), grid, block, 0, S(stream), M, bias, res, sum_out, act_out, total, C, H, W, \
+                       ncols)
+    if (ts == 8) BS_WOUT(8, 4);
+    else if (ms == 4) BS_WOUT(6, 4);
+    else BS_WOUT(6, 2);
+#undef BS_WOUT
     return launch_rc();
 }
 

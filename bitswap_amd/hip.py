@@ -64,8 +64,8 @@ def load():
     L.bs_bias_residual_elu_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     L.bs_head_params_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, p]
     L.bs_expand_rows5_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, p]
-    L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, p]
-    L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, p]
+    L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     for n in SYMBOLS:
         if n != "bs_strerror":
             getattr(L, n).restype = i32
@@ -369,25 +369,28 @@ def expand_rows5(x, bias=None, act=True):
     return out
 
 
-def wino_in(x, bias=None, act=True, ms=4):
-    """[N,C,H,W] -> V [36, C, N*T]: Winograd input transform of ELU(x + bias) (see include/bitswap_hip.h)."""
+def wino_in(x, bias=None, act=True, cfg=(6, 4)):
+    """[N,C,H,W] -> V [ts*ts, C, N*T]: Winograd input transform of ELU(x + bias); cfg = (tile size, tile stride)
+    from winograd.tile_config() (see include/bitswap_hip.h)."""
     _need_cuda(x, bias)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    ts, ms = cfg
     N, Cc, H, W = x.shape
-    V = torch.empty((36, Cc, N * (H // ms) * (W // ms)), dtype=torch.float32, device=x.device)
-    _check(load().bs_wino_in_f32(_ptr(x), _ptr(bias), _ptr(V), N, Cc, H, W, ms, 1 if act else 0, _stream()),
+    V = torch.empty((ts * ts, Cc, N * (H // ms) * (W // ms)), dtype=torch.float32, device=x.device)
+    _check(load().bs_wino_in_f32(_ptr(x), _ptr(bias), _ptr(V), N, Cc, H, W, ts, ms, 1 if act else 0, _stream()),
            "bs_wino_in_f32")
     return V
 
 
-def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, ms=4):
-    """M [36, C, N*T] -> (s | None, ELU(s) | None) as [N,C,H,W], s = A^T M A + bias[c] (+ res)."""
+def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, cfg=(6, 4)):
+    """M [ts*ts, C, N*T] -> (s | None, ELU(s) | None) as [N,C,H,W], s = A^T M A + bias[c] (+ res)."""
     _need_cuda(M, bias, res)
+    ts, ms = cfg
     N, Cc, H, W = shape
-    assert M.dtype == torch.float32 and M.is_contiguous() and tuple(M.shape) == (36, Cc, N * (H // ms) * (W // ms))
+    assert M.dtype == torch.float32 and M.is_contiguous() and tuple(M.shape) == (ts * ts, Cc, N * (H // ms) * (W // ms))
     assert res is None or (res.is_contiguous() and tuple(res.shape) == tuple(shape) and res.dtype == torch.float32)
     s_out = torch.empty(shape, dtype=torch.float32, device=M.device) if want_sum else None
     a_out = torch.empty(shape, dtype=torch.float32, device=M.device) if want_act else None
-    _check(load().bs_wino_out_f32(_ptr(M), _ptr(bias), _ptr(res), _ptr(s_out), _ptr(a_out), N, Cc, H, W, ms,
+    _check(load().bs_wino_out_f32(_ptr(M), _ptr(bias), _ptr(res), _ptr(s_out), _ptr(a_out), N, Cc, H, W, ts, ms,
                                   _stream()), "bs_wino_out_f32")
     return s_out, a_out

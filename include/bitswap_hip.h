@@ -186,12 +186,13 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *   GEMM W_dy [Cout, C*5] x out[n, :, dy:dy+H, :] (leading dimension (H+4)*W).  W % 4 == 0.
  *
  * bs_wino_in_f32 / bs_wino_out_f32 -- the two ends of a Winograd-domain convolution whose middle is ONE
- *   batched GEMM M[t] = U[t] x V[t], t = 0..35 (bitswap_amd/model.py::_conv_wino; U = G g G^T is computed
- *   from the folded weights once).  ms = 4: F(4x4, 3x3), 'same' padding 1;  ms = 2: F(2x2, 5x5), padding 2;
- *   both on the points {0, 1, -1, 2, -2, inf}.  H, W multiples of ms.
- *     in : V [36, C, N*T] <- B^T d B of the 6x6 windows of act(in [N,C,H,W] + bias[c]); T = (H/ms)*(W/ms),
- *          column = n*T + tile;  act != 0 applies ELU;  bias nullable.
- *     out: s = A^T M A + bias[c] (+ res [N,C,H,W]) from M [36, C, N*T]; sum_out = s, act_out = ELU(s)
+ *   batched GEMM M[t] = U[t] x V[t], t = 0..ts*ts-1 (bitswap_amd/model.py::_res_wino; U = G g G^T is computed
+ *   from the folded weights once, bitswap_amd/winograd.py).  (ts, ms) = tile size, tile stride:
+ *     (6, 4): F(4x4, 3x3), 'same' padding 1;  (6, 2): F(2x2, 5x5), padding 2;  (8, 4): F(4x4, 5x5), padding 2.
+ *   H, W multiples of ms.
+ *     in : V [ts*ts, C, N*T] <- B^T d B of the ts x ts windows of act(in [N,C,H,W] + bias[c]);
+ *          T = (H/ms)*(W/ms), column = n*T + tile;  act != 0 applies ELU;  bias nullable.
+ *     out: s = A^T M A + bias[c] (+ res [N,C,H,W]) from M [ts*ts, C, N*T]; sum_out = s, act_out = ELU(s)
  *          (each nullable, at least one), both [N,C,H,W].
  */
 #define BS_HEAD_SIGMOID 0
@@ -202,10 +203,10 @@ int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scal
                        int HW, int mode, void* stream);
 int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W,
                         int act, void* stream);
-int bs_wino_in_f32(const float* in, const float* bias, float* V, int64_t N, int C, int H, int W, int ms,
-                   int act, void* stream);
+int bs_wino_in_f32(const float* in, const float* bias, float* V, int64_t N, int C, int H, int W, int ts,
+                   int ms, int act, void* stream);
 int bs_wino_out_f32(const float* M, const float* bias, const float* res, float* sum_out, float* act_out,
-                    int64_t N, int C, int H, int W, int ms, void* stream);
+                    int64_t N, int C, int H, int W, int ts, int ms, void* stream);
 
 #ifdef __cplusplus
 }

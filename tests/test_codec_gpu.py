@@ -108,10 +108,10 @@ def test_cli_and_demo_container_on_gpu(tmp_path):
     assert rest == reference_init_state()[min_words:]
 
 
-@pytest.mark.parametrize("ks", [3, 5])
-def test_winograd_convs_match_torch(ks):
+@pytest.mark.parametrize("ks,small", [(3, False), (5, False), (5, True)])
+def test_winograd_convs_match_torch(ks, small):
     """The transform-domain convolution (k_wino_in -> one batched GEMM of 36 products -> k_wino_out) against
-    F.conv2d in float64: F(4x4,3x3) and F(2x2,5x5) on the points {0,+-1,+-2,inf}; fp32 error a few 1e-6 of the
+    F.conv2d in float64: F(4x4,3x3), F(4x4,5x5) (8x8 tiles, points +-1/2 added) and F(2x2,5x5); fp32 error a few 1e-6 of the
     output range; input-side bias+ELU and output-side bias+residual+ELU fused into the transforms."""
     from bitswap_amd import hip, winograd
     g = torch.Generator().manual_seed(ks)
@@ -120,8 +120,8 @@ def test_winograd_convs_match_torch(ks):
     w = (torch.randn((C, C, ks, ks), generator=g) / (C * ks * ks) ** 0.5).to(DEV)
     b_in, b_out = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
     res = torch.randn((n, C, 16, 16), generator=g).to(DEV)
-    ms = winograd.tile_stride(ks)
-    U = winograd.transform_weights(w)
+    ms = winograd.tile_config(ks, small)
+    U = winograd.transform_weights(w, ms)
     a = torch.nn.functional.elu(x.double() + b_in.double().view(1, -1, 1, 1))
     want = torch.nn.functional.conv2d(a, w.double(), padding=ks // 2) + b_out.double().view(1, -1, 1, 1) + res.double()
     m = torch.bmm(U, hip.wino_in(x, b_in, True, ms))
