@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cifar8", choices=["mnist2", "cifar8", "imagenet4", "imagenetcrop4"])
-    ap.add_argument("--chains", type=int, default=400,
+    ap.add_argument("--chains", type=int, default=800,
                     help="independent chains (rANS streams) per GPU; the reference runs 100 'experiments' one block at a time, "
                          "an MI355X wants a few hundred in lock-step (conv efficiency grows with the batch, DESIGN.md 6)")
     ap.add_argument("--quantbits", type=int, default=10)

@@ -265,6 +265,113 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, c
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_wino_fused<TS_IN, TS_OUT>: everything between two batched GEMMs of a ResNet layer in ONE pass.
+//   source   TS_IN == 0: x [N,C,H,W]              TS_IN in {6,8}: M [TS_IN^2, C, N*T] -> A^T M A
+//   s = source + bias[c] (+ res);  sum_out = s (nullable);  a = act ? ELU(s) : s;  act_out = a (nullable)
+//   target   TS_OUT in {6,8}: V [TS_OUT^2, C, N*T] <- B^T a B of the TS_OUT x TS_OUT windows (0 outside)
+// Tile stride 4 on both sides (F(4x4,3x3): TS 6, F(4x4,5x5): TS 8).  A workgroup owns one channel of
+// 256/T consecutive images (T = tiles per plane: 16 for 16x16): thread = (image, tile), so the column
+// index n*T + tile is consecutive across the block -- every M read and V write is a contiguous 1-KB
+// row -- and the activated planes meet in LDS (zero halo of 2) where the overlapping windows of the
+// forward transform are cut out with 16-byte reads.  Nothing pointwise is left outside: a layer
+// x + conv2(ELU(conv1(ELU(x)) + b1)) + b2 is  GEMM, fused, GEMM, fused.
+// ------------------------------------------------------------------------------------------
+template <int TS_IN, int TS_OUT>
+__global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ src, const float* __restrict__ bias,
+                                                    const float* __restrict__ res, float* __restrict__ sum_out,
+                                                    float* __restrict__ act_out, float* __restrict__ V, int64_t N,
+                                                    int C, int H, int W, int act) {
+    constexpr int LW_PAD = 8;                       // halo 4 left (keeps the 16-byte row writes aligned) + 4 right
+    extern __shared__ float lds[];                  // [IMG][H+4][W+8], zero halo
+    const int ntx = W / 4, T = (H / 4) * ntx;       // tiles per plane, divides 256
+    const int IMG = 256 / T;
+    const int LW = W + LW_PAD, LP = (H + 4) * LW;   // padded row / plane size
+    const int tid = threadIdx.x;
+    const int img = tid / T, tile = tid - img * T;
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)blockIdx.y * IMG + img;
+    const int64_t ncols = N * T;
+    const int64_t col = n * T + tile;
+    const bool live = n < N;
+    if (TS_OUT) {
+        for (int k = tid; k < IMG * LP; k += 256) lds[k] = 0.0f;
+        __syncthreads();
+    }
+    float v[4][4];
+    const int64_t pbase = ((n * C + c) * (int64_t)H + ty * 4) * W + tx * 4;  // this tile in an [N,C,H,W] tensor
+    if (live) {
+        if (TS_IN == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 t = *reinterpret_cast<const float4*>(src + pbase + (int64_t)r * W);
+                v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+            }
+        } else {
+            constexpr int TI = TS_IN ? TS_IN : 6;
+            const float* m = src + (int64_t)c * ncols + col;
+            const int64_t tstride = (int64_t)C * ncols;
+            float t1[4][TI];  // A^T M (columns)
+#pragma unroll
+            for (int q = 0; q < TI; ++q) {
+                float colv[TI], y[4];
+#pragma unroll
+                for (int r = 0; r < TI; ++r) colv[r] = m[(int64_t)(r * TI + q) * tstride];
+                wino_at<TI, 4>(colv, y);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t1[r][q] = y[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wino_at<TI, 4>(t1[r], v[r]);
+        }
+        const float b = bias ? bias[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 rr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (res) rr = *reinterpret_cast<const float4*>(res + pbase + (int64_t)r * W);
+            v[r][0] = (v[r][0] + b) + rr.x; v[r][1] = (v[r][1] + b) + rr.y;   // same association as k_wino_out
+            v[r][2] = (v[r][2] + b) + rr.z; v[r][3] = (v[r][3] + b) + rr.w;
+            if (sum_out) *reinterpret_cast<float4*>(sum_out + pbase + (int64_t)r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[r][q] = elu1(v[r][q]);
+            }
+            if (act_out) *reinterpret_cast<float4*>(act_out + pbase + (int64_t)r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            if (TS_OUT)
+                *reinterpret_cast<float4*>(lds + img * LP + (ty * 4 + r + 2) * LW + tx * 4 + 4) =
+                    make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        }
+    }
+    if (TS_OUT) {
+        constexpr int TO = TS_OUT ? TS_OUT : 6;
+        constexpr int PAD = (TO - 4) / 2;
+        __syncthreads();
+        if (!live) return;
+        // window origin in halo coordinates: row ty*4 - PAD + 2, column tx*4 - PAD + 4
+        const float* wbase = lds + img * LP + (ty * 4 - PAD + 2) * LW + tx * 4 - PAD + 4;
+        float t1[TO][TO];  // B^T d, window read column by column
+#pragma unroll
+        for (int q = 0; q < TO; ++q) {
+            float colv[TO], o[TO];
+#pragma unroll
+            for (int r = 0; r < TO; ++r) colv[r] = wbase[r * LW + q];
+            wino_bt<TO>(colv, o);
+#pragma unroll
+            for (int r = 0; r < TO; ++r) t1[r][q] = o[r];
+        }
+        float* out = V + (int64_t)c * ncols + col;
+        const int64_t tstride = (int64_t)C * ncols;
+#pragma unroll
+        for (int r = 0; r < TO; ++r) {
+            float o[TO];
+            wino_bt<TO>(t1[r], o);
+#pragma unroll
+            for (int q = 0; q < TO; ++q) out[(int64_t)(r * TO + q) * tstride] = o[q];
+        }
+    }
+}
+
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int launch_rc() { return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -345,6 +452,38 @@ int bs_wino_out_f32(const float* M, const float* bias, const float* res, float* 
     else if (ms == 4) BS_WOUT(6, 4);
     else BS_WOUT(6, 2);
 #undef BS_WOUT
+    return launch_rc();
+}
+
+int bs_wino_fused_f32(const float* src, int ts_in, const float* bias, const float* res, int act, float* sum_out,
+                      float* act_out, float* V, int ts_out, int64_t N, int C, int H, int W, void* stream) {
+    const bool in_ok = ts_in == 0 || ts_in == 6 || ts_in == 8, out_ok = ts_out == 0 || ts_out == 6 || ts_out == 8;
+    if (!src || !in_ok || !out_ok || (ts_out ? !V : (!sum_out && !act_out)) || N < 0 || C < 1 || H < 4 || W < 4 ||
+        H % 4 || W % 4)
+        return BS_EINVAL;
+    const int T = (H / 4) * (W / 4);
+    if (T > 256 || 256 % T) return BS_EUNSUPPORTED;  // tiles per plane must divide the block
+    if (!aligned16(src) || (res && !aligned16(res)) || (sum_out && !aligned16(sum_out)) || (act_out && !aligned16(act_out)))
+        return BS_EINVAL;
+    if (N == 0) return BS_OK;
+    const int IMG = 256 / T;
+    dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
+    const size_t shm = ts_out ? (size_t)IMG * (H + 4) * (W + 8) * sizeof(float) : 0;
+#define BS_WF(TI, TO)                                                                                             \
+    hipLaunchKernelGGL((k_wino_fused<TI, TO>), grid, block, shm, S(stream), src, bias, res, sum_out, act_out, V, N, C, H, \
+                       W, act)
+    switch (ts_in * 10 + ts_out) {
+        case 6: BS_WF(0, 6); break;
+        case 8: BS_WF(0, 8); break;
+        case 60: BS_WF(6, 0); break;
+        case 66: BS_WF(6, 6); break;
+        case 68: BS_WF(6, 8); break;
+        case 80: BS_WF(8, 0); break;
+        case 86: BS_WF(8, 6); break;
+        case 88: BS_WF(8, 8); break;
+        default: return BS_EINVAL;  // 0 -> 0 is bs_bias_residual_elu_f32
+    }
+#undef BS_WF
     return launch_rc();
 }
 

@@ -19,7 +19,7 @@ LAYOUT_LINEAR, LAYOUT_WAVE = 0, 1
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres",
-    "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32",
+    "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
@@ -64,6 +64,7 @@ def load():
     L.bs_bias_residual_elu_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     L.bs_head_params_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, p]
     L.bs_expand_rows5_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, p]
+    L.bs_wino_fused_f32.argtypes = [p, i32, p, p, i32, p, p, p, i32, i64, i32, i32, i32, p]
     L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     for n in SYMBOLS:
@@ -394,3 +395,21 @@ def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, cfg=(
     _check(load().bs_wino_out_f32(_ptr(M), _ptr(bias), _ptr(res), _ptr(s_out), _ptr(a_out), N, Cc, H, W, ts, ms,
                                   _stream()), "bs_wino_out_f32")
     return s_out, a_out
+
+
+def wino_fused(src, shape, ts_in=0, bias=None, res=None, act=True, want_sum=False, want_act=False, ts_out=0):
+    """One pass between two Winograd-domain GEMMs (include/bitswap_hip.h, bs_wino_fused_f32).
+    src: x [N,C,H,W] (ts_in = 0) or M [ts_in^2, C, N*T]; shape = (N,C,H,W).
+    -> (sum | None, act | None, V | None)."""
+    _need_cuda(src, bias, res)
+    N, Cc, H, W = shape
+    T = (H // 4) * (W // 4)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    assert tuple(src.shape) == (tuple(shape) if ts_in == 0 else (ts_in * ts_in, Cc, N * T))
+    assert res is None or (res.is_contiguous() and tuple(res.shape) == tuple(shape) and res.dtype == torch.float32)
+    s_out = torch.empty(shape, dtype=torch.float32, device=src.device) if want_sum else None
+    a_out = torch.empty(shape, dtype=torch.float32, device=src.device) if want_act else None
+    V = torch.empty((ts_out * ts_out, Cc, N * T), dtype=torch.float32, device=src.device) if ts_out else None
+    _check(load().bs_wino_fused_f32(_ptr(src), ts_in, _ptr(bias), _ptr(res), 1 if act else 0, _ptr(s_out), _ptr(a_out),
+                                    _ptr(V), ts_out, N, Cc, H, W, _stream()), "bs_wino_fused_f32")
+    return s_out, a_out, V

@@ -305,19 +305,31 @@ class Model(nn.Module):
             h = hip.bias_residual_elu(c2, L.conv2.b, h, want_sum=True, want_act=False)[0]
 
     def _res_wino(self, layers, h):
-        """A ResNet block in the Winograd domain (bitswap_amd/winograd.py): per conv one input transform
-        (carrying the ELU and conv1's bias), ONE batched GEMM of 36 [C x C] x [C x tiles] products on
-        rocBLAS/hipBLASLt, one output transform (carrying bias, residual add and the next ELU).  2.25x (3x3) /
+        """A ResNet block in the Winograd domain (bitswap_amd/winograd.py): per conv ONE batched GEMM of 36 / 64
+        [C x C] x [C x tiles] products on rocBLAS/hipBLASLt, and between two GEMMs ONE fused pass
+        (k_wino_fused: inverse transform, bias, residual, ELU, forward transform of the next operand).  2.25x (3x3) /
         6.25x (5x5) fewer multiplications than the direct convolution, all of them on the MFMA units."""
         from . import hip
         ts = int(round(layers[0].conv1._wu.shape[0] ** 0.5))
-        cfg = (ts, ts - layers[0].conv1.kernel_size + 1)
+        shape = tuple(h.shape)
+        if ts - layers[0].conv1.kernel_size + 1 != 4:          # F(2x2,5x5) alternative: separate transforms
+            return self._res_wino_unfused(layers, h, (ts, ts - layers[0].conv1.kernel_size + 1))
+        v = hip.wino_fused(h, shape, 0, None, None, True, ts_out=ts)[2]                       # B^T ELU(h) B
+        for k, L in enumerate(layers):
+            v = hip.wino_fused(torch.bmm(L.conv1._wu, v), shape, ts, L.conv1.b, None, True, ts_out=ts)[2]
+            m2 = torch.bmm(L.conv2._wu, v)
+            if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
+                return hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, want_act=True)[1]
+            h, _, v = hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, want_sum=True, ts_out=ts)
+
+    def _res_wino_unfused(self, layers, h, cfg):
+        from . import hip
         shape = tuple(h.shape)
         for k, L in enumerate(layers):
             m1 = torch.bmm(L.conv1._wu, hip.wino_in(h, None, True, cfg))              # conv1(ELU(h))
             t = hip.wino_out(m1, shape, L.conv1.b, None, False, True, cfg)[1]         # ELU(. + b1)
             m2 = torch.bmm(L.conv2._wu, hip.wino_in(t, None, False, cfg))
-            if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
+            if k == len(layers) - 1:
                 return hip.wino_out(m2, shape, L.conv2.b, h, False, True, cfg)[1]
             h = hip.wino_out(m2, shape, L.conv2.b, h, True, False, cfg)[0]
 

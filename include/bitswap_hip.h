@@ -194,6 +194,13 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *          T = (H/ms)*(W/ms), column = n*T + tile;  act != 0 applies ELU;  bias nullable.
  *     out: s = A^T M A + bias[c] (+ res [N,C,H,W]) from M [ts*ts, C, N*T]; sum_out = s, act_out = ELU(s)
  *          (each nullable, at least one), both [N,C,H,W].
+ *
+ * bs_wino_fused_f32 -- everything between two batched GEMMs of a ResNet layer in one pass (tile stride 4:
+ *   ts 6 = F(4x4,3x3), ts 8 = F(4x4,5x5); H, W multiples of 4 with (H/4)*(W/4) dividing 256):
+ *     source: ts_in == 0 ? src = x [N,C,H,W] : src = M [ts_in^2, C, N*T] -> A^T M A
+ *     s = source + bias[c] (+ res);  sum_out = s;  a = act ? ELU(s) : s;  act_out = a   (outputs nullable)
+ *     ts_out != 0: V [ts_out^2, C, N*T] <- B^T a B   (the operand of the next GEMM)
+ *   A layer x + conv2(ELU(conv1(ELU(x)) + b1)) + b2 is: GEMM, fused(ts,ts), GEMM, fused(ts,ts | 0).
  */
 #define BS_HEAD_SIGMOID 0
 #define BS_HEAD_SOFTPLUS 1
@@ -203,6 +210,8 @@ int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scal
                        int HW, int mode, void* stream);
 int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W,
                         int act, void* stream);
+int bs_wino_fused_f32(const float* src, int ts_in, const float* bias, const float* res, int act, float* sum_out,
+                      float* act_out, float* V, int ts_out, int64_t N, int C, int H, int W, void* stream);
 int bs_wino_in_f32(const float* in, const float* bias, float* V, int64_t N, int C, int H, int W, int ts,
                    int ms, int act, void* stream);
 int bs_wino_out_f32(const float* M, const float* bias, const float* res, float* sum_out, float* act_out,

@@ -129,6 +129,16 @@ def test_winograd_convs_match_torch(ks, small):
     scale = float(want.abs().max())
     assert float((s.double() - want).abs().max()) < 3e-5 * scale
     assert float((act.double() - torch.nn.functional.elu(want)).abs().max()) < 3e-5 * scale
+    if not small:   # the fused pass (k_wino_fused) must give the same bits as the separate transforms
+        ts = ms[0]
+        _, _, v = hip.wino_fused(x, tuple(x.shape), 0, b_in, None, True, ts_out=ts)
+        assert torch.equal(v, hip.wino_in(x, b_in, True, ms))
+        s2, a2, v2 = hip.wino_fused(m, tuple(x.shape), ts, b_out, res, True, want_sum=True, want_act=True, ts_out=ts)
+        assert torch.equal(s2, s) and torch.equal(a2, act)
+        assert torch.equal(v2, hip.wino_in(act, None, False, ms))
+        n7 = x[:3].contiguous()   # a partial image block (3 of 16 images of the workgroup live)
+        assert torch.equal(hip.wino_fused(n7, tuple(n7.shape), 0, None, None, False, ts_out=ts)[2],
+                           hip.wino_in(n7, None, False, ms))
     # plain conv (no bias, no activation, no residual) and bitwise repeatability
     m2 = torch.bmm(U, hip.wino_in(x, None, False, ms))
     y, _ = hip.wino_out(m2, tuple(x.shape), None, None, True, False, ms)
