@@ -132,6 +132,13 @@ def _resblock(width, kernel_size, padding, nlayers, dropout_p, act):
     return blk
 
 
+class _WinoOperand:
+    """A block output that only exists as the Winograd operand V [36, C, N*T] of the 3x3 convs that follow."""
+
+    def __init__(self, v, shape):
+        self.v, self.shape = v, tuple(shape)
+
+
 class Model(nn.Module):
     def __init__(self, xs=(3, 32, 32), nz=1, zchannels=16, nprocessing=1, kernel_size=3, resdepth=2,
                  reswidth=256, dropout_p=0., tag='', root_process=True, conditional_gen_std=False, nn_batch=None):
@@ -150,7 +157,7 @@ class Model(nn.Module):
         # five row GEMMs, 3x3 on MIOpen) or "miopen"; below gemm_min_batch images MIOpen always runs them
         self.conv_algo = "winograd"
         self.gemm_min_batch = 24
-        self._heads = {}
+        self._heads, self._heads_u, self._gen_mu_u = {}, {}, None
         self.conditional_gen_std = conditional_gen_std
         pad5, pad = 2, (kernel_size - 1) // 2
         assert kernel_size % 2 == 1
@@ -206,7 +213,7 @@ class Model(nn.Module):
     # ----------------------------------------------------------------------------------------
     def load_state_dict(self, *a, **k):
         """New weights invalidate everything derived from the old ones: call fold()/fuse() again."""
-        self.fused, self._heads = False, {}
+        self.fused, self._heads, self._heads_u, self._gen_mu_u = False, {}, {}, None
         return super().load_state_dict(*a, **k)
 
     def compress(self, compress=True):
@@ -251,6 +258,11 @@ class Model(nn.Module):
                     self._heads[f"gen{i + 1}"] = stack(self.deepgen_mu[i], self.deepgen_std[i])
                 if not self.conditional_gen_std:
                     self._gen_scale = (((2. / 255.) / 8.) + softplus(self.gen_std)).contiguous()
+                # the head convs (3x3) in the Winograd domain as well: U [36, Cout, W]
+                from .winograd import transform_weights as _tw
+                self._heads_u = {k: _tw(w) for k, (w, b) in self._heads.items() if w.shape[-1] == 3}
+                g0 = self.gen_mu[0]
+                self._gen_mu_u = _tw(g0._w) if g0.kernel_size == 3 else None
                 # ResNet convs (3x3 and 5x5, Cin == Cout) in the Winograd domain: U = G w G^T, [36, Cout, Cin]
                 from .winograd import transform_weights
                 for m in self.modules():
@@ -304,7 +316,7 @@ class Model(nn.Module):
                 return hip.bias_residual_elu(c2, L.conv2.b, h)[1]
             h = hip.bias_residual_elu(c2, L.conv2.b, h, want_sum=True, want_act=False)[0]
 
-    def _res_wino(self, layers, h):
+    def _res_wino(self, layers, h, want_v=False):
         """A ResNet block in the Winograd domain (bitswap_amd/winograd.py): per conv ONE batched GEMM of 36 / 64
         [C x C] x [C x tiles] products on rocBLAS/hipBLASLt, and between two GEMMs ONE fused pass
         (k_wino_fused: inverse transform, bias, residual, ELU, forward transform of the next operand).  2.25x (3x3) /
@@ -319,6 +331,8 @@ class Model(nn.Module):
             v = hip.wino_fused(torch.bmm(L.conv1._wu, v), shape, ts, L.conv1.b, None, True, ts_out=ts)[2]
             m2 = torch.bmm(L.conv2._wu, v)
             if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
+                if want_v:                # ... and only as the operand of the 3x3 head convs
+                    return _WinoOperand(hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, ts_out=6)[2], shape)
                 return hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, want_act=True)[1]
             h, _, v = hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, want_sum=True, ts_out=ts)
 
@@ -333,16 +347,17 @@ class Model(nn.Module):
                 return hip.wino_out(m2, shape, L.conv2.b, h, False, True, cfg)[1]
             h = hip.wino_out(m2, shape, L.conv2.b, h, True, False, cfg)[0]
 
-    def _fused_res(self, seq, h):
+    def _fused_res(self, seq, h, want_v=False):
         """Sequential(ResNetBlock, act) on an activated input h (Pass: identity).  Per layer
-        x + conv2(act(conv1(act(x)))): two convs, two epilogue launches."""
+        x + conv2(act(conv1(act(x)))): two convs, two epilogue launches.  want_v: the caller only feeds 3x3
+        head convs with the result and accepts it as a Winograd operand (_WinoOperand) instead of NCHW."""
         from . import hip
         if isinstance(seq, Pass):
             return h
         layers = list(seq[0].children())
         if (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
                 and h.shape[-1] % 4 == 0 and h.shape[-2] % 4 == 0):
-            return self._res_wino(layers, h)
+            return self._res_wino(layers, h, want_v and layers[0].conv1._wu.shape[0] in (36, 64))
         if (self.conv_algo in ("winograd", "gemm5") and layers[0].conv1.kernel_size == 5
                 and h.shape[0] >= self.gemm_min_batch and h.shape[-1] % 4 == 0 and layers[0].conv1._w5 is not None):
             return self._res5_gemm(layers, h)
@@ -357,27 +372,38 @@ class Model(nn.Module):
     def _fused_head(self, key, h, mode):
         from . import hip
         w, b = self._heads[key]
+        if isinstance(h, _WinoOperand):     # head convs as one more batched GEMM on the operand the block left
+            x = hip.wino_fused(torch.bmm(self._heads_u[key], h.v), (h.shape[0], w.shape[0]) + h.shape[2:], 6, None,
+                               None, False, want_sum=True)[0]
+            return hip.head_params(x, b, mode)
         return hip.head_params(F.conv2d(h, w, None, stride=1, padding=(w.shape[-1] - 1) // 2), b, mode)
 
     def _infer_stack_fused(self, i, h):
         from . import hip
+        hv = f"infer{i}" in self._heads_u
         if i == 0:
-            h = self._fused_res(self.infer_res1, self._fused_res(self.infer_res0, self._fused_in(self.infer_in, h)))
+            h = self._fused_res(self.infer_res1, self._fused_res(self.infer_res0, self._fused_in(self.infer_in, h)), hv)
         else:
-            h = self._fused_res(self.deepinfer_res[i - 1], self._fused_in(self.deepinfer_in[i - 1], h))
+            h = self._fused_res(self.deepinfer_res[i - 1], self._fused_in(self.deepinfer_in[i - 1], h), hv)
         return self._fused_head(f"infer{i}", h, hip.HEAD_SIGMOID)
 
     def _gen_stack_fused(self, i, h):
         from . import hip
         if i == 0:
-            h = self._fused_res(self.gen_res0, self._fused_res(self.gen_res1, self._fused_in(self.gen_in, h)))
+            hv = self._gen_mu_u is not None and not self.conditional_gen_std
+            h = self._fused_res(self.gen_res0, self._fused_res(self.gen_res1, self._fused_in(self.gen_in, h)), hv)
+            if isinstance(h, _WinoOperand):
+                g0 = self.gen_mu[0]
+                x = hip.wino_fused(torch.bmm(self._gen_mu_u, h.v), (h.shape[0], g0.out_dim) + h.shape[2:], 6, g0.b,
+                                   None, False, want_sum=True)[0]
+                return self.gen_mu[1](x), self._gen_scale
             mu = self.gen_mu(h)
             if self.conditional_gen_std:
                 scale = ((2. / 255.) / 8.) + softplus(self.gen_std(h))
             else:
                 scale = self._gen_scale
             return mu, scale
-        h = self._fused_res(self.deepgen_res[i - 1], self._fused_in(self.deepgen_in[i - 1], h))
+        h = self._fused_res(self.deepgen_res[i - 1], self._fused_in(self.deepgen_in[i - 1], h), f"gen{i}" in self._heads_u)
         return self._fused_head(f"gen{i}", h, hip.HEAD_SOFTPLUS)
 
     def _use_fused(self, h):
