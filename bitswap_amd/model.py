@@ -132,6 +132,33 @@ def _resblock(width, kernel_size, padding, nlayers, dropout_p, act):
     return blk
 
 
+class _blas:
+    """Route torch's GEMMs to a BLAS backend for the duration of a block.  The Winograd-domain GEMMs
+    (batch 36/64 of [C x C] x [C x tiles]) run at 102-107 TFLOP/s on the composable_kernel backend where the
+    default heuristic picks a 60-76 TFLOP/s kernel for batch 36 (tools/gemm_probe3.py)."""
+
+    def __init__(self, name):
+        self.name, self.prev = name, None
+
+    def __enter__(self):
+        if self.name:
+            try:
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    self.prev = torch.backends.cuda.preferred_blas_library()
+                    torch.backends.cuda.preferred_blas_library(self.name)
+            except Exception:
+                self.prev = None
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.backends.cuda.preferred_blas_library(self.prev)
+
+
 class _WinoOperand:
     """A block output that only exists as the Winograd operand V [36, C, N*T] of the 3x3 convs that follow."""
 
@@ -157,6 +184,7 @@ class Model(nn.Module):
         # five row GEMMs, 3x3 on MIOpen) or "miopen"; below gemm_min_batch images MIOpen always runs them
         self.conv_algo = "winograd"
         self.gemm_min_batch = 24
+        self.gemm_backend = "ck"     # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs
         self._heads, self._heads_u, self._gen_mu_u = {}, {}, None
         self.conditional_gen_std = conditional_gen_std
         pad5, pad = 2, (kernel_size - 1) // 2
@@ -412,7 +440,8 @@ class Model(nn.Module):
     # the conv stacks proper, on a [n, C, H, W] float32 batch -------------------------------
     def _infer_stack(self, i, h):
         if self._use_fused(h):
-            return self._infer_stack_fused(i, h.contiguous())
+            with _blas(self.gemm_backend if self.conv_algo == "winograd" else None):
+                return self._infer_stack_fused(i, h.contiguous())
         if i == 0:
             h = self.infer_res1(self.infer_res0(self.infer_in(h)))
             mu = self.infer_mu(h)
@@ -425,7 +454,8 @@ class Model(nn.Module):
 
     def _gen_stack(self, i, h):
         if self._use_fused(h):
-            return self._gen_stack_fused(i, h.contiguous())
+            with _blas(self.gemm_backend if self.conv_algo == "winograd" else None):
+                return self._gen_stack_fused(i, h.contiguous())
         if i == 0:
             h = self.gen_res0(self.gen_res1(self.gen_in(h)))
             mu = self.gen_mu(h)
