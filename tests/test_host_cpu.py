@@ -223,3 +223,40 @@ def test_ragged_lock_step_equals_chains_coded_alone():
         assert torch.equal(out[k], chains[i])
     one = reference_init_state()
     assert state.to_lists() == [one] * 4
+
+
+@pytest.mark.parametrize("m,r", [(4, 3), (2, 5), (4, 5)])
+def test_winograd_matrices_and_conv_identity(m, r):
+    """bitswap_amd/winograd.py on the CPU: the Cook-Toom triple (A^T, G, B^T) satisfies the bilinear identity,
+    F(4,3) is the familiar Lavin-Gray set, and the whole transform-domain pipeline (V = B^T d B per tile, one
+    batched product with U = G w G^T, Y = A^T M A) equals F.conv2d in float64 to 1e-12."""
+    from bitswap_amd import winograd as W
+    pts = W.POINTS if m + r - 1 == 6 else W.POINTS8
+    AT, G, BT = W.cook_toom(m, r, pts)
+    n = m + r - 1
+    rng = np.random.RandomState(m * 10 + r)
+    d, g = rng.randn(n), rng.randn(r)
+    want = np.array([sum(d[o + k] * g[k] for k in range(r)) for o in range(m)])
+    assert np.abs(AT @ ((G @ g) * (BT @ d)) - want).max() < 1e-12
+    if (m, r) == (4, 3):
+        assert np.array_equal(BT[0], [4, 0, -5, 0, 1, 0]) and np.array_equal(AT[3], [0, 1, -1, 8, -8, 1])
+        assert np.allclose(G[1], [-1 / 6, -1 / 6, -1 / 6])
+    # 2-D convolution of a 16x16 image through the transform domain
+    torch.manual_seed(r)
+    C, N = 6, 3
+    x = torch.randn(N, C, 16, 16, dtype=torch.float64)
+    w = torch.randn(C, C, r, r, dtype=torch.float64)
+    cfg = (n, m)
+    U = W.transform_weights(w.float(), cfg).double()                       # [n*n, Cout, Cin] (float32 storage)
+    U64 = torch.einsum("ik,ockl,jl->ijoc", torch.from_numpy(G), w, torch.from_numpy(G)).reshape(n * n, C, C)
+    assert torch.allclose(U, U64, rtol=1e-6, atol=1e-6)
+    p, nt = r // 2, 16 // m
+    xp = torch.nn.functional.pad(x, (p, p + m, p, p + m))
+    BTt, ATt = torch.from_numpy(BT), torch.from_numpy(AT)
+    tiles = torch.stack([torch.stack([xp[:, :, ty * m: ty * m + n, tx * m: tx * m + n] for tx in range(nt)], 2)
+                         for ty in range(nt)], 2)                          # [N, C, nt, nt, n, n]
+    V = torch.einsum("ik,bctskl,jl->ijcbts", BTt, tiles, BTt).reshape(n * n, C, N * nt * nt)
+    M = torch.bmm(U64, V).reshape(n, n, C, N, nt, nt)
+    Y = torch.einsum("ik,klcbts,jl->bctisj", ATt, M, ATt).reshape(N, C, 16, 16)
+    ref = torch.nn.functional.conv2d(x, w, padding=p)
+    assert float((Y - ref).abs().max()) < 1e-10 * float(ref.abs().max()) + 1e-10
