@@ -132,6 +132,10 @@ class BitSwapCodec:
     def __init__(self, model, zendpoints, zcentres, quantbits=10, bitswap=True, ansbits=31, backend=None,
                  timeline=None):
         self.backend = backend if backend is not None else HipBackend(zendpoints.device)
+        # the decoder must reproduce the encoder's (mu, scale) bit for bit: MIOpen has to pick the same,
+        # deterministic algorithm on both sides (the reference sets the same flag, mnist_compress.py:98)
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
         self.model = model
         self.nz = model.nz
         self.q, self.K, self.bits = quantbits, 1 << quantbits, ansbits

@@ -255,3 +255,22 @@ def test_ragged_chains_on_gpu():
     for k, i in enumerate(order):
         assert torch.equal(out[k].cpu(), chains[i])
     assert state.to_lists() == [initial_states(1)[0]] * len(lens)
+
+
+def test_full_width_batch_invariance_of_a_chain():
+    """The crop/demo contract at full model width (reswidth 256, Winograd-domain GEMMs at nn_batch = 32): a chain
+    coded in a ragged batch of 40 has exactly the stream it gets when coded alone, i.e. an image compressed in a
+    batch decompresses on its own.  (Needs MIOpen pinned to deterministic algorithms: BitSwapCodec sets it.)"""
+    torch.backends.cudnn.deterministic = False      # the codec must not rely on the caller for this
+    model, zend, zcen = workload.build("imagenetcrop4", DEV, quantbits=10, nn_batch=32)
+    lens = [2, 1, 2] + [1] * 37
+    chains = [workload.synthetic_blocks(n, model.xs, seed=80 + i).to(torch.int32) for i, n in enumerate(lens)]
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
+    state, order, met = codec.compress_ragged(chains)
+    lists = state.to_lists()
+    for k in (0, 2, 17):
+        alone, _, _ = codec.compress_ragged([chains[order[k]]])
+        assert alone.to_lists()[0] == lists[k]
+    one = codec.new_states(1, 2, states=[lists[0]])
+    out = codec.decompress_ragged(one, [2])
+    assert torch.equal(out[0].cpu(), chains[order[0]])
