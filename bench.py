@@ -228,6 +228,8 @@ def main():
                                f" {'Bit-Swap' if args.bitswap else 'BB-ANS'}, batch of 32x32 blocks",
                    "chains_per_gpu": B, "chain_groups": args.groups, "blocks_per_chain": K, "quantbits": args.quantbits, "ansbits": 31,
                    "latent_dims": codec.Z, "pixel_dims": codec.X, "conv_dtype": "f32",
+                   "conv_path": (f"{model.conv_algo} (fp32; ResNet/head convs as transform-domain batched GEMMs, "
+                                 f"BLAS backend {model.gemm_backend})" if getattr(model, "fused", False) else "torch modules"),
                    "weights": "seeded random init (no checkpoints offline)"},
         "lossless": ok, "bits_per_dim": round(bpd, 4), "stream_time_fraction": breakdown,
         "roofline": roof, "cpu_baseline": cpu, "stream_gather": gather,
