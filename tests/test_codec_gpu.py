@@ -274,3 +274,17 @@ def test_full_width_batch_invariance_of_a_chain():
     one = codec.new_states(1, 2, states=[lists[0]])
     out = codec.decompress_ragged(one, [2])
     assert torch.equal(out[0].cpu(), chains[order[0]])
+
+
+def test_sender_and_receiver_in_separate_processes(tmp_path):
+    """The receiver is another process: everything the conv stacks compute (MIOpen algorithm choice, BLAS heuristics,
+    the Winograd-domain GEMMs at 26 blocks per call) must come out bit-identical there, or the streams do not decode."""
+    import subprocess, sys
+    from conftest import ROOT
+    import os
+    f = str(tmp_path / "streams.npz")
+    tool = os.path.join(ROOT, "tools", "xproc_codec.py")
+    enc = subprocess.run([sys.executable, tool, "enc", f], capture_output=True, text=True, timeout=300)
+    assert enc.returncode == 0 and "encoded" in enc.stdout, enc.stderr[-2000:]
+    dec = subprocess.run([sys.executable, tool, "dec", f], capture_output=True, text=True, timeout=300)
+    assert dec.returncode == 0 and "decoded ok" in dec.stdout, (dec.stdout + dec.stderr)[-2000:]
