@@ -1,5 +1,5 @@
-"""Hierarchical-VAE `Model` for the compression path (PyTorch-ROCm modules; convs run on
-MIOpen/hipBLASLt -- the only MFMA-shaped work on the path).
+"""Hierarchical-VAE `Model` for the compression path (PyTorch-ROCm modules; the convolutions -- the only
+MFMA-shaped work on the path -- run on MIOpen or, fused, as Winograd-domain batched GEMMs on rocBLAS/hipBLASLt/CK).
 
 Mirrors the class surface of the reference's Model (model/mnist_train.py:17-438; the cifar /
 imagenet variants are identical, imagenetcrop_train.py:306-315,417 makes gen_std a conv):
@@ -19,8 +19,10 @@ What is different, MI355X-first:
   * `fuse()`: on a HIP device in compress mode the pointwise work between the convolutions (bias,
     ELU, residual add, the scale heads) runs as ONE launch per convolution
     (bitswap_amd/csrc/net_epilogue.hip) and the mu/std head pair is a single convolution with
-    stacked filters.  Sender and receiver must both use it (or both not): the parameters differ
-    from the unfused path in the last float32 bits.
+    stacked filters.  From `gemm_min_batch` blocks per call on, the 3x3 / 5x5 ResNet and head convolutions
+    themselves run in the Winograd domain (`conv_algo = "winograd"`, bitswap_amd/winograd.py): HIP transform
+    kernels around one batched GEMM per convolution.  Sender and receiver must both use the same route: the
+    parameters differ from the unfused path in the last float32 bits.
 """
 import numpy as np
 import torch
