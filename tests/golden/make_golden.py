@@ -440,10 +440,15 @@ def make_rgb4_chain():
     out["cfg"] = np.array(cfg, dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "model_rgb4_small.npz"), **out)
     nblocks = 2
-    ops, sent, restbits, nets, cma = replay_chain(model, zend, zcen, images[:nblocks], nz, 1, quantbits, xdim, zdim,
-                                                  cap=30000)
+    for bitswap in (1, 0):
+        _rgb4_chain(model, zend, zcen, mins, maxs, images, cfg, nz, quantbits, xdim, zdim, nblocks, bitswap)
+
+
+def _rgb4_chain(model, zend, zcen, mins, maxs, images, cfg, nz, quantbits, xdim, zdim, nblocks, bitswap):
+    ops, sent, restbits, nets, cma = replay_chain(model, zend, zcen, images[:nblocks], nz, bitswap, quantbits, xdim,
+                                                  zdim, cap=30000)
     o = {
-        "cfg": np.array(cfg + [quantbits, 1, nblocks], dtype=np.int64),
+        "cfg": np.array(cfg + [quantbits, bitswap, nblocks], dtype=np.int64),
         "images": images[:nblocks],
         "z_top_endpoints": zend[nz - 1][0], "z_top_centres": zcen[nz - 1][0],
         "z_mins": mins, "z_maxs": maxs,
@@ -457,8 +462,9 @@ def make_rgb4_chain():
     }
     for i, p in enumerate(ops):
         o[f"op{i}_mu"], o[f"op{i}_scale"], o[f"op{i}_sym"] = p["mu"], p["scale"], p["sym"].astype(np.int16)
-    np.savez_compressed(os.path.join(OUT, "chain_rgb4_small_bitswap.npz"), **o)
-    print("chain_rgb4_small_bitswap.npz ops", len(ops), "words", len(sent), "cma", cma)
+    name = f"chain_rgb4_small_{'bitswap' if bitswap else 'bbans'}.npz"
+    np.savez_compressed(os.path.join(OUT, name), **o)
+    print(name, "ops", len(ops), "words", len(sent), "cma", cma)
 
 
 if __name__ == "__main__":

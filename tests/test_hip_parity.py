@@ -331,7 +331,8 @@ def test_ans_class_drop_in(golden):
         a.decode([3 << 32])
 
 
-@pytest.mark.parametrize("chain", ["chain_mnist_small_bitswap", "chain_mnist_small_bbans", "chain_rgb4_small_bitswap"])
+@pytest.mark.parametrize("chain", ["chain_mnist_small_bitswap", "chain_mnist_small_bbans", "chain_rgb4_small_bitswap",
+                                   "chain_rgb4_small_bbans"])
 def test_chain_replay_matches_reference_words(golden, chain):
     """Teacher-forced replay of the reference sender through the HIP kernels: same popped symbols,
     same per-operation state, same final word stream as the reference's Python run."""

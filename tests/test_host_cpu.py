@@ -103,7 +103,8 @@ def test_discretize_sampling_and_cache(tmp_path):
 
 @pytest.mark.parametrize("chain,model_file", [("chain_mnist_small_bitswap", "model_mnist_small"),
                                               ("chain_mnist_small_bbans", "model_mnist_small"),
-                                              ("chain_rgb4_small_bitswap", "model_rgb4_small")])
+                                              ("chain_rgb4_small_bitswap", "model_rgb4_small"),
+                                              ("chain_rgb4_small_bbans", "model_rgb4_small")])
 def test_codec_reproduces_reference_chain(golden, chain, model_file):
     """Our Model + our batched schedule + the oracle = the reference's own sender run
     (mnist_compress.py:164-263): identical word stream and bit accounting, then the receiver
