@@ -268,8 +268,9 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, c
 // ------------------------------------------------------------------------------------------
 // k_wino_fused<TS_IN, TS_OUT>: everything between two batched GEMMs of a ResNet layer in ONE pass.
 //   source   TS_IN == 0: x [N,C,H,W]              TS_IN in {6,8}: M [TS_IN^2, C, N*T] -> A^T M A
-//   s = source + bias[c] (+ res);  sum_out = s (nullable);  a = act ? ELU(s) : s;  act_out = a (nullable)
-//   target   TS_OUT in {6,8}: V [TS_OUT^2, C, N*T] <- B^T a B of the TS_OUT x TS_OUT windows (0 outside)
+//   s = source + bias[c] (+ res);  sum_out = s (nullable);  a = (act & 1) ? ELU(s) : s;  act_out = a (nullable)
+//   target   TS_OUT in {6,8}: V [TS_OUT^2, C, N*T] <- B^T a' B of the TS_OUT x TS_OUT windows (0 outside),
+//            a' = (act & 2) ? ELU(a) : a
 // Tile stride 4 on both sides (F(4x4,3x3): TS 6, F(4x4,5x5): TS 8).  A workgroup owns one channel of
 // 256/T consecutive images (T = tiles per plane: 16 for 16x16): thread = (image, tile), so the column
 // index n*T + tile is consecutive across the block -- every M read and V write is a contiguous 1-KB
@@ -333,11 +334,15 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
             v[r][0] = (v[r][0] + b) + rr.x; v[r][1] = (v[r][1] + b) + rr.y;   // same association as k_wino_out
             v[r][2] = (v[r][2] + b) + rr.z; v[r][3] = (v[r][3] + b) + rr.w;
             if (sum_out) *reinterpret_cast<float4*>(sum_out + pbase + (int64_t)r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
-            if (act) {
+            if (act & 1) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[r][q] = elu1(v[r][q]);
             }
             if (act_out) *reinterpret_cast<float4*>(act_out + pbase + (int64_t)r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            if (act & 2) {  // act_out is the residual stream of a block whose first conv sees ELU of it again
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[r][q] = elu1(v[r][q]);
+            }
             if (TS_OUT)
                 *reinterpret_cast<float4*>(lds + img * LP + (ty * 4 + r + 2) * LW + tx * 4 + 4) =
                     make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);

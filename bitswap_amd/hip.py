@@ -399,7 +399,8 @@ def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, cfg=(
 
 def wino_fused(src, shape, ts_in=0, bias=None, res=None, act=True, want_sum=False, want_act=False, ts_out=0):
     """One pass between two Winograd-domain GEMMs (include/bitswap_hip.h, bs_wino_fused_f32).
-    src: x [N,C,H,W] (ts_in = 0) or M [ts_in^2, C, N*T]; shape = (N,C,H,W).
+    src: x [N,C,H,W] (ts_in = 0) or M [ts_in^2, C, N*T]; shape = (N,C,H,W).  act: False/0, True/1 (ELU), or 3 (ELU for
+    act_out, ELU of that again for V).
     -> (sum | None, act | None, V | None)."""
     _need_cuda(src, bias, res)
     N, Cc, H, W = shape
@@ -410,6 +411,6 @@ def wino_fused(src, shape, ts_in=0, bias=None, res=None, act=True, want_sum=Fals
     s_out = torch.empty(shape, dtype=torch.float32, device=src.device) if want_sum else None
     a_out = torch.empty(shape, dtype=torch.float32, device=src.device) if want_act else None
     V = torch.empty((ts_out * ts_out, Cc, N * T), dtype=torch.float32, device=src.device) if ts_out else None
-    _check(load().bs_wino_fused_f32(_ptr(src), ts_in, _ptr(bias), _ptr(res), 1 if act else 0, _ptr(s_out), _ptr(a_out),
+    _check(load().bs_wino_fused_f32(_ptr(src), ts_in, _ptr(bias), _ptr(res), int(act), _ptr(s_out), _ptr(a_out),
                                     _ptr(V), ts_out, N, Cc, H, W, _stream()), "bs_wino_fused_f32")
     return s_out, a_out, V

@@ -161,6 +161,13 @@ class _blas:
                 torch.backends.cuda.preferred_blas_library(self.prev)
 
 
+class _RawConv:
+    """Output of an input convolution whose bias + ELU the next block's first fused pass will apply."""
+
+    def __init__(self, c, b):
+        self.c, self.b = c, b
+
+
 class _WinoOperand:
     """A block output that only exists as the Winograd operand V [36, C, N*T] of the 3x3 convs that follow."""
 
@@ -308,14 +315,23 @@ class Model(nn.Module):
     def _conv_nb(m, x):
         return F.conv2d(x, m._w, None, stride=m.stride, padding=m.padding)
 
-    def _fused_in(self, seq, x):
-        """Sequential([Squeeze2d,] WnConv2d, act) -> ELU(conv(x) + b), one epilogue launch."""
+    def _fused_in(self, seq, x, nxt=None):
+        """Sequential([Squeeze2d,] WnConv2d, act) -> ELU(conv(x) + b), one epilogue launch.  If the block `nxt`
+        that follows runs in the Winograd domain, bias and ELU are left to its first fused pass (_RawConv)."""
         from . import hip
         mods = list(seq.children())
         if isinstance(mods[0], Squeeze2d):
             x = mods[0](x).contiguous()
             mods = mods[1:]
-        return hip.bias_residual_elu(self._conv_nb(mods[0], x), mods[0].b)[1]
+        c = self._conv_nb(mods[0], x)
+        if nxt is not None and not isinstance(nxt, Pass) and self._wino_ok(list(nxt[0].children()), c):
+            return _RawConv(c, mods[0].b)
+        return hip.bias_residual_elu(c, mods[0].b)[1]
+
+    def _wino_ok(self, layers, h):
+        return (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
+                and h.shape[-1] % 4 == 0 and h.shape[-2] % 4 == 0
+                and int(round(layers[0].conv1._wu.shape[0] ** 0.5)) - layers[0].conv1.kernel_size + 1 == 4)
 
     @staticmethod
     def _conv5_gemm(m, ax):
@@ -353,10 +369,14 @@ class Model(nn.Module):
         6.25x (5x5) fewer multiplications than the direct convolution, all of them on the MFMA units."""
         from . import hip
         ts = int(round(layers[0].conv1._wu.shape[0] ** 0.5))
-        shape = tuple(h.shape)
-        if ts - layers[0].conv1.kernel_size + 1 != 4:          # F(2x2,5x5) alternative: separate transforms
-            return self._res_wino_unfused(layers, h, (ts, ts - layers[0].conv1.kernel_size + 1))
-        v = hip.wino_fused(h, shape, 0, None, None, True, ts_out=ts)[2]                       # B^T ELU(h) B
+        if isinstance(h, _RawConv):     # the input conv's bias + ELU ride along: h = ELU(c + b), V = B^T ELU(h) B
+            shape = tuple(h.c.shape)
+            _, h, v = hip.wino_fused(h.c, shape, 0, h.b, None, 3, want_act=True, ts_out=ts)
+        else:
+            shape = tuple(h.shape)
+            if ts - layers[0].conv1.kernel_size + 1 != 4:          # F(2x2,5x5) alternative: separate transforms
+                return self._res_wino_unfused(layers, h, (ts, ts - layers[0].conv1.kernel_size + 1))
+            v = hip.wino_fused(h, shape, 0, None, None, True, ts_out=ts)[2]                   # B^T ELU(h) B
         for k, L in enumerate(layers):
             v = hip.wino_fused(torch.bmm(L.conv1._wu, v), shape, ts, L.conv1.b, None, True, ts_out=ts)[2]
             m2 = torch.bmm(L.conv2._wu, v)
@@ -385,6 +405,8 @@ class Model(nn.Module):
         if isinstance(seq, Pass):
             return h
         layers = list(seq[0].children())
+        if isinstance(h, _RawConv):
+            return self._res_wino(layers, h, want_v)
         if (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
                 and h.shape[-1] % 4 == 0 and h.shape[-2] % 4 == 0):
             return self._res_wino(layers, h, want_v and layers[0].conv1._wu.shape[0] in (36, 64))
@@ -412,16 +434,16 @@ class Model(nn.Module):
         from . import hip
         hv = f"infer{i}" in self._heads_u
         if i == 0:
-            h = self._fused_res(self.infer_res1, self._fused_res(self.infer_res0, self._fused_in(self.infer_in, h)), hv)
+            h = self._fused_res(self.infer_res1, self._fused_res(self.infer_res0, self._fused_in(self.infer_in, h, self.infer_res0)), hv)
         else:
-            h = self._fused_res(self.deepinfer_res[i - 1], self._fused_in(self.deepinfer_in[i - 1], h), hv)
+            h = self._fused_res(self.deepinfer_res[i - 1], self._fused_in(self.deepinfer_in[i - 1], h, self.deepinfer_res[i - 1]), hv)
         return self._fused_head(f"infer{i}", h, hip.HEAD_SIGMOID)
 
     def _gen_stack_fused(self, i, h):
         from . import hip
         if i == 0:
             hv = self._gen_mu_u is not None and not self.conditional_gen_std
-            h = self._fused_res(self.gen_res0, self._fused_res(self.gen_res1, self._fused_in(self.gen_in, h)), hv)
+            h = self._fused_res(self.gen_res0, self._fused_res(self.gen_res1, self._fused_in(self.gen_in, h, self.gen_res1)), hv)
             if isinstance(h, _WinoOperand):
                 g0 = self.gen_mu[0]
                 x = hip.wino_fused(torch.bmm(self._gen_mu_u, h.v), (h.shape[0], g0.out_dim) + h.shape[2:], 6, g0.b,
@@ -433,7 +455,8 @@ class Model(nn.Module):
             else:
                 scale = self._gen_scale
             return mu, scale
-        h = self._fused_res(self.deepgen_res[i - 1], self._fused_in(self.deepgen_in[i - 1], h), f"gen{i}" in self._heads_u)
+        h = self._fused_res(self.deepgen_res[i - 1], self._fused_in(self.deepgen_in[i - 1], h, self.deepgen_res[i - 1]),
+                            f"gen{i}" in self._heads_u)
         return self._fused_head(f"gen{i}", h, hip.HEAD_SOFTPLUS)
 
     def _use_fused(self, h):

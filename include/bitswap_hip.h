@@ -198,8 +198,8 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  * bs_wino_fused_f32 -- everything between two batched GEMMs of a ResNet layer in one pass (tile stride 4:
  *   ts 6 = F(4x4,3x3), ts 8 = F(4x4,5x5); H, W multiples of 4 with (H/4)*(W/4) dividing 256):
  *     source: ts_in == 0 ? src = x [N,C,H,W] : src = M [ts_in^2, C, N*T] -> A^T M A
- *     s = source + bias[c] (+ res);  sum_out = s;  a = act ? ELU(s) : s;  act_out = a   (outputs nullable)
- *     ts_out != 0: V [ts_out^2, C, N*T] <- B^T a B   (the operand of the next GEMM)
+ *     s = source + bias[c] (+ res);  sum_out = s;  a = (act & 1) ? ELU(s) : s;  act_out = a   (outputs nullable)
+ *     ts_out != 0: V [ts_out^2, C, N*T] <- B^T a' B, a' = (act & 2) ? ELU(a) : a   (the operand of the next GEMM)
  *   A layer x + conv2(ELU(conv1(ELU(x)) + b1)) + b2 is: GEMM, fused(ts,ts), GEMM, fused(ts,ts | 0).
  */
 #define BS_HEAD_SIGMOID 0
