@@ -4,7 +4,7 @@ This replaces the per-image Python loops of the reference's `compress()` functio
 (sender mnist_compress.py:164-263, receiver :277-358; Bit-Swap :176-205 / :293-319, BB-ANS
 :206-243 / :321-354, prior :245-251 / :284-291).  One "block step" codes one 32x32 block of every
 chain in lock-step: the conv stacks see a [B, ...] batch, the table kernels see B*D rows, the rANS
-kernels one chain per wavefront / lane.  Nothing in a step synchronises with the host; word counts
+kernels one chain per wavefront.  Nothing in a step synchronises with the host; word counts
 for the bit accounting are snapshotted on the device.
 
 The arithmetic back-end is an object with the interface of `HipBackend` below.  The product
