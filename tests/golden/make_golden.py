@@ -415,6 +415,31 @@ def make_model_and_chains():
     print("model_crop_small.npz")
 
 
+def make_bits_fixture():
+    """The reference ANS class at precisions other than its hard-coded 31 (`bits` is a constructor argument,
+    mnist_compress.py:14): tables and word streams at 16 / 24 / 28 bits, own file, own RNG."""
+    rng = np.random.RandomState(4321)
+    K, D, q = 256, 64, 8
+    pm = torch.from_numpy(rng.dirichlet(np.full(K, 0.3), size=D))
+    out = {"pmf_f64": pm.numpy(), "quantbits": np.int32(q)}
+    np.random.seed(77)
+    for bits in (16, 24, 28):
+        a = ANS(pm, bits=bits, quantbits=q)
+        out[f"b{bits}_f"] = a.pmfs.astype(np.uint32)
+        out[f"b{bits}_cdf"] = a.cdfs.astype(np.uint32)
+        st = init_state(300)
+        out[f"b{bits}_state0"] = words(st)
+        st, sym = a.decode(st)
+        out[f"b{bits}_pop_sym"] = sym.numpy().astype(np.int32)
+        out[f"b{bits}_state_after_pop"] = words(st)
+        fresh = torch.from_numpy(rng.randint(0, K, size=D))
+        st = a.encode(st, fresh)
+        out[f"b{bits}_push_sym"] = fresh.numpy().astype(np.int32)
+        out[f"b{bits}_state_after_push"] = words(st)
+    np.savez_compressed(os.path.join(OUT, "rans_bits.npz"), **out)
+    print("rans_bits.npz")
+
+
 def make_rgb4_chain():
     """A deeper, colour chain: xs = (3,32,32), nz = 4, Bit-Swap, 2 blocks -- pins the layer ordering for
     zi > 1 (mnist_compress.py:176-205) and the 3072-dim pixel op; written to its own files so that the
@@ -471,7 +496,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rgb4":
         make_rgb4_chain()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bits":
+        make_bits_fixture()
+        sys.exit(0)
     make_tables_and_rans()
     make_bins()
     make_model_and_chains()
     make_rgb4_chain()
+    make_bits_fixture()

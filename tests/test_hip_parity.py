@@ -278,6 +278,26 @@ def test_other_ans_precisions_vs_oracle(bits):
     assert st2.to_lists() == st.to_lists()
 
 
+@pytest.mark.parametrize("bits", [16, 24, 28])
+def test_other_precisions_vs_reference_fixture(golden, bits):
+    """HIP tables / pop / push at 16, 24, 28 bits against word streams produced by the reference's ANS class."""
+    h = hip()
+    g = golden("rans_bits.npz")
+    q, K = int(g["quantbits"]), g["pmf_f64"].shape[1]
+    f, cdf, st_rows = h.table_rows(dev(g["pmf_f64"]), bits, q, ld=h.aligned_ld(K))
+    assert int(st_rows.abs().max()) == 0
+    assert np.array_equal(u32(f), g[f"b{bits}_f"]) and np.array_equal(u32(cdf)[:, : K + 1], g[f"b{bits}_cdf"])
+    s0 = words_to_state(g[f"b{bits}_state0"])
+    st = h.RansState.from_lists([s0, s0], cap=len(s0) + 2 * cdf.shape[0] + 8, device=DEV)
+    sym, _ = h.rans_pop(st, cdf, K, bits=bits, B=2)
+    st.check()
+    assert np.array_equal(sym[1].cpu().numpy(), g[f"b{bits}_pop_sym"])
+    assert st.to_lists() == [words_to_state(g[f"b{bits}_state_after_pop"])] * 2
+    h.rans_push_table(st, cdf, dev(np.tile(g[f"b{bits}_push_sym"], (2, 1))), K, bits=bits)
+    st.check()
+    assert st.to_lists() == [words_to_state(g[f"b{bits}_state_after_push"])] * 2
+
+
 def test_status_codes():
     h = hip()
     K, D = 256, 300

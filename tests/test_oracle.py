@@ -101,3 +101,19 @@ def test_det_sigmoid_accuracy():
         ulp = abs(mp.mpf(float(y)) - exact) / mp.mpf(float(np.spacing(float(y)) or 5e-324))
         assert ulp <= 2.0, (x, y, float(ulp))
     assert np.all(np.diff(O.det_sigmoid(np.sort(t))) >= 0)  # monotone on this sample
+
+
+@pytest.mark.parametrize("bits", [16, 24, 28])
+def test_oracle_other_precisions_vs_reference(golden, bits):
+    """The reference ANS class takes `bits` as an argument (mnist_compress.py:14); the oracle's tables and
+    word streams at 16/24/28 bits equal the reference's."""
+    g = golden("rans_bits.npz")
+    q = int(g["quantbits"])
+    f, cdf, rc = O.tables(g["pmf_f64"], bits, q)
+    assert rc == O.OK and np.array_equal(f, g[f"b{bits}_f"]) and np.array_equal(cdf, g[f"b{bits}_cdf"])
+    st = O.Stack(words_to_state(g[f"b{bits}_state0"]))
+    sym, rc = O.pop(st, cdf, bits)
+    assert rc == O.OK and np.array_equal(sym, g[f"b{bits}_pop_sym"])
+    assert st.tolist() == words_to_state(g[f"b{bits}_state_after_pop"])
+    assert O.push(st, cdf, g[f"b{bits}_push_sym"], bits) == O.OK
+    assert st.tolist() == words_to_state(g[f"b{bits}_state_after_push"])
