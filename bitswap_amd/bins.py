@@ -31,6 +31,30 @@ def uniform_bins(mins, maxs, quantbits):
     return edges[:, 1:-1], (edges[:, :-1] + edges[:, 1:]) / 2
 
 
+def uniform_step(endpoints, tol_ulps=8.0):
+    """Bin width per row if every row of `endpoints` [D, K-1] (float64 tensor or array, rows may be expanded views)
+    is an arithmetic progression up to rounding -- what discretize_kbins(strategy='uniform') produces
+    (discretization.py:105-118) -- else None.  h = (e[K-2] - e[0]) / (K - 2), two IEEE float64 operations on the host,
+    so sender and receiver derive the same numbers from the same bins.  The rows qualify when no endpoint is further
+    than tol_ulps units in the last place (of the row's largest magnitude) from e[0] + j*h: the deterministic CDF
+    spec 2 (include/bitswap_hip.h) treats that distance as a first-order correction.
+    -> float64 numpy array [D] or None."""
+    e = endpoints.detach().cpu().numpy() if torch.is_tensor(endpoints) else np.asarray(endpoints)
+    e = e.astype(np.float64, copy=False)
+    if e.ndim != 2 or e.shape[1] < 3:
+        return None
+    n = e.shape[1] - 1
+    with np.errstate(all="ignore"):
+        h = (e[:, -1] - e[:, 0]) / np.float64(n)
+        if not (np.all(np.isfinite(h)) and np.all(h > 0)):
+            return None
+        ideal = e[:, :1] + np.arange(n + 1, dtype=np.float64)[None, :] * h[:, None]
+        ulp = np.spacing(np.maximum(np.abs(e[:, 0]), np.abs(e[:, -1])))
+        if not np.all(np.abs(e - ideal) <= tol_ulps * ulp[:, None]):
+            return None
+    return np.ascontiguousarray(h)
+
+
 def top_bins(zdim_flat, quantbits):
     """discretization.py:25-27 -- float32 zeros/ones on the CPU, like the reference."""
     zb = Bins(torch.zeros((1, 1, zdim_flat)), torch.ones((1, 1, zdim_flat)), quantbits)

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import container, dist, tiling, workload
-from .bins import discretize
+from .bins import discretize, _cache_names as _bins_cache_names
 from .codec import BitSwapCodec, initial_states
 from .model import elbo_bits, preset
 
@@ -73,7 +73,7 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
     """One (dataset, nz, quantbits, scheme) experiment set.  Returns dict of the metric arrays on
     rank 0 (None on other ranks)."""
     rank, world = dist.init()
-    dev = torch.device("cpu") if backend is not None else torch.device("cuda", gpu if world == 1 else rank % max(1, torch.cuda.device_count()))
+    dev = torch.device("cpu") if backend is not None else (torch.device("cuda", gpu) if world == 1 else dist.local_device())
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
     if verbose and rank == 0:
@@ -86,9 +86,15 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
         model = load_model(dataset, nz, dev, params, synthetic)
     images = load_images(dataset, data, synthetic or bool(small), model.xs, max(experiments * ndatapoints, 512))
     bins_data = images[: min(len(images), 4096)].view((-1,) + tuple(model.xs))
+    # the bins cache is written by rank 0 only; the other ranks wait and load it (no concurrent writers)
+    keep = not (synthetic or small)
+    if world > 1 and keep and rank != 0:
+        dist.barrier()
     zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, dataset, data=bins_data,
                             ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"),
-                            save=not (synthetic or small))
+                            save=keep and rank == 0)
+    if world > 1 and keep and rank == 0:
+        dist.barrier()
 
     # (experiments, ndatapoints) test images per experiment, without replacement (:133-137)
     idx_path = os.path.join(outdir, "bitstreams", dataset, "indices.npy")
@@ -100,6 +106,8 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
         if rank == 0:
             os.makedirs(os.path.dirname(idx_path), exist_ok=True)
             np.save(idx_path, randindices)
+    if world > 1:
+        dist.barrier()       # nobody may race ahead and find rank 0's half-written indices file on a later call
 
     mine = dist.shard_chains(experiments, world, rank)
     inits = initial_states(experiments, 10000, seed=100)        # experiment ei gets the ei-th draw (:158)
@@ -186,15 +194,28 @@ def crop_setup(gpu, nz=4, quantbits=10, synthetic=False, params=None, outdir="."
     images are coded next to it -- an image compressed in a lock-step batch of many can be decompressed
     on its own (demo_decompress.py) and vice versa.  32: enough columns for the Winograd-domain GEMM
     path (4.2 vs 2.3 Mpixel/s for 100 images on one GPU), 0.4 s to decode a single 80-block image."""
-    dev = torch.device("cpu") if backend is not None else torch.device("cuda", max(gpu, 0))
+    rank, world = dist.init() if backend is None else (0, 1)
+    if backend is not None:
+        dev = torch.device("cpu")
+    else:
+        # one process per GPU: under torchrun the device is this rank's LOCAL_RANK, not the --gpu flag; the HIP
+        # kernels are enqueued on the CURRENT device's stream, so it has to be selected before anything runs
+        dev = dist.local_device() if world > 1 else torch.device("cuda", max(gpu, 0))
+        torch.cuda.set_device(dev)
     if small:
         model = workload.synthetic_model("imagenetcrop", nz, dev, small=small, nn_batch=nn_batch)
     else:
         model = load_model("imagenetcrop", nz, dev, params, synthetic, nn_batch=nn_batch)
     data = workload.synthetic_blocks(512, model.xs, seed=100).view((-1,) + tuple(model.xs))
-    zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, "imagenetcrop", data=data,
-                            ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"),
-                            save=not (synthetic or small))
+    # bins fitted on synthetic blocks are never written under the reference's cache names (they would silently
+    # replace properly fitted bins of a real checkpoint); a real checkpoint needs its cached bins or real data
+    cache = os.path.join(outdir, "bins")
+    have = all(os.path.exists(f) for f in _bins_cache_names(cache, "imagenetcrop", nz, quantbits))
+    if not (synthetic or small or have):
+        raise FileNotFoundError(f"no cached bins under {cache} for imagenetcrop nz{nz}: fit them with "
+                                "bitswap_amd.bins.discretize(..., data=<training images>) or pass --synthetic")
+    zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, "imagenetcrop", data=data, ppb=2,
+                            cache_dir=cache, save=False)
     return model, zend, zcen, dev
 
 

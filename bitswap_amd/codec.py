@@ -45,13 +45,22 @@ class HipBackend:
         ld = hip.wave_ld(K) if self.table_layout(K) == hip.LAYOUT_WAVE else hip.aligned_ld(K)
         return torch.empty((B, D, ld), dtype=torch.int32, device=self.device)
 
-    def tables(self, endpoints, mu, scale, quantbits, bits, out=None):
+    def bin_step(self, endpoints):
+        """Per-row bin width on the device if the rows are uniform-width bins the CDF spec 2 kernels take
+        (K >= 256), else None (CDF spec 1)."""
+        from .bins import uniform_step
         K = endpoints.shape[1] + 1
-        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=self.table_layout(K))
+        h = uniform_step(endpoints) if K >= 256 else None
+        return None if h is None else torch.from_numpy(h).to(self.device)
 
-    def shared_table(self, endpoints, mu, scale, quantbits, bits):
+    def tables(self, endpoints, mu, scale, quantbits, bits, out=None, step=None, status=None):
+        K = endpoints.shape[1] + 1
+        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=self.table_layout(K),
+                                   step=step, status=status)
+
+    def shared_table(self, endpoints, mu, scale, quantbits, bits, step=None):
         """One table row set [D, ld] shared by every chain (the prior)."""
-        t = self.tables(endpoints, mu, scale, quantbits, bits)
+        t = self.tables(endpoints, mu, scale, quantbits, bits, step=step)
         p = t[0]
         p.bs_layout = t.bs_layout
         return p
@@ -59,8 +68,8 @@ class HipBackend:
     def pop(self, state, cdf, K, bits, centres=None):
         return hip.rans_pop(state, cdf, K, bits, centres=centres)
 
-    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits):
-        f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits)
+    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
+        f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits, step=step)
         hip.rans_push(state, f, c, bits)
 
     def push_table(self, state, cdf, sym, K, bits):
@@ -130,7 +139,7 @@ class BitSwapCodec:
     """
 
     def __init__(self, model, zendpoints, zcentres, quantbits=10, bitswap=True, ansbits=31, backend=None,
-                 timeline=None):
+                 timeline=None, cdf_spec=2):
         self.backend = backend if backend is not None else HipBackend(zendpoints.device)
         # the decoder must reproduce the encoder's (mu, scale) bit for bit: MIOpen has to pick the same,
         # deterministic algorithm on both sides (the reference sets the same flag, mnist_compress.py:98)
@@ -148,6 +157,16 @@ class BitSwapCodec:
         self.zcen = [zcentres[i].contiguous() for i in range(self.nz)]
         xb = ImageBins(torch.float64, dev, self.X)
         self.xend, self.xcen = xb.endpoints(), xb.centres()   # expanded views, row stride 0
+        # deterministic CDF specification per table (include/bitswap_hip.h): spec 2 on every set of uniform-width
+        # bins (all latent layers but the top one, and the pixels), spec 1 elsewhere.  The choice is a function of
+        # the bins alone, so a receiver built from the same bins makes the same one; cdf_spec=1 forces spec 1
+        # everywhere (streams written before spec 2 existed).
+        assert cdf_spec in (1, 2)
+        self.cdf_spec = cdf_spec
+        none = lambda e: None
+        stepper = getattr(self.backend, "bin_step", none) if cdf_spec == 2 else none
+        self.zstep = [stepper(e) for e in self.zend]
+        self.xstep = stepper(self.xend)
         self.tl = timeline or Timeline(False)
         self._cdf_bufs = {}
         # optional stream split (GroupedCodec): convs + table kernels on `bulk`, the serial rANS kernels
@@ -161,7 +180,8 @@ class BitSwapCodec:
         # the prior p(z_L) = Logistic(0,1) table does not depend on the image: build it once
         # (the reference rebuilds it for every image, mnist_compress.py:246-251)
         one = torch.ones((1, self.Z), dtype=torch.float32, device=dev)
-        self.prior_cdf = self.backend.shared_table(self.zend[-1], torch.zeros_like(one), one, self.q, self.bits)
+        self.prior_cdf = self.backend.shared_table(self.zend[-1], torch.zeros_like(one), one, self.q, self.bits,
+                                                     step=self.zstep[-1])
         model.compress(True)
 
     # ------------------------------------------------------------------------------------------
@@ -215,11 +235,11 @@ class BitSwapCodec:
                 if t is not None and t.is_cuda:
                     t.record_stream(stream)
 
-    def _pop_layer(self, state, endpoints, centres, mu, scale, quantbits, K, key):
+    def _pop_layer(self, state, endpoints, centres, mu, scale, quantbits, K, key, step=None):
         ts = self._tables_stream((mu, scale))
         with self._on(ts), self.tl.span("tables_" + key):
             cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
-                                      out=self._cdf(mu.shape[0], mu.shape[1], K))
+                                      out=self._cdf(mu.shape[0], mu.shape[1], K), step=step, status=state.status)
         self._serial_waits_bulk()
         with self._on(self.serial):
             with self.tl.span("pop_" + key):
@@ -237,14 +257,14 @@ class BitSwapCodec:
         if ml is not None:
             torch.minimum(ml, state.len.to(ml.device), out=ml)
 
-    def _push_layer(self, state, endpoints, mu, scale, sym, quantbits, key):
+    def _push_layer(self, state, endpoints, mu, scale, sym, quantbits, key, step=None):
         if self.serial is None:
             with self.tl.span("push_" + key):
-                self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits)
+                self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits, step=step)
             return
         ts = self._tables_stream((mu, scale, sym))
         with self._on(ts), self.tl.span("fc_" + key):
-            f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, self.bits, quantbits)
+            f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, self.bits, quantbits, step=step)
             self._share((f, c), self.serial)
         self._serial_waits_bulk()
         with self._on(self.serial), self.tl.span("push_" + key):
@@ -286,22 +306,22 @@ class BitSwapCodec:
             zsym = None
             for zi in range(nz):
                 mu, sc = self._net(m.infer(zi), given)
-                zsymtop, z = self._pop_layer(state, self.zend[zi], self.zcen[zi], mu, sc, self.q, self.K, "z")
+                zsymtop, z = self._pop_layer(state, self.zend[zi], self.zcen[zi], mu, sc, self.q, self.K, "z", self.zstep[zi])
                 if rest_len is not None and zi == 0:
                     self._snap(rest_len, state)
                 yield
                 mu, sc = self._net(m.generate(zi), z)
                 if zi == 0:
-                    self._push_layer(state, self.xend, mu, sc, x, 8, "x")
+                    self._push_layer(state, self.xend, mu, sc, x, 8, "x", self.xstep)
                 else:
-                    self._push_layer(state, self.zend[zi - 1], mu, sc, zsym, self.q, "z")
+                    self._push_layer(state, self.zend[zi - 1], mu, sc, zsym, self.q, "z", self.zstep[zi - 1])
                 yield
                 zsym, given = zsymtop, z
         else:
             syms, zs = [], []
             for zi in range(nz):
                 mu, sc = self._net(m.infer(zi), given)
-                s, z = self._pop_layer(state, self.zend[zi], self.zcen[zi], mu, sc, self.q, self.K, "z")
+                s, z = self._pop_layer(state, self.zend[zi], self.zcen[zi], mu, sc, self.q, self.K, "z", self.zstep[zi])
                 syms.append(s)
                 zs.append(z)
                 given = z
@@ -311,9 +331,9 @@ class BitSwapCodec:
             for zi in range(nz):
                 mu, sc = self._net(m.generate(zi), zs[zi])
                 if zi == 0:
-                    self._push_layer(state, self.xend, mu, sc, x, 8, "x")
+                    self._push_layer(state, self.xend, mu, sc, x, 8, "x", self.xstep)
                 else:
-                    self._push_layer(state, self.zend[zi - 1], mu, sc, syms[zi - 1], self.q, "z")
+                    self._push_layer(state, self.zend[zi - 1], mu, sc, syms[zi - 1], self.q, "z", self.zstep[zi - 1])
                 yield
             zsymtop = syms[-1]
         with self._on(self.serial), self.tl.span("push_prior"):
@@ -335,13 +355,13 @@ class BitSwapCodec:
             for zi in reversed(range(nz)):
                 mu, sc = self._net(m.generate(zi), z)
                 if zi == 0:
-                    sym, given = self._pop_layer(state, self.xend, self.xcen, mu, sc, 8, 256, "x")
+                    sym, given = self._pop_layer(state, self.xend, self.xcen, mu, sc, 8, 256, "x", self.xstep)
                 else:
                     sym, given = self._pop_layer(state, self.zend[zi - 1], self.zcen[zi - 1], mu, sc, self.q,
-                                                 self.K, "z")
+                                                 self.K, "z", self.zstep[zi - 1])
                 yield None
                 mu, sc = self._net(m.infer(zi), given)
-                self._push_layer(state, self.zend[zi], mu, sc, zsymtop, self.q, "z")
+                self._push_layer(state, self.zend[zi], mu, sc, zsymtop, self.q, "z", self.zstep[zi])
                 yield None
                 zsymtop, z = sym, given
             yield zsymtop
@@ -350,16 +370,16 @@ class BitSwapCodec:
         for zi in reversed(range(nz)):
             mu, sc = self._net(m.generate(zi), cens[-1])
             if zi == 0:
-                s, c = self._pop_layer(state, self.xend, self.xcen, mu, sc, 8, 256, "x")
+                s, c = self._pop_layer(state, self.xend, self.xcen, mu, sc, 8, 256, "x", self.xstep)
             else:
-                s, c = self._pop_layer(state, self.zend[zi - 1], self.zcen[zi - 1], mu, sc, self.q, self.K, "z")
+                s, c = self._pop_layer(state, self.zend[zi - 1], self.zcen[zi - 1], mu, sc, self.q, self.K, "z", self.zstep[zi - 1])
             syms.append(s)
             cens.append(c)
             yield None
         # syms = [z_L, ..., z_1, x]; push z_L .. z_1 back under q(z_i | z_{i-1} or x)
         for k, zi in enumerate(reversed(range(nz))):
             mu, sc = self._net(m.infer(zi), cens[k + 1])
-            self._push_layer(state, self.zend[zi], mu, sc, syms[k], self.q, "z")
+            self._push_layer(state, self.zend[zi], mu, sc, syms[k], self.q, "z", self.zstep[zi])
             yield None
         yield syms[-1]
 

@@ -59,6 +59,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double lane_shift_up_f64(double v) {
     // value of lane-1 (lane 0 receives garbage; caller overrides)
     return __shfl_up(v, 1, 64);
@@ -85,8 +92,8 @@ __device__ __forceinline__ double recip_1_to_huge(double x) {
     return fma(r, y, y);
 }
 
-__device__ __forceinline__ double det_sigmoid(double t) {
-    double a = -t;
+// exp(a) for the clamped argument: the exponential half of the deterministic sigmoid
+__device__ __forceinline__ double det_exp(double a) {
     a = fmin(fmax(a, -700.0), 700.0);
     const double kd = rint(a * 0x1.71547652b82fep+0);
     double r = fma(-kd, 0x1.62e42fee00000p-1, a);
@@ -103,9 +110,10 @@ __device__ __forceinline__ double det_sigmoid(double t) {
     p = fma(p, r, 0x1.0000000000011p-1);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    const double e = ldexp(p, (int)kd);
-    return recip_1_to_huge(1.0 + e);
+    return ldexp(p, (int)kd);
 }
+
+__device__ __forceinline__ double det_sigmoid(double t) { return recip_1_to_huge(1.0 + det_exp(-t)); }
 
 // ------------------------------------------------------------------------------------------
 // integer tail shared by the table kernels.  A lane holds t[i] = trunc(pmf * M) of NPL consecutive bins
@@ -177,8 +185,44 @@ __device__ __forceinline__ int wave_offset(int j) {
     return (((r >> 2) << 6) + l) * 4 + (r & 3);
 }
 
-template <int NPL, typename PT, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
+// UNI: BS_CDF_SPEC 2 for rows of uniform-width bins (bin width step[d]): one exponential per lane (the anchor
+// A = exp(-t) of its first bin) and one per row (the geometric factors Q_b = exp(-b*h/scale), b < NPL, computed by
+// lane b < NPL of every 16-lane row), then per bin 1 + E = fma(Q_b, A*(1 - eps), 1), eps = r_b / scale, where
+// r_b = e_b - (e_0 + b*h) ~ 1e-16 is how far the stored endpoint sits from the ideal progression (computed once per
+// wave: the registers that held the endpoints hold the residuals).  Q_b reaches every lane INSIDE the multiply-add
+// (v_fmac_f64 with DPP row_newbcast:b, the one DPP control CDNA offers for 64-bit operands), so a bin costs
+// 3 + 9 (correctly rounded reciprocal) + 3 (difference, scale, truncate) float64 issue slots instead of 35.
+// oracle/bitswap_oracle.c::det2_row_cdf is the C restatement.
+template <int B_>
+__device__ __forceinline__ double fma_rowbcast(double q, double u) {
+    // fma(q[lane b of this lane's 16-lane row], u, 1.0); s_nop: a DPP read needs 2 wait states after the VALU
+    // write of its source, which the compiler cannot see through inline asm
+    double d = 1.0;
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(q), "v"(u), "n"(B_));
+    return d;
+}
+template <int NPL, int I>
+__device__ __forceinline__ double one_plus_e(double qb, double u) {
+    if constexpr (NPL <= 16) return fma_rowbcast<I>(qb, u);
+    else return fma(readlane_f64(qb, I), u, 1.0);
+}
+template <int NPL, int I>
+__device__ __forceinline__ void uni_bins(const double (&e)[NPL], double rs, double A, double qb, double M, int lane,
+                                         double& prev, Bins<NPL>& bn) {
+    if constexpr (I < NPL) {
+        const double eps = e[I] * rs;
+        const double u = fma(-A, eps, A);
+        double c = recip_1_to_huge(one_plus_e<NPL, I>(qb, u));
+        if (I == NPL - 1 && lane == 63) c = 1.0;
+        bn.t[I] = trunc_u32((c - prev) * M);
+        prev = c;
+        uni_bins<NPL, I + 1>(e, rs, A, qb, M, lane, prev, bn);
+    }
+}
+
+template <int NPL, typename PT, int MODE, bool UNI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7, 8))) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
+                                                  const double* __restrict__ step,
                                                   const PT* __restrict__ mu, const PT* __restrict__ scale,
                                                   const int32_t* __restrict__ sym, int B, int D, int bits,
                                                   int quantbits, int nb, uint32_t* __restrict__ out0,
@@ -199,6 +243,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     for (int i = 0; i < NPL; ++i) e[i] = (lane * NPL + i < K - 1) ? er[i] : 0.0;
 
     const double M = (double)((1ll << bits) - (1ll << quantbits));
+    const double hstep = UNI ? step[d] : 0.0;
+    if (UNI) {
+#pragma unroll
+        for (int i = 1; i < NPL; ++i) e[i] = e[i] - fma((double)i, hstep, e[0]);   // residuals r_i; e[0] stays the anchor
+    }
     // (mu, scale) of the next chain are fetched while the current one is computed: the row is
     // wave-uniform, so these are scalar loads whose latency would otherwise sit in front of every row
     PT mu_n = mu[(int64_t)b0 * D + d], sc_n = scale[(int64_t)b0 * D + d];
@@ -206,20 +255,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         const int64_t row = (int64_t)b * D + d;
         const double m_ = (double)mu_n;
         const double rs = 1.0 / (double)sc_n;
+        // NaN / Inf / non-positive parameters (a broken checkpoint) would still produce a well-formed table of
+        // garbage: flag the chain instead (first error sticks; later launches skip it)
+        const bool okp = ((double)sc_n > 0.0) && (rs > 0.0) && (fabs(m_) < __builtin_huge_val());
         const int64_t nrow = (int64_t)min(b + 1, b1 - 1) * D + d;
         mu_n = mu[nrow];
         sc_n = scale[nrow];
 
         Bins<NPL> bn;
-        double c0 = det_sigmoid((e[0] - m_) * rs);
-        if (NPL == 1 && lane == 63) c0 = 1.0;
-        double prev = c0;
+        double c0, prev;
+        if (UNI) {
+            const double hr = hstep * rs;
+            const double qb = det_exp(-((double)(lane & (NPL - 1)) * hr));   // lane b < NPL: Q_b
+            const double ta = (e[0] - m_) * rs;
+            const double A = det_exp(-ta);
+            c0 = recip_1_to_huge(1.0 + A);
+            prev = c0;
+            uni_bins<NPL, 1>(e, rs, A, qb, M, lane, prev, bn);
+        } else {
+            c0 = det_sigmoid((e[0] - m_) * rs);
+            if (NPL == 1 && lane == 63) c0 = 1.0;
+            prev = c0;
 #pragma unroll
-        for (int i = 1; i < NPL; ++i) {
-            double c = det_sigmoid((e[i] - m_) * rs);
-            if (i == NPL - 1 && lane == 63) c = 1.0;
-            bn.t[i] = trunc_u32((c - prev) * M);
-            prev = c;
+            for (int i = 1; i < NPL; ++i) {
+                double c = det_sigmoid((e[i] - m_) * rs);
+                if (i == NPL - 1 && lane == 63) c = 1.0;
+                bn.t[i] = trunc_u32((c - prev) * M);
+                prev = c;
+            }
         }
         double below = lane_shift_up_f64(prev);
         // reference: pmf[0] = cdf[0] (no subtraction), mnist_compress.py:185
@@ -228,6 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
         bool bad;
         uint32_t c = bump_and_scan<NPL>(bn, lane, bits, bad);
+        if (status && (__ballot(bad) != 0ull || !okp) && lane == 0 && status[b] == BS_ST_OK) status[b] = BS_ST_BADTABLE;
 
         if (MODE == M_WAVE) {
             // wave-native rows for k_rans_pop_wave: the K entries permuted as wave_offset(), then 64 pivot
@@ -765,12 +829,6 @@ struct TableSource {  // cdf rows + symbols (drop-in ANS.encode, shared prior ta
     }
 };
 
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
 
 // serial part shared by both sources.  h / f through a float64 reciprocal: after the renormalisation
 // h < 2^(64-bits) * f, so q = h / f < 2^33; RN(h) * RN(1/f) is within 3 ulp of h / f (< 3e-6 absolute),
@@ -1041,7 +1099,7 @@ inline int launch_rc() { return hipGetLastError() == hipSuccess ? BS_OK : BS_ELA
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int NPL, typename PT>
-int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
+int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
                     const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0, uint32_t* out1,
                     int64_t ld, int32_t* status, hipStream_t st) {
     // chains per wavefront: amortise the endpoint fetch, but keep >= ~8 waves per SIMD in flight
@@ -1050,25 +1108,31 @@ int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const v
     dim3 grid((D + 3) / 4, (B + nb - 1) / nb), block(256);
     const PT* m = static_cast<const PT*>(mu);
     const PT* s = static_cast<const PT*>(scale);
-#define BS_LAUNCH(MODE)                                                                                          \
-    hipLaunchKernelGGL((k_logistic<NPL, PT, MODE>), grid, block, 0, st, endpoints, e_stride, m, s, sym, B, D, bits, \
-                       quantbits, nb, out0, out1, ld, status)
-    if (mode == M_WAVE && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR));
-    else if (mode == M_LINEAR_VEC && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_LINEAR_VEC : M_LINEAR));
-    else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE);
-    else BS_LAUNCH(M_LINEAR);
+#define BS_LAUNCH(MODE, UNI)                                                                                     \
+    hipLaunchKernelGGL((k_logistic<NPL, PT, MODE, UNI>), grid, block, 0, st, endpoints, e_stride, step, m, s, sym, B, D, \
+                       bits, quantbits, nb, out0, out1, ld, status)
+    if (step) {  // CDF spec 2 (uniform bins); host dispatch guarantees NPL >= 4
+        if (mode == M_WAVE) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR), (NPL >= 4));
+        else if (mode == M_LINEAR_VEC) BS_LAUNCH((NPL >= 4 ? M_LINEAR_VEC : M_LINEAR), (NPL >= 4));
+        else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, (NPL >= 4));
+        else BS_LAUNCH(M_LINEAR, (NPL >= 4));
+    } else if (mode == M_WAVE && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR), false);
+    else if (mode == M_LINEAR_VEC && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_LINEAR_VEC : M_LINEAR), false);
+    else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, false);
+    else BS_LAUNCH(M_LINEAR, false);
 #undef BS_LAUNCH
     return launch_rc();
 }
 
 template <typename PT>
-int dispatch_logistic(int K, int mode, const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
+int dispatch_logistic(int K, int mode, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
                       const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0, uint32_t* out1,
                       int64_t ld, int32_t* status, hipStream_t st) {
 #define BS_CASE(NPL)                                                                                             \
     case 64 * NPL:                                                                                               \
-        return launch_logistic<NPL, PT>(mode, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits, out0, \
+        return launch_logistic<NPL, PT>(mode, endpoints, e_stride, step, mu, scale, sym, B, D, bits, quantbits, out0, \
                                         out1, ld, status, st)
+    if (step && K < 256) return BS_EUNSUPPORTED;  // CDF spec 2 is defined for K >= 256 (groups of K/64 >= 4 bins)
     switch (K) {
         BS_CASE(1);
         BS_CASE(2);
@@ -1125,9 +1189,9 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
     return launch_rc();
 }
 
-int bs_logistic_tables(const double* endpoints, int64_t e_stride, const void* mu, const void* scale, int param_dtype,
-                       int B, int D, int K, int bits, int quantbits, uint32_t* cdf_out, int64_t ld, int layout,
-                       void* stream) {
+int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+                       const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits,
+                       uint32_t* cdf_out, int64_t ld, int layout, int32_t* status, void* stream) {
     if (!endpoints || !mu || !scale || !cdf_out || B < 0 || D < 0 || bits < 1 || bits > 31 || quantbits < 0 ||
         quantbits >= bits || e_stride < 0)
         return BS_EINVAL;
@@ -1143,26 +1207,26 @@ int bs_logistic_tables(const double* endpoints, int64_t e_stride, const void* mu
     }
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_logistic<float>(K, mode, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
-                                        cdf_out, nullptr, ld, nullptr, S(stream));
+        return dispatch_logistic<float>(K, mode, endpoints, e_stride, bin_step, mu, scale, nullptr, B, D, bits, quantbits,
+                                        cdf_out, nullptr, ld, status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_logistic<double>(K, mode, endpoints, e_stride, mu, scale, nullptr, B, D, bits, quantbits,
-                                         cdf_out, nullptr, ld, nullptr, S(stream));
+        return dispatch_logistic<double>(K, mode, endpoints, e_stride, bin_step, mu, scale, nullptr, B, D, bits, quantbits,
+                                         cdf_out, nullptr, ld, status, S(stream));
     return BS_EINVAL;
 }
 
-int bs_logistic_fc(const double* endpoints, int64_t e_stride, const void* mu, const void* scale, int param_dtype,
-                   const int32_t* sym, int B, int D, int K, int bits, int quantbits, uint32_t* f_out, uint32_t* c_out,
-                   int32_t* status, void* stream) {
+int bs_logistic_fc(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu, const void* scale,
+                   int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits, uint32_t* f_out,
+                   uint32_t* c_out, int32_t* status, void* stream) {
     if (!endpoints || !mu || !scale || !sym || !f_out || !c_out || !status || B < 0 || D < 0 || bits < 1 ||
         bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0)
         return BS_EINVAL;
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_logistic<float>(K, M_ENCODE, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
+        return dispatch_logistic<float>(K, M_ENCODE, endpoints, e_stride, bin_step, mu, scale, sym, B, D, bits, quantbits,
                                         f_out, c_out, 0, status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_logistic<double>(K, M_ENCODE, endpoints, e_stride, mu, scale, sym, B, D, bits, quantbits,
+        return dispatch_logistic<double>(K, M_ENCODE, endpoints, e_stride, bin_step, mu, scale, sym, B, D, bits, quantbits,
                                          f_out, c_out, 0, status, S(stream));
     return BS_EINVAL;
 }

@@ -20,7 +20,11 @@ def init(backend=None):
         return 0, 1
     if not td.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            # RCCL binds a communicator to the CURRENT device: select this rank's GPU before the first collective
+            torch.cuda.set_device(local_device())
+        td.init_process_group(backend)
     return td.get_rank(), td.get_world_size()
 
 
@@ -39,28 +43,45 @@ def shard_chains(nchains, world, rank, weights=None):
     return [c for c in range(nchains) if owner[c] == rank]
 
 
+def local_device():
+    """The HIP device of this rank: LOCAL_RANK (torchrun) modulo the visible device count.  One process per GPU."""
+    n = max(1, torch.cuda.device_count())
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) % n)
+
+
 def _device():
     return torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _max_over_ranks(n, dev):
+    """Largest per-rank count: LPT sharding (shard_chains(weights=...)) may give one rank far more chains
+    than ceil(nchains / world), so every gather buffer is sized by what the ranks actually hold."""
+    t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return int(t.item())
 
 
 def gather_streams(local, chain_ids, nchains, dst=0):
     """local: list of uint32 numpy arrays (one finished bitstream per owned chain, any lengths),
     chain_ids: their global chain indices.  Returns on `dst` a list of nchains arrays (None
-    elsewhere).  Two collectives: all_gather of the per-chain word counts, gather of the padded
-    payloads."""
+    elsewhere).  Collectives: max of the per-rank chain counts, all_gather of the per-chain word counts,
+    gather of the padded payloads.  Any sharding (round-robin or LPT) is accepted."""
+    assert len(local) == len(chain_ids)
     if not td.is_initialized() or td.get_world_size() == 1:
         out = [None] * nchains
         for c, a in zip(chain_ids, local):
             out[c] = np.asarray(a, dtype=np.uint32)
         return out
     world, rank, dev = td.get_world_size(), td.get_rank(), _device()
-    per = (nchains + world - 1) // world
-    meta = torch.full((per, 2), -1, dtype=torch.int64, device=dev)     # (chain id, words)
+    per = max(1, _max_over_ranks(len(chain_ids), dev))
+    meta = torch.full((per, 2), -1, dtype=torch.int64)     # (chain id, words)
     for k, (c, a) in enumerate(zip(chain_ids, local)):
-        meta[k, 0], meta[k, 1] = c, len(a)
+        meta[k, 0], meta[k, 1] = int(c), len(a)
+    meta = meta.to(dev)
     metas = [torch.empty_like(meta) for _ in range(world)]
     td.all_gather(metas, meta)
-    maxwords = max(int(m[:, 1].clamp(min=0).sum()) for m in metas)
+    metas = [m.cpu() for m in metas]
+    maxwords = max(1, max(int(m[:, 1].clamp(min=0).sum()) for m in metas))
     flat = np.zeros(maxwords, dtype=np.uint32)
     if local:
         cat = np.concatenate([np.asarray(a, dtype=np.uint32) for a in local])
@@ -74,12 +95,17 @@ def gather_streams(local, chain_ids, nchains, dst=0):
     for r in range(world):
         words = bufs[r].cpu().numpy().view(np.uint32)
         off = 0
-        for c, nwords in metas[r].cpu().tolist():
+        for c, nwords in metas[r].tolist():
             if c < 0:
                 continue
             out[c] = words[off: off + nwords].copy()
             off += nwords
     return out
+
+
+def barrier():
+    if td.is_initialized() and td.get_world_size() > 1:
+        td.barrier()
 
 
 def allreduce_sum(values):
@@ -92,28 +118,33 @@ def allreduce_sum(values):
 
 
 def gather_rows(local, chain_ids, nchains, dst=0):
-    """Gather per-chain float rows (metrics [n_local, ndatapoints]) to `dst` in chain order."""
+    """Gather per-chain float rows (metrics [n_local, width]) to `dst` in chain order.  A rank may own no chain."""
     local = np.asarray(local, dtype=np.float64)
+    if local.ndim == 1:
+        local = local.reshape(len(chain_ids), -1)
     if not td.is_initialized() or td.get_world_size() == 1:
-        out = np.zeros((nchains,) + local.shape[1:])
+        out = np.zeros((nchains, local.shape[1]))
         out[chain_ids] = local
         return out
     world, rank, dev = td.get_world_size(), td.get_rank(), _device()
-    per = (nchains + world - 1) // world
-    buf = torch.zeros((per,) + local.shape[1:], dtype=torch.float64, device=dev)
-    ids = torch.full((per,), -1, dtype=torch.int64, device=dev)
+    per = max(1, _max_over_ranks(len(chain_ids), dev))      # LPT shards are not bounded by ceil(nchains / world)
+    width = _max_over_ranks(local.shape[1], dev)            # a rank without chains does not know the row width
+    buf = torch.zeros((per, width), dtype=torch.float64)
+    ids = torch.full((per,), -1, dtype=torch.int64)
     if len(chain_ids):
-        buf[: len(chain_ids)] = torch.from_numpy(local).to(dev)
-        ids[: len(chain_ids)] = torch.tensor(chain_ids, device=dev)
+        buf[: len(chain_ids)] = torch.from_numpy(local)
+        ids[: len(chain_ids)] = torch.tensor([int(c) for c in chain_ids])
+    buf, ids = buf.to(dev), ids.to(dev)
     bufs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     idl = [torch.empty_like(ids) for _ in range(world)]
     td.all_gather(idl, ids)
     td.gather(buf, bufs, dst=dst)
     if rank != dst:
         return None
-    out = np.zeros((nchains,) + local.shape[1:])
+    out = np.zeros((nchains, width))
     for r in range(world):
+        rows = bufs[r].cpu().numpy()
         for k, c in enumerate(idl[r].cpu().tolist()):
             if c >= 0:
-                out[c] = bufs[r][k].cpu().numpy()
+                out[c] = rows[k]
     return out

@@ -10,7 +10,7 @@ import torch
 
 from . import build as _build
 
-ABI_VERSION = 2   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
+ABI_VERSION = 3   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
 PARAM_F32, PARAM_F64 = 0, 1
@@ -53,8 +53,8 @@ def load():
     L.bs_strerror.restype = C.c_char_p
     L.bs_strerror.argtypes = [i32]
     L.bs_table_rows_f64.argtypes = [p, i64, i32, i32, i32, p, p, i64, p, p]
-    L.bs_logistic_tables.argtypes = [p, i64, p, p, i32, i32, i32, i32, i32, i32, p, i64, i32, p]
-    L.bs_logistic_fc.argtypes = [p, i64, p, p, i32, p, i32, i32, i32, i32, i32, p, p, p, p]
+    L.bs_logistic_tables.argtypes = [p, i64, p, p, p, i32, i32, i32, i32, i32, i32, p, i64, i32, p, p]
+    L.bs_logistic_fc.argtypes = [p, i64, p, p, p, i32, p, i32, i32, i32, i32, i32, p, p, p, p]
     L.bs_rans_push.argtypes = [p, p, p, i64, p, p, i32, i32, i32, p, p]
     L.bs_rans_push_table.argtypes = [p, p, p, i64, p, i64, i64, i32, p, i32, i32, i32, i32, p, p]
     L.bs_rans_pop.argtypes = [p, p, p, i64, p, i64, i64, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
@@ -88,9 +88,17 @@ def _stream():
 
 
 def _need_cuda(*ts):
+    """Every tensor on the CURRENT HIP device: the C side launches on the current device's stream and never
+    calls hipSetDevice, so a tensor of another device would be touched by a kernel of the wrong GPU."""
+    cur = torch.cuda.current_device() if torch.cuda.is_available() else -1
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise BitswapHipError("bitswap_amd kernels need tensors on a HIP device (no CPU fallback)")
+        if t.device.index != cur:
+            raise BitswapHipError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: call "
+                                  "torch.cuda.set_device() first (one process per GPU)")
 
 
 def _ptr(t):
@@ -162,32 +170,45 @@ def table_rows(pmf, bits=31, quantbits=8, ld=None, want_f=True):
     return f, cdf, status
 
 
-def logistic_tables(endpoints, mu, scale, bits=31, quantbits=10, ld=None, out=None, layout=LAYOUT_LINEAR):
+def _step(step, D):
+    if step is None:
+        return None
+    if step.dtype != torch.float64 or tuple(step.shape) != (D,) or not step.is_contiguous():
+        raise BitswapHipError(f"bin_step must be a contiguous float64 [{D}] tensor")
+    return step
+
+
+def logistic_tables(endpoints, mu, scale, bits=31, quantbits=10, ld=None, out=None, layout=LAYOUT_LINEAR, step=None,
+                    status=None):
     """Fused CDF -> integer cdf rows.  endpoints [D,K-1] f64, mu/scale [B,D] -> cdf [B,D,ld] int32.
     layout=LAYOUT_WAVE writes the wave-native hand-off format (ld = K+64) that rans_pop searches
-    with two ballots; the returned tensor remembers its layout (`bs_layout`)."""
-    _need_cuda(endpoints, mu, scale)
+    with two ballots; the returned tensor remembers its layout (`bs_layout`).  step [D] f64 (bins.uniform_step)
+    selects CDF spec 2 for uniform-width bins; status [B] int32 receives BS_ST_BADTABLE for degenerate parameters."""
+    _need_cuda(endpoints, mu, scale, step, status)
     B, D = mu.shape
     K = endpoints.shape[1] + 1
     endpoints, es = _row_stride(endpoints, K - 1)
+    step = _step(step, D)
     mu, scale = mu.contiguous(), scale.contiguous()
     if out is not None:
         ld = out.shape[-1]
     ld = ld or (wave_ld(K) if layout == LAYOUT_WAVE else aligned_ld(K))
     if out is None:
         out = torch.empty((B, D, ld), dtype=torch.int32, device=mu.device)
-    _check(load().bs_logistic_tables(_ptr(endpoints), es, _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K, bits,
-                                     quantbits, _ptr(out), ld, layout, _stream()), "bs_logistic_tables")
+    _check(load().bs_logistic_tables(_ptr(endpoints), es, _ptr(step), _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K,
+                                     bits, quantbits, _ptr(out), ld, layout, _ptr(status), _stream()),
+           "bs_logistic_tables")
     out.bs_layout = layout
     return out
 
 
-def logistic_fc(endpoints, mu, scale, sym, status, bits=31, quantbits=10, out=None):
+def logistic_fc(endpoints, mu, scale, sym, status, bits=31, quantbits=10, out=None, step=None):
     """Fused CDF -> (f, c) of the given symbols.  sym [B,D] int32 -> f, c [B,D] int32."""
-    _need_cuda(endpoints, mu, scale, sym, status)
+    _need_cuda(endpoints, mu, scale, sym, status, step)
     B, D = mu.shape
     K = endpoints.shape[1] + 1
     endpoints, es = _row_stride(endpoints, K - 1)
+    step = _step(step, D)
     mu, scale = mu.contiguous(), scale.contiguous()
     sym = sym.contiguous()
     if sym.dtype != torch.int32:
@@ -197,8 +218,8 @@ def logistic_fc(endpoints, mu, scale, sym, status, bits=31, quantbits=10, out=No
         c = torch.empty((B, D), dtype=torch.int32, device=mu.device)
     else:
         f, c = out
-    _check(load().bs_logistic_fc(_ptr(endpoints), es, _ptr(mu), _ptr(scale), _param_dtype(mu), _ptr(sym), B, D, K,
-                                 bits, quantbits, _ptr(f), _ptr(c), _ptr(status), _stream()), "bs_logistic_fc")
+    _check(load().bs_logistic_fc(_ptr(endpoints), es, _ptr(step), _ptr(mu), _ptr(scale), _param_dtype(mu), _ptr(sym), B,
+                                 D, K, bits, quantbits, _ptr(f), _ptr(c), _ptr(status), _stream()), "bs_logistic_fc")
     return f, c
 
 

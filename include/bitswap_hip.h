@@ -38,11 +38,15 @@
 extern "C" {
 #endif
 
-/* 2: layout argument, BS_LAYOUT_WAVE pivot words, conv-stack epilogue entry points */
-#define BS_ABI_VERSION 2
-/* version of the deterministic logistic-CDF specification; streams written with
- * one CDF spec can only be decoded with the same one */
-#define BS_CDF_SPEC 1
+/* 2: layout argument, BS_LAYOUT_WAVE pivot words, conv-stack epilogue entry points
+ * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop */
+#define BS_ABI_VERSION 3
+/* highest version of the deterministic logistic-CDF specification this library implements;
+ * a stream written with one CDF spec can only be decoded with the same one.
+ *   spec 1: one float64 sigmoid per bin endpoint (bin_step == NULL); any bins.
+ *   spec 2: rows of UNIFORM-width bins (bin_step != NULL, K >= 256): one exponential per group of K/64 bins
+ *           and a geometric factor per bin; same endpoints, agrees with spec 1 to a few ulp of the cdf. */
+#define BS_CDF_SPEC 2
 
 #define BS_OK 0
 #define BS_EINVAL (-1)       /* bad argument (null pointer, negative size, ld < K+1 ...)   */
@@ -93,24 +97,31 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
  *              all equal, may pass e_stride = 0).
  *   mu, scale [B,D] of param_dtype (the reference's Model emits float32 and casts up,
  *              model/mnist_train.py:375-376; both are converted to f64 exactly).
+ *   bin_step:  NULL selects CDF spec 1.  Otherwise [D] doubles, the bin width h_d = (e[d][K-2] - e[d][0]) / (K-2)
+ *              of rows whose endpoints are an arithmetic progression up to rounding (every latent layer but
+ *              the top one: discretization.py:81-83,105-118) and selects CDF spec 2 (K >= 256).  The caller
+ *              decides from the bins alone, so sender and receiver agree.
  *   cdf_out [B,D,ld] in `layout` (BS_LAYOUT_LINEAR or BS_LAYOUT_WAVE).
+ *   status [B] (nullable) receives BS_ST_BADTABLE for a chain with a non-finite mu, a scale that is not a
+ *              positive finite number, or a row whose remnant drives a frequency below 1 (mnist_compress.py:46-47).
  * The CDF is evaluated in float64 by the deterministic routine of DESIGN.md (BS_CDF_SPEC);
  * it agrees with torch.sigmoid to a few ulp, everything after it is exact integer work.
  * K must be 64*n, n in {1,2,4,8,16,32}.
  */
-int bs_logistic_tables(const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
-                       int param_dtype, int B, int D, int K, int bits, int quantbits,
-                       uint32_t* cdf_out, int64_t ld, int layout, void* stream);
+int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+                       const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits,
+                       uint32_t* cdf_out, int64_t ld, int layout, int32_t* status, void* stream);
 
 /*
  * bs_logistic_fc -- same fused computation, "encode flavour": given the symbol of every
  * (chain, dim) emit only its frequency f and cumulative start c (what ANS.encode reads at
  * mnist_compress.py:51,55); no table is written.
- *   sym [B,D] int32; f_out, c_out [B,D] uint32; status [B] receives BS_ST_BADSYMBOL.
+ *   sym [B,D] int32; f_out, c_out [B,D] uint32; status [B] receives BS_ST_BADSYMBOL / BS_ST_BADTABLE.
+ *   bin_step as in bs_logistic_tables (must be the same choice on both sides of a stream).
  */
-int bs_logistic_fc(const double* endpoints, int64_t e_stride, const void* mu, const void* scale,
-                   int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits,
-                   uint32_t* f_out, uint32_t* c_out, int32_t* status, void* stream);
+int bs_logistic_fc(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+                   const void* scale, int param_dtype, const int32_t* sym, int B, int D, int K, int bits,
+                   int quantbits, uint32_t* f_out, uint32_t* c_out, int32_t* status, void* stream);
 
 /*
  * bs_rans_push -- ANS.encode (mnist_compress.py:49-56), B chains, symbols i = 0..D-1 in order:

@@ -15,11 +15,11 @@ from . import oracle as O
 class _Tables:
     """Lazy 'cdf rows' handle: the oracle rebuilds each row inside layer_pop/layer_push."""
 
-    def __init__(self, endpoints, mu, scale, quantbits, shared=False):
-        self.e, self.mu, self.scale, self.q, self.shared = endpoints, mu, scale, quantbits, shared
+    def __init__(self, endpoints, mu, scale, quantbits, shared=False, step=None):
+        self.e, self.mu, self.scale, self.q, self.shared, self.step = endpoints, mu, scale, quantbits, shared, step
 
     def __getitem__(self, i):
-        return _Tables(self.e, self.mu[i:i + 1], self.scale[i:i + 1], self.q, shared=True)
+        return _Tables(self.e, self.mu[i:i + 1], self.scale[i:i + 1], self.q, shared=True, step=self.step)
 
 
 class OracleState:
@@ -73,19 +73,31 @@ class OracleBackend:
     def table_buffer(self, B, D, K):
         return None
 
-    def shared_table(self, endpoints, mu, scale, quantbits, bits):
-        return self.tables(endpoints, mu, scale, quantbits, bits)[0]
+    def bin_step(self, endpoints):
+        """Same decision as HipBackend.bin_step (bitswap_amd.bins.uniform_step); only the deterministic mode has a
+        spec 2 -- the libm mode restates the reference formula and ignores it."""
+        from bitswap_amd.bins import uniform_step
+        if self.mode == O.MODE_LIBM or endpoints.shape[1] + 1 < 256:
+            return None
+        return uniform_step(endpoints)
 
-    def tables(self, endpoints, mu, scale, quantbits, bits, out=None):
+    def _mode(self, step):
+        return O.MODE_DET2 if (step is not None and self.mode != O.MODE_LIBM) else self.mode
+
+    def shared_table(self, endpoints, mu, scale, quantbits, bits, step=None):
+        return self.tables(endpoints, mu, scale, quantbits, bits, step=step)[0]
+
+    def tables(self, endpoints, mu, scale, quantbits, bits, out=None, step=None, status=None):
         return _Tables(self._np(endpoints).astype(np.float64), self._np(mu).astype(np.float64),
-                       self._np(scale).astype(np.float64), quantbits)
+                       self._np(scale).astype(np.float64), quantbits,
+                       step=None if step is None else self._np(step).astype(np.float64))
 
     def pop(self, state, t, K, bits, centres=None):
         def one(b):
             if state.rc[b]:
                 return np.zeros(t.e.shape[0], dtype=np.int32)
             i = 0 if t.shared else b
-            sym, rc = O.layer_pop(state.stacks[b], t.e, t.mu[i], t.scale[i], bits, t.q, self.mode)
+            sym, rc = O.layer_pop(state.stacks[b], t.e, t.mu[i], t.scale[i], bits, t.q, self._mode(t.step), t.step)
             state.rc[b] = rc
             if rc:
                 sym[:] = 0   # sticky failure (e.g. too few initial bits); reported by check()
@@ -94,13 +106,15 @@ class OracleBackend:
         z = self.centres(centres, sym) if centres is not None else None
         return sym, z
 
-    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits):
+    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
         e, mu, scale = self._np(endpoints).astype(np.float64), self._np(mu).astype(np.float64), self._np(scale).astype(np.float64)
         sym = self._np(sym).astype(np.int32)
+        step = None if step is None else self._np(step).astype(np.float64)
 
         def one(b):
             if not state.rc[b]:
-                state.rc[b] = O.layer_push(state.stacks[b], e, mu[b], scale[b], sym[b], bits, quantbits, self.mode)
+                state.rc[b] = O.layer_push(state.stacks[b], e, mu[b], scale[b], sym[b], bits, quantbits,
+                                           self._mode(step), step)
         self._map(one, state.B)
 
     def push_table(self, state, t, sym, K, bits):
@@ -109,7 +123,8 @@ class OracleBackend:
         def one(b):
             if not state.rc[b]:
                 i = 0 if t.shared else b
-                state.rc[b] = O.layer_push(state.stacks[b], t.e, t.mu[i], t.scale[i], sym[b], bits, t.q, self.mode)
+                state.rc[b] = O.layer_push(state.stacks[b], t.e, t.mu[i], t.scale[i], sym[b], bits, t.q,
+                                           self._mode(t.step), t.step)
         self._map(one, state.B)
 
     def centres(self, centres, sym):

@@ -66,6 +66,52 @@ double orc_det_sigmoid(double t) {
     return 1.0 / (1.0 + e);
 }
 
+/* exp part of the deterministic sigmoid: exp(a) for the clamped argument, same operations as above */
+static double det_exp(double a) {
+    a = fmin(fmax(a, -700.0), 700.0);
+    double kd = rint(a * DET_LOG2E);
+    double r = fma(-kd, DET_LN2_HI, a);
+    r = fma(-kd, DET_LN2_LO, r);
+    double p = DET_C[11];
+    for (int i = 10; i >= 0; --i) p = fma(p, r, DET_C[i]);
+    return p * det_pow2((int)kd);
+}
+
+/*
+ * BS_CDF_SPEC 2 (mode 2) -- the logistic CDF of one row of UNIFORM-width bins (every latent layer but the top
+ * one: discretization.py:81-83,105-118 -> numpy.linspace edges), evaluated at the same K-1 stored endpoints as
+ * utils/torch/rand.py:67-68 but with ONE exponential per group of N = K/64 consecutive bins instead of one per bin:
+ *   rs = 1/scale;  hr = h * rs                 (h = bin width of the row, supplied by the caller)
+ *   Q_b = exp(-(b * hr)),  b = 1..N-1          (the geometric factor between a group's anchor and its b-th bin)
+ *   anchor of group g (bin j0 = g*N):  t_a = (e[j0] - mu) * rs;  A = exp(-t_a);  E = A
+ *   bin j = j0 + b:  r = e[j] - fma(b, h, e[j0])   (how far the stored endpoint is from the ideal progression:
+ *                                                   a few 1e-16, independent of the chain)
+ *                    eps = r * rs;  u = fma(-A, eps, A)   ( = A (1 - eps) );   x = fma(Q_b, u, 1)   ( = 1 + E )
+ *   cdf_j = 1 / x                                 (anchor: x = 1 + A)
+ * exp() is det_exp above.  The argument of the exponential is t_a + b*hr + eps = (e[j] - mu)/scale up to three
+ * roundings of relative size 2^-53, so x - 1 equals exp(-t_j) to a few ulp: the integer tables agree with spec 1 /
+ * torch at the same sub-ppm level (tests/test_oracle.py::test_cdf_spec2_*).  Every operation is a single
+ * IEEE-754 binary64 operation; the HIP kernel (k_logistic, uniform flavour) performs the same ones.
+ */
+static void det2_row_cdf(const double* e, double h, double mu, double scale, int K, double* cdf /* K-1 */) {
+    const int N = K >= 64 ? K / 64 : 1;
+    const double rs = 1.0 / scale;
+    const double hr = h * rs;
+    double Q[64];
+    for (int b = 1; b < N && b < 64; ++b) Q[b] = det_exp(-((double)b * hr));
+    for (int j0 = 0; j0 < K - 1; j0 += N) {
+        const double ta = (e[j0] - mu) * rs;
+        const double A = det_exp(-ta);
+        cdf[j0] = 1.0 / (1.0 + A);
+        for (int b = 1; b < N && j0 + b < K - 1; ++b) {
+            const double r = e[j0 + b] - fma((double)b, h, e[j0]);
+            const double eps = r * rs;
+            const double u = fma(-A, eps, A);
+            cdf[j0 + b] = 1.0 / fma(Q[b], u, 1.0);
+        }
+    }
+}
+
 /* reference formula: torch.sigmoid((x - mu) / scale), utils/torch/rand.py:67-68 */
 static double ref_sigmoid(double x, double mu, double scale) {
     double t = (x - mu) / scale;
@@ -82,6 +128,18 @@ static double ref_sigmoid(double x, double mu, double scale) {
  *   mode 1: the deterministic spec of the HIP kernels:
  *           rs = 1/scale (correctly rounded), t = (e - mu) * rs, det sigmoid.
  */
+void orc_logistic_pmf2(const double* endpoints, const double* step, const double* mu, const double* scale,
+                       int64_t D, int K, double* pmf) {
+    double* c = (double*)malloc(sizeof(double) * (size_t)K);
+    for (int64_t d = 0; d < D; ++d) {
+        double* p = pmf + d * (int64_t)K;
+        det2_row_cdf(endpoints + d * (int64_t)(K - 1), step[d], mu[d], scale[d], K, c);
+        for (int j = 0; j < K - 1; ++j) p[j] = (j == 0) ? c[0] : c[j] - c[j - 1];
+        p[K - 1] = 1.0 - c[K - 2];
+    }
+    free(c);
+}
+
 void orc_logistic_pmf(const double* endpoints, const double* mu, const double* scale,
                       int64_t D, int K, int mode, double* pmf) {
     for (int64_t d = 0; d < D; ++d) {
@@ -230,12 +288,20 @@ int orc_pop(uint64_t* head, uint32_t* stack, int64_t* len,
  * three functions above (mnist_compress.py:183-188 / :198-203).
  */
 static void row_table(const double* e, double mu, double scale, int K, int bits, int quantbits,
-                      int mode, double* p, int64_t* f, uint32_t* c) {
+                      int mode, double h, double* p, int64_t* f, uint32_t* c) {
     double prev = 0.0, rs = 1.0 / scale;
-    for (int j = 0; j < K - 1; ++j) {
-        double v = mode ? orc_det_sigmoid((e[j] - mu) * rs) : ref_sigmoid(e[j], mu, scale);
-        p[j] = (j == 0) ? v : v - prev;
-        prev = v;
+    if (mode == 2) {   /* CDF spec 2: uniform bins of width h */
+        double* cd = (double*)malloc(sizeof(double) * (size_t)K);
+        det2_row_cdf(e, h, mu, scale, K, cd);
+        for (int j = 0; j < K - 1; ++j) p[j] = (j == 0) ? cd[0] : cd[j] - cd[j - 1];
+        prev = cd[K - 2];
+        free(cd);
+    } else {
+        for (int j = 0; j < K - 1; ++j) {
+            double v = mode ? orc_det_sigmoid((e[j] - mu) * rs) : ref_sigmoid(e[j], mu, scale);
+            p[j] = (j == 0) ? v : v - prev;
+            prev = v;
+        }
     }
     p[K - 1] = 1.0 - prev;
     const double mult = (double)(((int64_t)1 << bits) - ((int64_t)1 << quantbits));
@@ -252,15 +318,16 @@ static void row_table(const double* e, double mu, double scale, int K, int bits,
     for (int j = 0; j < K; ++j) { acc += f[j]; c[j + 1] = (uint32_t)acc; }
 }
 
+/* step: bin width per row, used by mode 2 only (may be NULL otherwise) */
 int orc_layer_pop(uint64_t* head, uint32_t* stack, int64_t* len,
                   const double* endpoints, const double* mu, const double* scale,
-                  int64_t D, int K, int bits, int quantbits, int mode, int32_t* sym_out) {
+                  int64_t D, int K, int bits, int quantbits, int mode, const double* step, int32_t* sym_out) {
     double* p = (double*)malloc(sizeof(double) * (size_t)K);
     int64_t* f = (int64_t*)malloc(sizeof(int64_t) * (size_t)K);
     uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(K + 1));
     int rc = ORC_OK;
     for (int64_t i = D - 1; i >= 0 && rc == ORC_OK; --i) {
-        row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, p, f, c);
+        row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, step ? step[i] : 0.0, p, f, c);
         rc = orc_pop(head, stack, len, c, 0, 1, K, bits, sym_out + i);
     }
     free(p); free(f); free(c);
@@ -269,17 +336,17 @@ int orc_layer_pop(uint64_t* head, uint32_t* stack, int64_t* len,
 
 int orc_layer_push(uint64_t* head, uint32_t* stack, int64_t* len, int64_t cap,
                    const double* endpoints, const double* mu, const double* scale,
-                   int64_t D, int K, int bits, int quantbits, int mode, const int32_t* sym) {
+                   int64_t D, int K, int bits, int quantbits, int mode, const double* step, const int32_t* sym) {
     double* p = (double*)malloc(sizeof(double) * (size_t)K);
     int64_t* f = (int64_t*)malloc(sizeof(int64_t) * (size_t)K);
     uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(K + 1));
     int rc = ORC_OK;
     for (int64_t i = 0; i < D && rc == ORC_OK; ++i) {
-        row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, p, f, c);
+        row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, step ? step[i] : 0.0, p, f, c);
         rc = orc_push(head, stack, len, cap, c, 0, 1, bits, sym + i);
     }
     free(p); free(f); free(c);
     return rc;
 }
 
-int orc_version(void) { return 1; }
+int orc_version(void) { return 2; }

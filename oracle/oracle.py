@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 OK, UNDERFLOW, OVERFLOW, BAD_TABLE = 0, 1, 2, 3
-MODE_LIBM, MODE_DET = 0, 1
+MODE_LIBM, MODE_DET, MODE_DET2 = 0, 1, 2   # reference formula / CDF spec 1 / CDF spec 2 (uniform bins)
 
 
 def build(force=False):
@@ -51,9 +51,11 @@ def lib():
         L.orc_pop.restype = i32
         L.orc_pop.argtypes = [p, p, p, p, i64, i64, i32, i32, p]
         L.orc_layer_pop.restype = i32
-        L.orc_layer_pop.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, p]
+        L.orc_layer_pop.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, p, p]
         L.orc_layer_push.restype = i32
-        L.orc_layer_push.argtypes = [p, p, p, i64, p, p, p, i64, i32, i32, i32, i32, p]
+        L.orc_layer_push.argtypes = [p, p, p, i64, p, p, p, i64, i32, i32, i32, i32, p, p]
+        L.orc_logistic_pmf2.restype = None
+        L.orc_logistic_pmf2.argtypes = [p, p, p, p, i64, i32, p]
         _lib = L
     return _lib
 
@@ -76,12 +78,23 @@ def det_sigmoid(t):
     return out
 
 
-def logistic_pmf(endpoints, mu, scale, mode=MODE_LIBM):
-    """endpoints [D,K-1], mu/scale [D] -> pmf [D,K] float64."""
+def bin_step(endpoints):
+    """Bin width per row of uniform-width bins, the `h` of CDF spec 2: (e[K-2] - e[0]) / (K - 2) in float64
+    (restates bitswap_amd.bins.uniform_step; two IEEE operations, identical everywhere)."""
+    e = _f64(endpoints)
+    return (e[:, -1] - e[:, 0]) / np.float64(e.shape[1] - 1)
+
+
+def logistic_pmf(endpoints, mu, scale, mode=MODE_LIBM, step=None):
+    """endpoints [D,K-1], mu/scale [D] -> pmf [D,K] float64.  mode MODE_DET2 needs step [D] (bin_step())."""
     e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
     D, Km1 = e.shape
     pmf = np.empty((D, Km1 + 1), dtype=np.float64)
-    lib().orc_logistic_pmf(_ptr(e), _ptr(mu), _ptr(scale), D, Km1 + 1, mode, _ptr(pmf))
+    if mode == MODE_DET2:
+        step = _f64(bin_step(e) if step is None else step)
+        lib().orc_logistic_pmf2(_ptr(e), _ptr(step), _ptr(mu), _ptr(scale), D, Km1 + 1, _ptr(pmf))
+    else:
+        lib().orc_logistic_pmf(_ptr(e), _ptr(mu), _ptr(scale), D, Km1 + 1, mode, _ptr(pmf))
     return pmf
 
 
@@ -146,19 +159,28 @@ def pop(st, cdf, bits=31):
     return sym, rc
 
 
-def layer_pop(st, endpoints, mu, scale, bits=31, quantbits=10, mode=MODE_DET):
+def _step_ptr(e, mode, step):
+    if mode != MODE_DET2:
+        return None, C.c_void_p(0)
+    step = _f64(bin_step(e) if step is None else step)
+    return step, _ptr(step)
+
+
+def layer_pop(st, endpoints, mu, scale, bits=31, quantbits=10, mode=MODE_DET, step=None):
     e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
     D, Km1 = e.shape
     sym = np.empty(D, dtype=np.int32)
+    step, sp = _step_ptr(e, mode, step)
     rc = lib().orc_layer_pop(_ptr(st.head), _ptr(st.stack), _ptr(st.len), _ptr(e), _ptr(mu), _ptr(scale),
-                             D, Km1 + 1, bits, quantbits, mode, _ptr(sym))
+                             D, Km1 + 1, bits, quantbits, mode, sp, _ptr(sym))
     return sym, rc
 
 
-def layer_push(st, endpoints, mu, scale, sym, bits=31, quantbits=10, mode=MODE_DET):
+def layer_push(st, endpoints, mu, scale, sym, bits=31, quantbits=10, mode=MODE_DET, step=None):
     e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
     sym = np.ascontiguousarray(sym, dtype=np.int32)
     D, Km1 = e.shape
     st.grow(D)
+    step, sp = _step_ptr(e, mode, step)
     return lib().orc_layer_push(_ptr(st.head), _ptr(st.stack), _ptr(st.len), st.cap, _ptr(e), _ptr(mu),
-                                _ptr(scale), D, Km1 + 1, bits, quantbits, mode, _ptr(sym))
+                                _ptr(scale), D, Km1 + 1, bits, quantbits, mode, sp, _ptr(sym))

@@ -62,3 +62,37 @@ def chain_tables(g):
     X = int(cfg[0]) * 1024
     xend = np.broadcast_to(((np.arange(1, 256) - 127.5) / 127.5 - 1. / 255.)[None], (X, 255))
     return zend, xend, zcen
+
+
+def linear_to_wave(cdf, K, bits=31, pad_rows_to=64):
+    """Reference-layout cdf rows [D, >=K+1] (ANS.cdfs, mnist_compress.py:39-40) -> BS_LAYOUT_WAVE rows [D', K+64]
+    following include/bitswap_hip.h (entry j at dword ((j/256)*64 + j%64)*4 + (j/64)%4, then the pivot words).
+    The wave pop kernel wants whole 64-row chunks: rows are appended (they are popped FIRST, rows go D-1..0) that
+    hold the one-symbol table f_0 = 2^bits, whose pop leaves head and stack untouched."""
+    cdf = np.asarray(cdf).astype(np.uint32)
+    D = cdf.shape[0]
+    Dp = (D + pad_rows_to - 1) // pad_rows_to * pad_rows_to
+    lin = np.full((Dp, K + 1), 1 << bits, dtype=np.uint32)
+    lin[:, 0] = 0
+    lin[:D] = cdf[:, : K + 1]
+    j = np.arange(K)
+    off = ((j // 256) * 64 + j % 64) * 4 + (j // 64) % 4
+    out = np.full((Dp, K + 64), 0xffffffff, dtype=np.uint32)
+    out[:, off] = lin[:, :K]
+    nr = K // 64
+    out[:, K: K + nr] = lin[:, 0:K:64]
+    out[:, K + nr] = 1 << bits
+    return out
+
+
+def load_golden_model(g, device="cpu", **kw):
+    """bitswap_amd Model with the weights of a reference-generated model fixture (tests/golden/model_*.npz)."""
+    import torch
+    from bitswap_amd.model import Model
+    cfg = g["cfg"]
+    m = Model(xs=(int(cfg[0]), 32, 32), nz=int(cfg[1]), zchannels=int(cfg[2]), nprocessing=int(cfg[3]),
+              kernel_size=int(cfg[4]), resdepth=int(cfg[5]), reswidth=int(cfg[6]), **kw)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    assert set(sd) == set(m.state_dict())          # identical state-dict keys as the reference Model
+    m.load_state_dict(sd)
+    return m.to(device).eval()

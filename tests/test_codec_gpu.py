@@ -7,7 +7,7 @@ import oracle as O
 from oracle.backend import OracleBackend
 from bitswap_amd import cli, container, tiling, workload
 from bitswap_amd.codec import BitSwapCodec, initial_states
-from conftest import reference_init_state
+from conftest import chain_tables, load_golden_model, reference_init_state, words_to_state
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -288,3 +288,122 @@ def test_sender_and_receiver_in_separate_processes(tmp_path):
     assert enc.returncode == 0 and "encoded" in enc.stdout, enc.stderr[-2000:]
     dec = subprocess.run([sys.executable, tool, "dec", f], capture_output=True, text=True, timeout=300)
     assert dec.returncode == 0 and "decoded ok" in dec.stdout, (dec.stdout + dec.stderr)[-2000:]
+
+
+class _Count:
+    """Count calls of a bitswap_amd.hip entry point for the duration of a block (is the Winograd route live?)."""
+
+    def __init__(self, name):
+        from bitswap_amd import hip
+        self.hip, self.name, self.n = hip, name, 0
+
+    def __enter__(self):
+        self.orig = getattr(self.hip, self.name)
+
+        def wrapped(*a, **k):
+            self.n += 1
+            return self.orig(*a, **k)
+        setattr(self.hip, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.hip, self.name, self.orig)
+
+
+@pytest.mark.parametrize("name,bitswap", [("cifar8", 1), ("imagenet4", 1), ("imagenet4", 0)])
+def test_full_width_oracle_word_parity(name, bitswap):
+    """BASELINE configs 2, 3 and 5 at FULL model width (reswidth 252 / 254, Z = 2048, X = 3072, K = 1024 / 256) with
+    enough chains per call (26 >= gemm_min_batch) that the conv stacks take the route the bench takes -- Winograd-domain
+    batched GEMMs -- and the production kernel pair (k_logistic wave layout, CDF spec 2 + k_rans_pop_wave +
+    systolic push): the oracle replays the schedule on the CPU with the GPU's conv outputs and must produce the very
+    same words (mnist_compress.py:176-251); then the GPU receiver returns the blocks and unwinds every chain."""
+    model, zend, zcen = workload.build(name, DEV, quantbits=10)
+    B, n = 26, 1
+    assert model.fused and model.conv_algo == "winograd" and B >= model.gemm_min_batch
+    images = workload.synthetic_blocks(B * n, model.xs, seed=17).view(B, n, -1).to(torch.int32)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap))
+    assert codec.cdf_spec == 2 and all(s is not None for s in codec.zstep[:-1]) and codec.zstep[-1] is None
+    from bitswap_amd import hip
+    assert codec.backend.table_layout(codec.K) == hip.LAYOUT_WAVE
+    rec, plain_net = record_nets(codec)
+    with _Count("wino_fused") as wf:
+        state, met = codec.compress(images.to(DEV))
+    assert wf.n > 0, "the Winograd-domain conv route was not taken"
+    sent = state.to_lists()
+
+    it = iter(rec)
+    oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=bool(bitswap),
+                      backend=OracleBackend(O.MODE_DET, threads=16))
+    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    ostate, omet = oc.compress(images)
+    assert ostate.to_lists() == sent
+    assert np.array_equal(omet["cma"], met["cma"]) and np.array_equal(omet["rest_len"], met["rest_len"])
+
+    codec._net = plain_net
+    out = codec.decompress(state, n)
+    assert torch.equal(out.cpu(), images)
+    assert state.to_lists() == initial_states(B)
+
+
+@pytest.mark.parametrize("name", ["cifar8", "imagenet4"])
+def test_full_width_winograd_matches_torch_modules(name):
+    """The conv route of the bench (fused epilogues + Winograd-domain batched GEMMs at full width, 26 blocks per
+    call) against the plain torch modules of the same Model (MIOpen direct convolutions, separate pointwise ops):
+    every infer(i) / generate(i) output within 5e-4 of the output range, bitwise repeatable."""
+    model, _, _ = workload.build(name, DEV, quantbits=6)
+    model.compress(True)
+    g = torch.Generator().manual_seed(1)
+    N = 26
+    worst = 0.0
+    with torch.no_grad(), _Count("wino_fused") as wf:
+        for i in range(model.nz):
+            x = (torch.randint(0, 256, (N, model.xdim), generator=g).float() - 127.5) / 127.5
+            zin = torch.randn((N, model.zdim_flat), generator=g)
+            for fn, inp in ((model.infer(i), (x if i == 0 else zin).to(DEV)), (model.generate(i), zin.to(DEV))):
+                model.fused = True
+                mu_f, sc_f = fn(inp)
+                mu_f2, sc_f2 = fn(inp)
+                model.fused = False
+                mu_t, sc_t = fn(inp)
+                model.fused = True
+                assert torch.equal(mu_f, mu_f2) and torch.equal(sc_f, sc_f2)
+                for a, b in ((mu_f, mu_t), (sc_f, sc_t.expand_as(sc_f))):
+                    rng = float(b.abs().max()) + 1e-6
+                    worst = max(worst, float((a - b).abs().max()) / rng)
+    assert wf.n > 0
+    print(f"full-width {name}: max |fused - torch| / range = {worst:.2e}")
+    assert worst < 5e-4, worst
+
+
+@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
+def test_gpu_bits_per_dim_matches_reference(golden, sched):
+    """north_star: bits/dim within 1e-4 of the reference.  The reference's own chain (model weights, bins, images and
+    bit accounting produced by the reference code, tests/golden/make_golden.py) coded UNTETHERED on the GPU: our Model
+    with fused epilogues and the Winograd-domain convs forced on (gemm_min_batch = 1), the production HIP kernels, CDF
+    spec 2.  cma (mnist_compress.py:253-261) must match to 1e-4 at every block, and so must the exact information
+    content of the final state (32 bits per stack word + log2 of the head) per dimension; the receiver is lossless."""
+    g = golden(f"chain_rgb4_small_{sched}.npz")
+    cfg = g["cfg"]
+    q, bitswap, nblocks = int(cfg[7]), bool(cfg[8]), int(cfg[9])
+    model = load_golden_model(golden("model_rgb4_small.npz"), DEV).fold().fuse()
+    model.gemm_min_batch = 1
+    zend, _, zcen = chain_tables(g)
+    codec = BitSwapCodec(model, torch.from_numpy(zend).to(DEV), torch.from_numpy(zcen).to(DEV), quantbits=q,
+                         bitswap=bitswap)
+    B = 3
+    imgs = torch.from_numpy(g["images"].astype(np.int32)).view(1, nblocks, -1).expand(B, -1, -1).contiguous()
+    init = [reference_init_state()] * B
+    with _Count("wino_fused") as wf:
+        state, met = codec.compress(imgs.to(DEV), state=codec.new_states(B, nblocks, states=init))
+    assert wf.n > 0
+    X = model.xdim
+    for b in range(B):
+        assert np.abs(met["cma"][b] - g["cma"]).max() <= 1e-4, (met["cma"][b], g["cma"])
+        assert np.abs(met["nets"][b] - g["nets"]).max() <= 1e-4
+    ref = words_to_state(g["sent_words"])
+    info_ref = 32 * (len(ref) - 1) + np.log2(float(ref[-1]))
+    for st in state.to_lists():
+        info = 32 * (len(st) - 1) + np.log2(float(st[-1]))
+        assert abs(info - info_ref) / (X * nblocks) <= 1e-4
+    out = codec.decompress(state, nblocks)
+    assert torch.equal(out.cpu(), imgs) and state.to_lists() == init

@@ -45,6 +45,42 @@ def _worker(rank, world, port, outdir):
     if rank == 0:
         assert np.array_equal(rows, np.array([[c, c * 2.0] for c in range(nch)]))
     assert dist.allreduce_sum([1.0, rank]) == [world, sum(range(world))]
+    # LPT sharding by block count (config 4, imagenetcrop_compress.py:279-300): one long chain pins rank 0, every
+    # short chain lands on rank 1 -- far more than ceil(nchains / world) -- and nothing may overflow or deadlock
+    nch = 9
+    weights = [100] + [1] * 8
+    mine = dist.shard_chains(nch, world, rank, weights=weights)
+    assert len(mine) == (1 if rank == 0 else 8)
+    local = [np.arange(5 + c, dtype=np.uint32) + 1000 * c for c in mine]
+    got = dist.gather_streams(local, mine, nch)
+    rows = dist.gather_rows(np.array([[c, weights[c]] for c in mine], dtype=np.float64), mine, nch)
+    if rank == 0:
+        for c in range(nch):
+            assert np.array_equal(got[c], np.arange(5 + c, dtype=np.uint32) + 1000 * c)
+        assert np.array_equal(rows, np.array([[c, weights[c]] for c in range(nch)], dtype=np.float64))
+    # a rank that owns nothing at all
+    mine0 = [0, 1, 2] if rank == 1 else []
+    got = dist.gather_streams([np.full(4, c, dtype=np.uint32) for c in mine0], mine0, 3)
+    rows = dist.gather_rows(np.array([[c] for c in mine0], dtype=np.float64).reshape(len(mine0), 1), mine0, 3)
+    if rank == 0:
+        assert [a.tolist() for a in got] == [[c] * 4 for c in range(3)] and rows[:, 0].tolist() == [0.0, 1.0, 2.0]
+    # the crop driver's sender with ragged chains, LPT-sharded: every image is coded by exactly one rank and the
+    # gathered bits/dim are those of a single-process run with the same nn_batch (batch-invariant convs)
+    from bitswap_amd import tiling
+    ob = OracleBackend(O.MODE_DET)
+    setup = cli.crop_setup(-1, nz=2, quantbits=6, backend=ob, small=8, nn_batch=2)
+    rng = np.random.RandomState(5)
+    blocks = [tiling.extract_blocks(rng.randint(0, 256, (32 * a, 32 * b, 3)).astype(np.uint8))[0]
+              for a, b in ((3, 2), (1, 1), (1, 2), (1, 1))]
+    w = [len(b) for b in blocks]
+    mine = dist.shard_chains(len(blocks), world, rank, weights=w)
+    assert mine == ([0] if rank == 0 else [1, 2, 3])
+    res = cli.compress_images([blocks[i] for i in mine], quantbits=6, nz=2, setup=setup, backend=ob)
+    bpd = dist.gather_rows(np.array([[r[2]] for r in res]), mine, len(blocks))
+    words = dist.gather_streams([np.array(r[0][:-1], dtype=np.uint32) for r in res], mine, len(blocks))
+    if rank == 0:
+        np.save(os.path.join(outdir, "crop_bpd_world2.npy"), bpd[:, 0])
+        np.save(os.path.join(outdir, "crop_words_world2.npy"), np.array([len(a) for a in words]))
     # the full experiment driver, sharded
     res = cli.compress(6, 2, 1, 0, dataset="mnist", experiments=4, ndatapoints=2, decompress=True,
                        outdir=outdir, backend=OracleBackend(O.MODE_DET), small=8, verbose=False)
@@ -81,3 +117,13 @@ def test_two_rank_gather_and_sharded_experiment(tmp_path):
     # identical across shardings; the bit rates must agree closely and every chain must be present
     assert two.shape == one["cmas"].shape and np.all(two > 0)
     assert np.abs(two - one["cmas"]).max() < 0.5
+    # ragged crop chains: with nn_batch the streams do not depend on the sharding at all
+    from bitswap_amd import tiling
+    ob = OracleBackend(O.MODE_DET)
+    setup = cli.crop_setup(-1, nz=2, quantbits=6, backend=ob, small=8, nn_batch=2)
+    rng = np.random.RandomState(5)
+    blocks = [tiling.extract_blocks(rng.randint(0, 256, (32 * a, 32 * b, 3)).astype(np.uint8))[0]
+              for a, b in ((3, 2), (1, 1), (1, 2), (1, 1))]
+    res = cli.compress_images(blocks, quantbits=6, nz=2, setup=setup, backend=ob)
+    assert np.array_equal(np.load(tmp_path / "crop_bpd_world2.npy"), np.array([r[2] for r in res]))
+    assert np.load(tmp_path / "crop_words_world2.npy").tolist() == [len(r[0]) - 1 for r in res]

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle as O
-from conftest import chain_tables, reference_init_state, words_to_state
+from conftest import chain_tables, linear_to_wave, reference_init_state, words_to_state
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -141,29 +141,52 @@ def test_logistic_fc_matches_tables(K):
     assert status.cpu().tolist() == [0, 0, hip().ST_BADSYMBOL, 0, 0, 0]
 
 
+def wave_table(h, rows, K, bits=31):
+    """Reference cdf rows as a BS_LAYOUT_WAVE device tensor (whole 64-row chunks, identity rows appended)."""
+    t = dev(linear_to_wave(rows, K, bits).view(np.int32))
+    t.bs_layout = h.LAYOUT_WAVE
+    return t
+
+
 @pytest.mark.parametrize("name", ["ztop", "zuni", "x"])
-@pytest.mark.parametrize("aligned", [False, True])
-def test_rans_words_bit_exact_vs_reference(golden, name, aligned):
+@pytest.mark.parametrize("form", ["linear", "aligned", "wave"])
+def test_rans_words_bit_exact_vs_reference(golden, name, form):
+    """ANS.decode / ANS.encode word streams of the reference against every table form the kernels take: the
+    reference's rows (ld = K+1), 16-byte rows, and BS_LAYOUT_WAVE -- the form the production pop kernel
+    (k_rans_pop_wave) and the prior push read."""
     h = hip()
     g = golden("tables_rans.npz")
     K = g[f"{name}_cdf"].shape[1] - 1
     D = g[f"{name}_cdf"].shape[0]
-    ld = h.aligned_ld(K) if aligned else K + 1
-    tab = np.zeros((D, ld), dtype=np.uint32)
-    tab[:, : K + 1] = g[f"{name}_cdf"]
-    cdf = dev(tab.view(np.int32))
     B = 3  # the same chain three times + per-chain tables
+    if form == "wave":
+        cdf = wave_table(h, g[f"{name}_cdf"], K)
+        Dp = cdf.shape[0]
+        per_chain = cdf.unsqueeze(0).expand(B, -1, -1).contiguous()
+        per_chain.bs_layout = h.LAYOUT_WAVE
+    else:
+        ld = h.aligned_ld(K) if form == "aligned" else K + 1
+        tab = np.zeros((D, ld), dtype=np.uint32)
+        tab[:, : K + 1] = g[f"{name}_cdf"]
+        cdf, Dp = dev(tab.view(np.int32)), D
+        per_chain = cdf.unsqueeze(0).expand(B, -1, -1).contiguous()
+
+    def padded(sym):   # symbols of the appended identity rows: 0
+        out = np.zeros((B, Dp), dtype=np.int32)
+        out[:, :D] = sym
+        return dev(out)
     s0 = words_to_state(g[f"{name}_state0"])
-    st = h.RansState.from_lists([s0] * B, cap=len(s0) + 2 * D + 8, device=DEV)
-    sym, _ = h.rans_pop(st, cdf.unsqueeze(0).expand(B, -1, -1).contiguous(), K)
+    st = h.RansState.from_lists([s0] * B, cap=len(s0) + 2 * Dp + 8, device=DEV)
+    sym, _ = h.rans_pop(st, per_chain, K)
     st.check()
     for b in range(B):
-        assert np.array_equal(sym[b].cpu().numpy(), g[f"{name}_pop_sym"])
+        assert np.array_equal(sym[b, :D].cpu().numpy(), g[f"{name}_pop_sym"])
+        assert int(sym[b, D:].abs().sum()) == 0
     assert st.to_lists() == [words_to_state(g[f"{name}_state_after_pop"])] * B
     h.rans_push_table(st, cdf, sym, K)               # shared table, chain_stride 0
     st.check()
     assert st.to_lists() == [s0] * B
-    h.rans_push_table(st, cdf.unsqueeze(0).expand(B, -1, -1).contiguous(), dev(np.tile(g[f"{name}_push_sym"], (B, 1))), K)
+    h.rans_push_table(st, per_chain, padded(g[f"{name}_push_sym"]), K)
     st.check()
     assert st.to_lists() == [words_to_state(g[f"{name}_state_after_push"])] * B
 
@@ -279,14 +302,19 @@ def test_other_ans_precisions_vs_oracle(bits):
 
 
 @pytest.mark.parametrize("bits", [16, 24, 28])
-def test_other_precisions_vs_reference_fixture(golden, bits):
-    """HIP tables / pop / push at 16, 24, 28 bits against word streams produced by the reference's ANS class."""
+@pytest.mark.parametrize("layout", ["linear", "wave"])
+def test_other_precisions_vs_reference_fixture(golden, bits, layout):
+    """HIP tables / pop / push at 16, 24, 28 bits against word streams produced by the reference's ANS class;
+    `wave`: the same rows in BS_LAYOUT_WAVE through k_rans_pop_wave."""
     h = hip()
     g = golden("rans_bits.npz")
     q, K = int(g["quantbits"]), g["pmf_f64"].shape[1]
     f, cdf, st_rows = h.table_rows(dev(g["pmf_f64"]), bits, q, ld=h.aligned_ld(K))
     assert int(st_rows.abs().max()) == 0
     assert np.array_equal(u32(f), g[f"b{bits}_f"]) and np.array_equal(u32(cdf)[:, : K + 1], g[f"b{bits}_cdf"])
+    if layout == "wave":
+        assert cdf.shape[0] % 64 == 0
+        cdf = wave_table(h, g[f"b{bits}_cdf"], K, bits)
     s0 = words_to_state(g[f"b{bits}_state0"])
     st = h.RansState.from_lists([s0, s0], cap=len(s0) + 2 * cdf.shape[0] + 8, device=DEV)
     sym, _ = h.rans_pop(st, cdf, K, bits=bits, B=2)
@@ -353,14 +381,26 @@ def test_ans_class_drop_in(golden):
 
 @pytest.mark.parametrize("chain", ["chain_mnist_small_bitswap", "chain_mnist_small_bbans", "chain_rgb4_small_bitswap",
                                    "chain_rgb4_small_bbans"])
-def test_chain_replay_matches_reference_words(golden, chain):
+@pytest.mark.parametrize("layout", ["linear", "wave"])
+@pytest.mark.parametrize("spec", [1, 2])
+def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
     """Teacher-forced replay of the reference sender through the HIP kernels: same popped symbols,
-    same per-operation state, same final word stream as the reference's Python run."""
+    same per-operation state, same final word stream as the reference's Python run -- for the production kernel
+    pair (layout wave: k_logistic<.., M_WAVE> + k_rans_pop_wave; spec 2: the uniform-bin CDF on every table that
+    qualifies) as well as for the reference's linear rows / CDF spec 1."""
+    from bitswap_amd.bins import uniform_step
     h = hip()
     g = golden(chain + ".npz")
     zend, xend, zcen = chain_tables(g)
     zend_d = [dev(z) for z in zend]
     xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)
+    steps = {}
+    for tab, e in list(enumerate(zend)) + [(-1, xend)]:
+        hs = uniform_step(e) if (spec == 2 and e.shape[1] + 1 >= 256) else None
+        steps[tab] = None if hs is None else dev(hs)
+    if spec == 2:
+        assert steps[-1] is not None and steps[0] is not None and steps[len(zend) - 1] is None
+    lay = h.LAYOUT_WAVE if layout == "wave" else h.LAYOUT_LINEAR
     B = 2
     s0 = reference_init_state()
     st = h.RansState.from_lists([s0] * B, cap=40000, device=DEV)
@@ -370,14 +410,14 @@ def test_chain_replay_matches_reference_words(golden, chain):
         mu = dev(np.tile(g[f"op{i}_mu"], (B, 1)))
         sc = dev(np.tile(g[f"op{i}_scale"], (B, 1)))
         if kind == 0:
-            cdf = h.logistic_tables(e, mu, sc, 31, int(q))
+            cdf = h.logistic_tables(e, mu, sc, 31, int(q), layout=lay, step=steps[int(tab)], status=st.status)
             sym, z = h.rans_pop(st, cdf, K, centres=dev(zcen[tab]))
             assert np.array_equal(sym[1].cpu().numpy(), g[f"op{i}_sym"])
             want_z = zcen[tab][np.arange(zcen.shape[1]), g[f"op{i}_sym"]].astype(np.float32)
             assert np.array_equal(z[0].cpu().numpy(), want_z)
         else:
             sym = dev(np.tile(g[f"op{i}_sym"].astype(np.int32), (B, 1)))
-            f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, int(q))
+            f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, int(q), step=steps[int(tab)])
             h.rans_push(st, f, c)
         assert (st.len.cpu() + 1).tolist() == [int(g["op_nwords"][i])] * B
         assert int(st.head[0].cpu().numpy().view(np.uint64)) == int(g["op_head"][i])
@@ -385,36 +425,44 @@ def test_chain_replay_matches_reference_words(golden, chain):
     assert st.to_lists() == [words_to_state(g["sent_words"])] * B
 
 
-def test_full_size_round_trip_property():
+@pytest.mark.parametrize("layout", ["linear", "wave"])
+@pytest.mark.parametrize("spec", [1, 2])
+def test_full_size_round_trip_property(layout, spec):
     """BASELINE config sizes (D=2048, K=1024 latents; D=3072, K=256 pixels), 64 chains: bits-back
     pop followed by push of the same symbols restores every state exactly; pushing then popping
-    returns the pushed symbols.  Size-independent property, no oracle needed."""
+    returns the pushed symbols.  Size-independent property, no oracle needed.  All four (layout, CDF spec)
+    kernel combinations; the production pair is (wave, 2)."""
+    from bitswap_amd.bins import uniform_step
     h = hip()
     rng = np.random.RandomState(9)
+    lay = h.LAYOUT_WAVE if layout == "wave" else h.LAYOUT_LINEAR
     for (D, K, q) in ((2048, 1024, 10), (3072, 256, 8)):
         B = 64
         lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
-        e = dev(np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)]))
+        e_np = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
+        e = dev(e_np)
+        step = dev(uniform_step(e_np)) if spec == 2 else None
         mu = dev(rng.randn(B, D).astype(np.float32))
         sc = dev(rng.uniform(0.1, 1.0, (B, D)).astype(np.float32))
         states = [reference_init_state(3000, seed=100 + b) for b in range(B)]
         st = h.RansState.from_lists(states, cap=3000 + D + 64, device=DEV)
-        cdf = h.logistic_tables(e, mu, sc, 31, q)
+        cdf = h.logistic_tables(e, mu, sc, 31, q, layout=lay, step=step, status=st.status)
         sym, _ = h.rans_pop(st, cdf, K)
-        f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, q)
+        f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, q, step=step)
         h.rans_push(st, f, c)
         st.check()
         assert st.to_lists() == states
         data = dev(rng.randint(0, K, (B, D)).astype(np.int32))
-        f, c = h.logistic_fc(e, mu, sc, data, st.status, 31, q)
+        f, c = h.logistic_fc(e, mu, sc, data, st.status, 31, q, step=step)
         h.rans_push(st, f, c)
         back, _ = h.rans_pop(st, cdf, K)
         st.check()
         assert torch.equal(back, data)
         assert st.to_lists() == states
         # every cdf row is a valid table
-        t = u32(cdf[:4])[:, :, : K + 1].astype(np.int64)
-        assert np.all(t[:, :, 0] == 0) and np.all(t[:, :, -1] == 1 << 31) and np.all(np.diff(t, axis=2) >= 1)
+        rows = u32(cdf[:4])
+        t = (unpermute_wave(rows, K)[0] if layout == "wave" else rows[:, :, :K]).astype(np.int64)
+        assert np.all(t[:, :, 0] == 0) and np.all(t[:, :, -1] < 1 << 31) and np.all(np.diff(t, axis=2) >= 1)
 
 
 def unpermute_wave(rows, K):
@@ -465,3 +513,76 @@ def test_wave_layout_tables_and_pop(K):
     h.rans_push_table(s3, one, sym3, K)
     s3.check()
     assert s3.to_lists() == [states[0]] * 2
+
+
+@pytest.mark.parametrize("K", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("ptype", [torch.float32, torch.float64])
+def test_logistic_spec2_bit_exact_vs_oracle(K, ptype):
+    """CDF spec 2 (uniform bins) on the GPU -- decode flavour in both layouts and encode flavour -- against the
+    oracle's C restatement (oracle/bitswap_oracle.c::det2_row_cdf), bit for bit; 6 chains so that a wavefront
+    walks several chains with the same residual registers, scales down to the model's minimum and saturated rows."""
+    from bitswap_amd.bins import uniform_step
+    h = hip()
+    q = int(np.log2(K))
+    rng = np.random.RandomState(K + 7)
+    D, B = 41, 6
+    lo = rng.uniform(-9, -2, D).astype(np.float16).astype(np.float64)
+    hi = rng.uniform(2, 9, D).astype(np.float16).astype(np.float64)
+    e = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
+    step = uniform_step(e)
+    assert step is not None
+    mu = (rng.randn(B, D) * 0.8).astype(np.float32)
+    sc = rng.uniform(0.1, 1.0, (B, D)).astype(np.float32)
+    sc[0, :8] = 0.1
+    mu[1, 0], mu[1, 1] = 30.0, -30.0
+    sym = rng.randint(0, K, (B, D)).astype(np.int32)
+    sym[0, :4] = [0, K - 1, 1, K - 2]
+    status = torch.zeros(B, dtype=torch.int32, device=DEV)
+    lin = u32(h.logistic_tables(dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, step=dev(step), status=status))
+    wav = u32(h.logistic_tables(dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, layout=h.LAYOUT_WAVE, step=dev(step),
+                                status=status))
+    f, c = h.logistic_fc(dev(e), dev(mu, ptype), dev(sc, ptype), dev(sym), status, 31, q, step=dev(step))
+    f, c = u32(f), u32(c)
+    assert int(status.abs().max()) == 0
+    cw, piv = unpermute_wave(wav, K)
+    rows = np.arange(D)
+    for b in range(B):
+        pmf = O.logistic_pmf(e, mu[b].astype(np.float64), sc[b].astype(np.float64), O.MODE_DET2, step)
+        _, want, rc = O.tables(pmf, 31, q)
+        assert rc == O.OK
+        assert np.array_equal(lin[b][:, : K + 1], want), b
+        assert np.array_equal(cw[b], want[:, :K]), b
+        assert np.array_equal(piv[b][:, : K // 64], want[:, 0:K:64])
+        assert np.array_equal(c[b], want[rows, sym[b]])
+        assert np.array_equal(f[b], want[rows, sym[b] + 1] - want[rows, sym[b]])
+    # K below 256 has no spec 2
+    e64 = np.stack([np.linspace(-4, 4, 65)[1:-1]] * 3)
+    with pytest.raises(h.BitswapHipError):
+        h.logistic_tables(dev(e64), dev(mu[:, :3]), dev(sc[:, :3]), 31, 6, step=dev(uniform_step(e64)))
+
+
+@pytest.mark.parametrize("spec", [1, 2])
+def test_degenerate_parameters_are_flagged(spec):
+    """NaN / Inf / non-positive (mu, scale) from a broken checkpoint: the table kernels set BS_ST_BADTABLE for the
+    chain (the reference would trip over its assert at mnist_compress.py:47 or code garbage), later kernels skip it,
+    the healthy chains are untouched."""
+    from bitswap_amd.bins import uniform_step
+    h = hip()
+    K, D, B = 256, 64, 5
+    e = np.stack([np.linspace(-4, 4, K + 1)[1:-1]] * D)
+    step = dev(uniform_step(e)) if spec == 2 else None
+    mu = np.zeros((B, D), dtype=np.float32)
+    sc = np.full((B, D), 0.5, dtype=np.float32)
+    mu[1, 3] = np.nan
+    sc[2, 60] = 0.0
+    sc[3, 7] = np.inf
+    states = [reference_init_state(800, seed=b) for b in range(B)]
+    st = h.RansState.from_lists(states, cap=2000, device=DEV)
+    cdf = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, step=step, status=st.status)
+    assert st.status.cpu().tolist() == [0, h.ST_BADTABLE, h.ST_BADTABLE, h.ST_BADTABLE, 0]
+    sym, _ = h.rans_pop(st, cdf, K)
+    got = st.to_lists()
+    assert got[1:4] == states[1:4] and got[0] != states[0] and got[4] != states[4]
+    st2 = h.RansState.from_lists(states, cap=2000, device=DEV)
+    h.logistic_fc(dev(e), dev(mu), dev(sc), sym, st2.status, 31, 8, step=step)
+    assert st2.status.cpu().tolist() == [0, h.ST_BADTABLE, h.ST_BADTABLE, h.ST_BADTABLE, 0]

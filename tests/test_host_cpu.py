@@ -12,17 +12,11 @@ from oracle.backend import OracleBackend
 from bitswap_amd import bins, cli, container, rand, tiling, workload
 from bitswap_amd.codec import BitSwapCodec, initial_states
 from bitswap_amd.model import Model
-from conftest import chain_tables, reference_init_state, words_to_state
+from conftest import chain_tables, load_golden_model, reference_init_state, words_to_state
 
 
 def load_model(g, **kw):
-    cfg = g["cfg"]
-    m = Model(xs=(int(cfg[0]), 32, 32), nz=int(cfg[1]), zchannels=int(cfg[2]), nprocessing=int(cfg[3]),
-              kernel_size=int(cfg[4]), resdepth=int(cfg[5]), reswidth=int(cfg[6]), **kw)
-    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
-    assert set(sd) == set(m.state_dict())          # identical state-dict keys as the reference Model
-    m.load_state_dict(sd)
-    return m.eval()
+    return load_golden_model(g, **kw)
 
 
 @pytest.mark.parametrize("fold", [False, True])
@@ -85,6 +79,33 @@ def test_bins_match_reference(golden):
     assert np.array_equal(e, b["kbins_endpoints_q6"]) and np.array_equal(c, b["kbins_centres_q6"])
     te, tc = bins.top_bins(8, 10)
     assert np.array_equal(te[5], b["top_endpoints_q10"]) and np.array_equal(tc[0], b["top_centres_q10"])
+
+
+def test_uniform_step_decides_the_cdf_spec():
+    """bins.uniform_step: the bin width of uniform-width rows (what discretize() makes below the top layer and what
+    ImageBins is), None for anything else -- the top layer's equal-mass bins, a perturbed row."""
+    rng = np.random.RandomState(0)
+    lo, hi = rng.uniform(-9, -2, 7).astype(np.float16).astype(np.float64), rng.uniform(2, 9, 7)
+    e, _ = bins.uniform_bins(lo, hi, 10)
+    h = bins.uniform_step(torch.from_numpy(e))
+    assert h is not None and h.dtype == np.float64 and np.allclose(h, (hi - lo) / 1024, rtol=1e-12)
+    assert np.array_equal(h, (e[:, -1] - e[:, 0]) / np.float64(1022))
+    te, _ = bins.top_bins(4, 10)
+    assert bins.uniform_step(te) is None
+    xe = rand.ImageBins(torch.float64, "cpu", 5).endpoints()          # expanded view, row stride 0
+    hx = bins.uniform_step(xe)
+    assert hx is not None and np.allclose(hx, 2 / 255)
+    bad = e.copy()
+    bad[3, 500] += 1e-9
+    assert bins.uniform_step(bad) is None
+    # the codec: spec 2 on the uniform layers and the pixels, spec 1 on the top layer; cdf_spec=1 turns it off
+    model, zend, zcen = workload.build("cifar8", "cpu", quantbits=8, small=8)
+    c2 = BitSwapCodec(model, zend, zcen, quantbits=8, backend=OracleBackend(O.MODE_DET))
+    assert [s is not None for s in c2.zstep] == [True] * 7 + [False] and c2.xstep is not None
+    c1 = BitSwapCodec(model, zend, zcen, quantbits=8, backend=OracleBackend(O.MODE_DET), cdf_spec=1)
+    assert all(s is None for s in c1.zstep) and c1.xstep is None
+    c0 = BitSwapCodec(model, zend, zcen, quantbits=8, backend=OracleBackend(O.MODE_LIBM))
+    assert all(s is None for s in c0.zstep)            # the libm mode restates the reference formula only
 
 
 def test_discretize_sampling_and_cache(tmp_path):

@@ -117,3 +117,77 @@ def test_oracle_other_precisions_vs_reference(golden, bits):
     assert st.tolist() == words_to_state(g[f"b{bits}_state_after_pop"])
     assert O.push(st, cdf, g[f"b{bits}_push_sym"], bits) == O.OK
     assert st.tolist() == words_to_state(g[f"b{bits}_state_after_push"])
+
+
+def _uniform_rows(rng, D, K, f16=False):
+    lo, hi = rng.uniform(-9, -2, D), rng.uniform(2, 9, D)
+    if f16:   # discretize() takes min/max of float16 samples (discretization.py:59-61)
+        lo, hi = lo.astype(np.float16).astype(np.float64), hi.astype(np.float16).astype(np.float64)
+    return np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
+
+
+@pytest.mark.parametrize("K", [256, 1024, 2048])
+def test_cdf_spec2_agrees_with_spec1_and_torch(K):
+    """CDF spec 2 (uniform bins: one exponential per group of K/64 bins) against spec 1 and against the reference
+    formula evaluated by torch (utils/torch/rand.py:67-68 + mnist_compress.py:183-185): same float budget as spec 1
+    (pmf within 6 ulp of 1.0 of torch's) and integer tables that differ in at most 2 ppm of the entries, |df| <= 1."""
+    import torch
+    rng = np.random.RandomState(K)
+    D, q = 1024 * 256 // K, int(np.log2(K))
+    e = _uniform_rows(rng, D, K, f16=True)
+    mu = (rng.randn(D) * 0.7).astype(np.float32).astype(np.float64)
+    sc = rng.uniform(0.1, 1.0, D).astype(np.float32).astype(np.float64)
+    sc[: D // 8] = np.float64(np.float32(0.1))          # the model's minimum scale (mnist_train.py:349)
+    mu[0], mu[1] = 30.0, -30.0                          # saturated rows
+    p1 = O.logistic_pmf(e, mu, sc, O.MODE_DET)
+    p2 = O.logistic_pmf(e, mu, sc, O.MODE_DET2)
+    assert p2.min() >= 0.0
+    cd = torch.sigmoid((torch.from_numpy(e).t() - torch.from_numpy(mu)) / torch.from_numpy(sc)).t()
+    pt = torch.cat((cd[:, :1], cd[:, 1:] - cd[:, :-1], 1. - cd[:, -1:]), 1).numpy()
+    assert np.abs(p2 - pt).max() <= 6 * 2.2204460492503131e-16
+    f1, f2, ft = (O.tables(p, 31, q)[0].astype(np.int64) for p in (p1, p2, pt))
+    assert O.tables(p2, 31, q)[2] == O.OK
+    for other in (f1, ft):
+        d = np.abs(f2 - other)
+        assert d.max() <= 1 and (d > 0).mean() <= 2e-6
+
+
+def test_cdf_spec2_accuracy_vs_exact():
+    import mpmath as mp
+    mp.mp.prec = 200
+    rng = np.random.RandomState(8)
+    K, D = 1024, 6
+    e = _uniform_rows(rng, D, K)
+    mu = rng.randn(D) * 0.7
+    sc = np.array([0.1, 0.1, 0.3, 0.5, 0.9, 1.0])
+    p2 = O.logistic_pmf(e, mu, sc, O.MODE_DET2)
+    for d in range(D):
+        ex = [1 / (1 + mp.exp(-(mp.mpf(e[d, j]) - mp.mpf(mu[d])) / mp.mpf(sc[d]))) for j in range(K - 1)]
+        pm = [ex[0]] + [ex[j] - ex[j - 1] for j in range(1, K - 1)] + [1 - ex[-1]]
+        err = max(abs(mp.mpf(float(p2[d, j])) - pm[j]) for j in range(K))
+        assert err <= 3 * 2.2204460492503131e-16, (d, float(err))
+
+
+def test_chain_replay_spec2_matches_reference_words(golden):
+    """The reference sender replayed (teacher-forced) with CDF spec 2 on every uniform-bin table still yields the
+    reference's word stream on the rgb nz=4 chain: its tables equal spec 1's and torch's on these rows."""
+    from bitswap_amd.bins import uniform_step
+    for sched in ("bitswap", "bbans"):
+        g = golden(f"chain_rgb4_small_{sched}.npz")
+        zend, xend, _ = chain_tables(g)
+        steps = {tab: uniform_step(e) for tab, e in list(enumerate(zend)) + [(-1, xend)]}
+        assert steps[len(zend) - 1] is None and all(steps[t] is not None for t in range(len(zend) - 1))
+        assert steps[-1] is not None                      # the pixel bins are uniform too (rand.py:134-153)
+        st = O.Stack(reference_init_state(), cap=60000)
+        for i, (kind, tab, q) in enumerate(zip(g["op_kind"], g["op_table"], g["op_q"])):
+            e = xend if tab < 0 else zend[tab]
+            h = steps[int(tab)]
+            mode = O.MODE_DET2 if h is not None else O.MODE_DET
+            mu, sc = g[f"op{i}_mu"].astype(np.float64), g[f"op{i}_scale"].astype(np.float64)
+            if kind == 0:
+                sym, rc = O.layer_pop(st, e, mu, sc, 31, int(q), mode, h)
+                assert rc == O.OK and np.array_equal(sym, g[f"op{i}_sym"])
+            else:
+                assert O.layer_push(st, e, mu, sc, g[f"op{i}_sym"].astype(np.int32), 31, int(q), mode, h) == O.OK
+            assert int(st.head[0]) == int(g["op_head"][i])
+        assert st.tolist() == words_to_state(g["sent_words"])

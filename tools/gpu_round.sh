@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, bench, kernel microbench, rocprofv3 stats + PMC passes.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r01b [notest] [noprof]'
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r02a [notest] [noprof] [nobench]'
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 TAG=${1:-rXX}
 shift
@@ -9,16 +9,18 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 has() { for a in "$@"; do [ "$a" = "$WANT" ] && return 0; done; return 1; }
 WANT=notest; if ! has "$@"; then
-  timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/${TAG}_pytest.log" 2>&1
+  timeout 1200 python -m pytest tests -m gpu -x -q > "$OUT/${TAG}_pytest.log" 2>&1
   echo "pytest exit $?" | tee -a "$OUT/${TAG}_pytest.log"
-  tail -3 "$OUT/${TAG}_pytest.log"
+  tail -15 "$OUT/${TAG}_pytest.log"
 fi
-timeout 600 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
-echo "bench exit $?"; cat "$OUT/${TAG}_bench.json"; tail -3 "$OUT/${TAG}_bench.err"
+WANT=nobench; if ! has "$@"; then
+  timeout 900 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+  echo "bench exit $?"; cat "$OUT/${TAG}_bench.json"; tail -3 "$OUT/${TAG}_bench.err"
+fi
 timeout 300 python tools/microbench.py > "$OUT/${TAG}_micro.json" 2> "$OUT/${TAG}_micro.err"
 echo "micro exit $?"; cat "$OUT/${TAG}_micro.json"; tail -3 "$OUT/${TAG}_micro.err"
 WANT=noprof; if ! has "$@"; then
-  BCMD="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+  BCMD="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
   ( cd /tmp && rm -rf prof_stats prof_fetch prof_write
     timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -o st --output-format csv -- $BCMD > "$OUT/${TAG}_prof_stats.log" 2>&1
     timeout 600 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch -o pf --output-format csv -- $BCMD > "$OUT/${TAG}_prof_fetch.log" 2>&1

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel-level timings of the hot path at BASELINE sizes (run on the GPU box)."""
+"""Kernel-level timings of the hot path at BASELINE sizes, SURVEY 8(d) parameter regime (latents: mu ~ N(0, 0.5^2),
+scale ~ U[0.1, 1], uniform bins over +-2..8; pixels: K = 256).  Run on the GPU box:
+    python tools/microbench.py --B 400
+"""
 import argparse
 import json
 import os
@@ -10,6 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bitswap_amd import hip  # noqa: E402
+from bitswap_amd.bins import uniform_step  # noqa: E402
 
 
 def timeit(fn, iters=10, warmup=2):
@@ -25,9 +29,19 @@ def timeit(fn, iters=10, warmup=2):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+def fresh_state(B, D, dev, nwords=10000):
+    np.random.seed(1)
+    words = np.random.randint(1 << 16, (1 << 32) - 1, size=(B, nwords), dtype=np.uint32)
+    st = hip.RansState(B, nwords + 4 * D, dev)
+    st.stack[:, :nwords] = torch.from_numpy(words.view(np.int32)).to(dev)
+    st.len.fill_(nwords - 1)
+    st.head.copy_(torch.from_numpy((words[:, -1].astype(np.uint64) << np.uint64(32)).view(np.int64)))
+    return st
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--B", type=int, default=100)
+    ap.add_argument("--B", type=int, default=400)
     ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     dev = "cuda"
@@ -36,51 +50,41 @@ def main():
     for (name, D, K, q) in (("z", 2048, 1024, 10), ("x", 3072, 256, 8)):
         B = args.B
         lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
-        e = torch.from_numpy(np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])).to(dev)
+        e_np = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
+        e = torch.from_numpy(e_np).to(dev)
+        step = torch.from_numpy(uniform_step(e_np)).to(dev)
         mu = torch.from_numpy((rng.randn(B, D) * 0.5).astype(np.float32)).to(dev)
         sc = torch.from_numpy(rng.uniform(0.1, 1.0, (B, D)).astype(np.float32)).to(dev)
-        np.random.seed(1)
-        words = np.random.randint(1 << 16, (1 << 32) - 1, size=(B, 10000), dtype=np.uint32)
-        st = hip.RansState(B, 10000 + 4 * D, dev)
-        st.stack[:, :10000] = torch.from_numpy(words.view(np.int32)).to(dev)
-        st.len.fill_(9999)
-        st.head.copy_(torch.from_numpy((words[:, -1].astype(np.uint64) << np.uint64(32)).view(np.int64)))
-        ld = hip.aligned_ld(K)
-        cdf = torch.empty((B, D, ld), dtype=torch.int32, device=dev)
-        t_tab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=cdf), args.iters)
-        sym, _ = hip.rans_pop(st, cdf, K)
-        fo = (torch.empty((B, D), dtype=torch.int32, device=dev), torch.empty((B, D), dtype=torch.int32, device=dev))
-        t_fc = timeit(lambda: hip.logistic_fc(e, mu, sc, sym, st.status, 31, q, out=fo), args.iters)
-
-        def poppush():
-            s2, _ = hip.rans_pop(st, cdf, K)
-            hip.rans_push(st, fo[0], fo[1])
-        t_pp = timeit(poppush, args.iters)
-        t_pop = timeit(lambda: (hip.rans_pop(st, cdf, K), hip.rans_push(st, fo[0], fo[1]))[0], 1, 0)  # placeholder
-        # separate pop / push timings (state returns to the start after each pair)
-        def only_pop():
-            hip.rans_pop(st, cdf, K)
-        def only_push():
-            hip.rans_push(st, fo[0], fo[1])
-        tp = []
-        tq = []
-        for _ in range(args.iters):
-            tp.append(timeit(only_pop, 1, 0))
-            tq.append(timeit(only_push, 1, 0))
-        # wave-native hand-off layout
+        st = fresh_state(B, D, dev)
         wcdf = torch.empty((B, D, hip.wave_ld(K)), dtype=torch.int32, device=dev)
-        t_wtab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=wcdf, layout=hip.LAYOUT_WAVE), args.iters)
-        wcdf.bs_layout = hip.LAYOUT_WAVE
-        tw = []
-        for _ in range(args.iters):
-            tw.append(timeit(lambda: hip.rans_pop(st, wcdf, K), 1, 0))
+        fo = (torch.empty((B, D), dtype=torch.int32, device=dev), torch.empty((B, D), dtype=torch.int32, device=dev))
+        r = dict(B=B, D=D, K=K)
+        for spec, stp in ((1, None), (2, step)):
+            t_tab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=wcdf, layout=hip.LAYOUT_WAVE, step=stp,
+                                                       status=st.status), args.iters)
+            wcdf.bs_layout = hip.LAYOUT_WAVE
+            sym, _ = hip.rans_pop(st, wcdf, K)
+            t_fc = timeit(lambda: hip.logistic_fc(e, mu, sc, sym, st.status, 31, q, out=fo, step=stp), args.iters)
             hip.rans_push(st, fo[0], fo[1])
-        st.check()
-        rows = B * D
-        alg = rows * ((K - 1) * 8 + 12)
-        res[name] = dict(B=B, D=D, K=K, tables_s=t_tab, tables_wave_s=t_wtab, pop_wave_s=float(np.median(tw)), fc_s=t_fc, pop_s=float(np.median(tp)), push_s=float(np.median(tq)),
-                         tables_rows_per_s=rows / t_tab, tables_alg_GBps=alg / t_tab / 1e9,
-                         fc_alg_GBps=alg / t_fc / 1e9, sigmoids_per_s_tables=rows * (K - 1) / t_tab)
+            tp, tq = [], []
+            for _ in range(args.iters):
+                tp.append(timeit(lambda: hip.rans_pop(st, wcdf, K), 1, 0))
+                tq.append(timeit(lambda: hip.rans_push(st, fo[0], fo[1]), 1, 0))
+            st.check()
+            rows = B * D
+            alg = rows * ((K - 1) * 8 + 12)
+            r[f"spec{spec}"] = dict(tables_wave_s=t_tab, fc_s=t_fc, pop_wave_s=float(np.median(tp)),
+                                    push_s=float(np.median(tq)), tables_alg_GBps=alg / t_tab / 1e9,
+                                    fc_alg_GBps=alg / t_fc / 1e9, ns_per_row_tables=t_tab / rows * 1e9)
+            if hasattr(hip, "layer_pop"):
+                cen = torch.from_numpy(rng.randn(D, K)).to(dev)
+                tl = []
+                for _ in range(args.iters):
+                    tl.append(timeit(lambda: hip.layer_pop(st, e, mu, sc, 31, q, centres=cen, step=stp), 1, 0))
+                    hip.rans_push(st, fo[0], fo[1])
+                st.check()
+                r[f"spec{spec}"]["layer_pop_s"] = float(np.median(tl))
+        res[name] = r
     print(json.dumps(res, indent=1))
 
 
