@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--quantbits", type=int, default=10)
     ap.add_argument("--bitswap", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only (no imagenet4 / 100-chain sub-results)")
     ap.add_argument("--cpu-blocks", type=int, default=20, help="blocks per chain in the CPU baseline sample")
     ap.add_argument("--no-timeline", action="store_true", help="skip per-kernel events (roofline becomes null)")
     ap.add_argument("--groups", type=int, default=2,

@@ -67,9 +67,13 @@ def _cache_names(cache_dir, dataset, nz, quantbits):
 
 
 def discretize(nz, quantbits, type, device, model, dataset, data=None, ppb=30, cache_dir="bins", batch=128,
-               save=True):
+               save=True, eps_fn=None, order=None):
     """Same positional signature as the reference.  `data`: uint8/float images [N, C, 32, 32] in
-    [0, 255] used for the posterior samples when no cached bins exist."""
+    [0, 255] used for the posterior samples when no cached bins exist.
+    eps_fn(shape) -> Logistic(0,1) noise on `device` (default: rand.logistic_eps on the device, bound 1e-30 like
+    discretization.py:62,70,78); order: indices into `data`, one per sample (default: random with replacement -- the
+    reference walks a shuffled DataLoader, :45-53).  Both exist so that the sampling procedure can be replayed
+    against the reference's with the same noise (tests/golden/make_golden.py::make_discretize_fixture)."""
     fe, fc = _cache_names(cache_dir, dataset, nz, quantbits)
     if os.path.exists(fe) and os.path.exists(fc):
         zendpoints = torch.load(fe, map_location="cpu")
@@ -89,21 +93,27 @@ def discretize(nz, quantbits, type, device, model, dataset, data=None, ppb=30, c
         was_compressing = model.compressing
         model.compress(False)
         dev = torch.device(device)
-        nb = (nsamples + batch - 1) // batch
+        if eps_fn is None:
+            eps_fn = lambda shape: logistic_eps(shape, device=dev, bound=1e-30)
+        nb = nsamples // batch                  # whole batches only, like the reference (:55-56)
+        assert nb >= 1, "ppb * 2^quantbits must be at least one batch of 128 samples"
         with torch.no_grad():
+            # float16 sample stores, like the reference (:59-61); the tail beyond nb*batch stays zero there too
             gen = torch.zeros((nz, nsamples) + tuple(model.zdim), dtype=torch.float16, device=dev)
             inf = torch.zeros((nz, nsamples) + tuple(model.zdim), dtype=torch.float16, device=dev)
-            gen[-1] = logistic_eps((nsamples,) + tuple(model.zdim), device=dev, bound=1e-30).half()
-            idx = torch.randint(0, data.shape[0], (nsamples,))
+            gen[-1] = eps_fn((nsamples,) + tuple(model.zdim)).half()
+            idx = torch.as_tensor(order) if order is not None else torch.randint(0, data.shape[0], (nsamples,))
             for zi in reversed(range(1, nz)):
-                li = nz - zi - 1   # inference layer sampled in this round (discretization.py:73-78)
-                for bi in range(nb):
-                    sl = slice(bi * batch, min(nsamples, (bi + 1) * batch))
+                for bi in range(nb):            # ancestral samples of z_{zi-1} (:66-70)
+                    sl = slice(bi * batch, (bi + 1) * batch)
                     mu, scale = model.generate(zi)(given=gen[zi][sl].float())
-                    gen[zi - 1][sl] = transform(logistic_eps(mu.shape, device=dev, bound=1e-30), mu, scale).half()
+                    gen[zi - 1][sl] = transform(eps_fn(tuple(mu.shape)), mu, scale).half()
+                li = nz - zi - 1                # posterior samples of z_{li+1} on the data (:73-78)
+                for bi in range(nb):
+                    sl = slice(bi * batch, (bi + 1) * batch)
                     given = data[idx[sl]].to(dev).float() if li == 0 else inf[li - 1][sl].float()
                     mu, scale = model.infer(li)(given=given)
-                    inf[li][sl] = transform(logistic_eps(mu.shape, device=dev, bound=1e-30), mu, scale).half()
+                    inf[li][sl] = transform(eps_fn(tuple(mu.shape)), mu, scale).half()
             for zi in range(nz - 1):
                 s = torch.cat([gen[zi], inf[zi]], dim=0).reshape(-1, Z).double()
                 zendpoints[zi], zcentres[zi] = uniform_bins(s.min(0).values.cpu().numpy(),

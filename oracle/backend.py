@@ -75,14 +75,40 @@ class OracleBackend:
 
     def bin_step(self, endpoints):
         """Same decision as HipBackend.bin_step (bitswap_amd.bins.uniform_step); only the deterministic mode has a
-        spec 2 -- the libm mode restates the reference formula and ignores it."""
+        spec 2 -- the libm / torch modes restate the reference formula and ignore it."""
         from bitswap_amd.bins import uniform_step
-        if self.mode == O.MODE_LIBM or endpoints.shape[1] + 1 < 256:
+        if self.mode != O.MODE_DET or endpoints.shape[1] + 1 < 256:
             return None
         return uniform_step(endpoints)
 
     def _mode(self, step):
-        return O.MODE_DET2 if (step is not None and self.mode != O.MODE_LIBM) else self.mode
+        return O.MODE_DET2 if (step is not None and self.mode == O.MODE_DET) else self.mode
+
+    @staticmethod
+    def _torch_cdf_rows(e, mu, scale, bits, q):
+        """MODE_TORCH: the reference's lines verbatim -- logistic_cdf (utils/torch/rand.py:67-68), pmf assembly
+        (mnist_compress.py:183-185) -- evaluated by this torch build, then the oracle's integer tables.  Reproduces
+        the reference's words exactly wherever the reference ran on the same torch CPU build."""
+        e, mu, scale = torch.from_numpy(e), torch.from_numpy(mu), torch.from_numpy(scale)
+        cdfs = torch.sigmoid((e.t() - mu) / scale).t()
+        pmfs = cdfs[:, 1:] - cdfs[:, :-1]
+        pmfs = torch.cat((cdfs[:, 0].unsqueeze(1), pmfs, 1. - cdfs[:, -1].unsqueeze(1)), dim=1)
+        _, cdf, rc = O.tables(pmfs.numpy(), bits, q)
+        return cdf, rc
+
+    def _pop1(self, stack, t, i, bits):
+        if self.mode == O.MODE_TORCH:
+            cdf, rc = self._torch_cdf_rows(t.e, t.mu[i], t.scale[i], bits, t.q)
+            if rc:
+                return np.zeros(t.e.shape[0], dtype=np.int32), rc
+            return O.pop(stack, cdf, bits)
+        return O.layer_pop(stack, t.e, t.mu[i], t.scale[i], bits, t.q, self._mode(t.step), t.step)
+
+    def _push1(self, stack, e, mu, scale, sym, bits, q, step):
+        if self.mode == O.MODE_TORCH:
+            cdf, rc = self._torch_cdf_rows(e, mu, scale, bits, q)
+            return rc or O.push(stack, cdf, sym, bits)
+        return O.layer_push(stack, e, mu, scale, sym, bits, q, self._mode(step), step)
 
     def shared_table(self, endpoints, mu, scale, quantbits, bits, step=None):
         return self.tables(endpoints, mu, scale, quantbits, bits, step=step)[0]
@@ -97,7 +123,7 @@ class OracleBackend:
             if state.rc[b]:
                 return np.zeros(t.e.shape[0], dtype=np.int32)
             i = 0 if t.shared else b
-            sym, rc = O.layer_pop(state.stacks[b], t.e, t.mu[i], t.scale[i], bits, t.q, self._mode(t.step), t.step)
+            sym, rc = self._pop1(state.stacks[b], t, i, bits)
             state.rc[b] = rc
             if rc:
                 sym[:] = 0   # sticky failure (e.g. too few initial bits); reported by check()
@@ -113,8 +139,7 @@ class OracleBackend:
 
         def one(b):
             if not state.rc[b]:
-                state.rc[b] = O.layer_push(state.stacks[b], e, mu[b], scale[b], sym[b], bits, quantbits,
-                                           self._mode(step), step)
+                state.rc[b] = self._push1(state.stacks[b], e, mu[b], scale[b], sym[b], bits, quantbits, step)
         self._map(one, state.B)
 
     def push_table(self, state, t, sym, K, bits):
@@ -123,8 +148,7 @@ class OracleBackend:
         def one(b):
             if not state.rc[b]:
                 i = 0 if t.shared else b
-                state.rc[b] = O.layer_push(state.stacks[b], t.e, t.mu[i], t.scale[i], sym[b], bits, t.q,
-                                           self._mode(t.step), t.step)
+                state.rc[b] = self._push1(state.stacks[b], t.e, t.mu[i], t.scale[i], sym[b], bits, t.q, t.step)
         self._map(one, state.B)
 
     def centres(self, centres, sym):

@@ -17,6 +17,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 
 OK, UNDERFLOW, OVERFLOW, BAD_TABLE = 0, 1, 2, 3
 MODE_LIBM, MODE_DET, MODE_DET2 = 0, 1, 2   # reference formula / CDF spec 1 / CDF spec 2 (uniform bins)
+MODE_TORCH = 3   # backend.py only: the reference formula evaluated by torch.sigmoid itself (utils/torch/rand.py:67-68)
 
 
 def build(force=False):

@@ -17,6 +17,9 @@ the fixtures are outputs of the reference's own classes on seeded synthetic inpu
                   (mu, scale, symbols, state) captured per coding operation
   bins.npz        Bins / ImageBins / discretize_kbins outputs (rand.py:78-153,
                   discretization.py:105-118)
+  demo_surface.npz   tiling, demo container (.npy), pickle: outputs of the reference's own extract_blocks,
+                  demo_compress.compress and demo_decompress.decompress functions (see make_surface_fixture)
+  discretize_small.npz  the sampling procedure of discretize() with explicit seeds (see make_discretize_fixture)
 
 The reference is imported unmodified; torchvision and tensorboardX (absent here) are
 stubbed exactly as SURVEY.md section 8(c) describes.
@@ -43,6 +46,24 @@ def _stub_missing_modules():
     tb = types.ModuleType("tensorboardX")
     tb.SummaryWriter = object
     sys.modules["tensorboardX"] = tb
+    # demo_compress.py:4,13,100: torchvision.transforms.Compose / ToTensor and terminaltables.AsciiTable (absent here).
+    # ToTensor's documented behaviour on a uint8 HWC PIL image: CHW float32 in [0, 1].
+    class Compose:
+        def __init__(self, ops):
+            self.ops = ops
+
+        def __call__(self, x):
+            for op in self.ops:
+                x = op(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, pic):
+            return torch.from_numpy(np.asarray(pic).copy()).permute(2, 0, 1).contiguous().float().div(255)
+    tv.transforms.Compose, tv.transforms.ToTensor = Compose, ToTensor
+    tt = types.ModuleType("terminaltables")
+    tt.AsciiTable = object
+    sys.modules["terminaltables"] = tt
 
 
 _stub_missing_modules()
@@ -492,7 +513,167 @@ def _rgb4_chain(model, zend, zcen, mins, maxs, images, cfg, nz, quantbits, xdim,
     print(name, "ops", len(ops), "words", len(sent), "cma", cma)
 
 
+def make_surface_fixture():
+    """The on-disk surface, produced by the reference's OWN functions (not a replay):
+      * benchmark_compress.extract_blocks / unextract_blocks (:20-39) on a 70x100 image;
+      * demo_compress.compress() (:72-162: sender loop, excess_state_len bookkeeping, `del state[0:excess - 1]`) and
+        the container assembly of its main block (:272-283, restated below line by line);
+      * demo_decompress main block (:214-227) + demo_decompress.decompress() (:69-148), asserted lossless here;
+      * the per-experiment pickle of mnist_compress.py:265-267.
+    The two functions hard-code the full-width crop model; `Model` in their module namespaces is replaced by a
+    constructor that narrows it (reswidth 12, 1 processing layer, 4 ResNet layers) so that the fixture stays small.
+    Checkpoint and bins reach them the way they do in the reference: as files `model/params/imagenetcrop/nz4` and
+    `bins/imagenetcrop_nz4_z{endpoints,centres}10.pt` under the working directory."""
+    import pickle
+    import tempfile
+    import demo_compress as ref_dc
+    import demo_decompress as ref_dd
+    import benchmark_compress as ref_bc
+
+    torch.manual_seed(53)
+    rng = np.random.RandomState(13)
+    nz, quantbits, zch = 4, 10, 8
+    cfg = [3, nz, zch, 1, 3, 4, 12]
+
+    def small(**kw):
+        kw.update(nprocessing=1, resdepth=4, reswidth=12, root_process=False)
+        return RefCropModel(**kw)
+    model = small(xs=(3, 32, 32), nz=nz, zchannels=zch, kernel_size=3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(".b"):
+                p.add_(torch.randn_like(p) * 0.3)
+            if n.endswith(".gain"):
+                p.add_(torch.randn_like(p) * 0.2)
+    model.eval()
+    zdim = zch * 16 * 16
+    images = synth_images(rng, 64, (3, 32, 32))
+    zend, zcen, mins, maxs = synth_bins(model, nz, zdim, quantbits, images, rng)
+
+    yy, xx = np.mgrid[0:70, 0:100]
+    img = np.stack([127 + 80 * np.sin(yy / (7. + 3 * c) + c) * np.cos(xx / (9. + 2 * c)) for c in range(3)], -1)
+    img = np.clip(np.rint(img + rng.randn(70, 100, 3) * 5), 0, 255).astype(np.uint8)
+    blocks, h, w = ref_bc.extract_blocks(img)
+    crop = ref_bc.unextract_blocks(blocks, h, w)
+    assert np.array_equal(crop, img[:h, :w])
+
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "model/params/imagenetcrop"))
+        os.makedirs(os.path.join(tmp, "bins"))
+        torch.save(model.state_dict(), os.path.join(tmp, "model/params/imagenetcrop/nz4"))
+        torch.save(torch.from_numpy(zend), os.path.join(tmp, f"bins/imagenetcrop_nz{nz}_zendpoints{quantbits}.pt"))
+        torch.save(torch.from_numpy(zcen), os.path.join(tmp, f"bins/imagenetcrop_nz{nz}_zcentres{quantbits}.pt"))
+        ref_dc.Model = ref_dd.Model = small
+        os.chdir(tmp)
+        try:
+            np.random.seed(100)                                  # demo_compress.py:225
+            state = ref_dc.compress(quantbits=quantbits, nz=nz, gpu=-1, blocks=blocks)
+            trimmed = list(state)
+            # demo_compress.py:272-283, verbatim
+            state.append(state[-1] >> 32)
+            state[-2] = state[-2] & ((1 << 32) - 1)
+            state.append(blocks.shape[0])
+            state.append(h)
+            state.append(w)
+            state_array = np.array(state, dtype=np.uint32)
+            np.save(os.path.join(tmp, "img_bitswap"), state_array)
+            npy_bytes = open(os.path.join(tmp, "img_bitswap.npy"), "rb").read()
+            # demo_decompress.py:177-179 (reads the file), :214-227
+            st = list(map(int, np.load(os.path.join(tmp, "img_bitswap.npy"))))
+            w2 = st.pop()
+            h2 = st.pop()
+            nblocks = st.pop()
+            st.append(st.pop() << 32 | st.pop())
+            assert st == trimmed and (nblocks, h2, w2) == (len(blocks), h, w)
+            out = ref_dd.decompress(quantbits=quantbits, nz=nz, gpu=-1, state=st, nblocks=nblocks)
+            assert np.all(ref_bc.unextract_blocks(out, h2, w2) == crop)   # demo_decompress.py:235-236
+        finally:
+            os.chdir(cwd)
+    # `st` is now what the receiver is left with: the untouched tail of the initial words (the reference never checks it)
+    pk = pickle.dumps(trimmed)                                   # mnist_compress.py:265-267 writes pickle.dump(state, fp)
+    # torch.sigmoid(float64) is third-party arithmetic whose last bit depends on the build / CPU dispatch (SURVEY 8c):
+    # a probe lets a test know whether the torch it runs on evaluates the CDF like the one that wrote this container
+    probe_t = torch.from_numpy(np.random.RandomState(99).uniform(-40, 40, 1 << 16))
+    probe = torch.sigmoid(probe_t).numpy()
+    o = {"sd_" + k: v.numpy() for k, v in model.state_dict().items()}
+    o.update(cfg=np.array(cfg + [quantbits], dtype=np.int64), image=img, blocks=blocks, hw=np.array([h, w]), crop=crop,
+             container=state_array, container_npy=np.frombuffer(npy_bytes, dtype=np.uint8),
+             state_pickle=np.frombuffer(pk, dtype=np.uint8), state_words=words(trimmed), rest_words=words(st),
+             sigmoid_probe=probe,
+             z_top_endpoints=zend[nz - 1][0], z_top_centres=zcen[nz - 1][0], z_mins=mins, z_maxs=maxs)
+    np.savez_compressed(os.path.join(OUT, "demo_surface.npz"), **o)
+    print("demo_surface.npz: blocks", blocks.shape, "container words", len(state_array), "of 10000 initial +",
+          "bits/dim", 32 * (len(state_array) - 5 - 0) / (blocks.shape[0] * 3072))
+
+
+def make_discretize_fixture():
+    """discretize()'s sampling procedure (discretization.py:55-83) replayed around the imported reference pieces
+    (Model, logistic_eps, transform, discretize_kbins) with EXPLICIT seeds, so that bitswap_amd.bins.discretize can
+    be driven with the very same noise and data order on the GPU.  Noise: torch.manual_seed(777) right before the
+    first draw, then the reference's call order -- gen_samples[-1], then for zi = nz-1..1: all generative batches,
+    all inference batches.  Data: batch bi = images[order[bi*128 : (bi+1)*128]]."""
+    torch.manual_seed(54)
+    rng = np.random.RandomState(14)
+    nz, quantbits, zch = 3, 8, 2
+    cfg = [3, nz, zch, 1, 3, 3, 10]
+    model = RefModel(xs=(3, 32, 32), nz=nz, zchannels=zch, nprocessing=1, kernel_size=3, resdepth=3, reswidth=10,
+                     root_process=False)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(".b") or n.endswith("gen_std"):
+                p.add_(torch.randn_like(p) * 0.3)
+            if n.endswith(".gain"):
+                p.add_(torch.randn_like(p) * 0.2)
+    model.eval()
+    zdim = zch * 16 * 16
+    K = 1 << quantbits
+    images = synth_images(rng, 96, (3, 32, 32))
+    nsamples, bs = 2 * K, 128
+    batches = nsamples // bs
+    order = rng.randint(0, len(images), size=nsamples)
+    data = torch.from_numpy(images[order]).float()
+    torch.manual_seed(777)
+    gen = np.zeros((nz, nsamples) + model.zdim, dtype=np.float16)
+    gen[-1] = logistic_eps((nsamples,) + model.zdim, device="cpu", bound=1e-30).numpy()
+    inf = np.zeros((nz, nsamples) + model.zdim, dtype=np.float16)
+    with torch.no_grad():
+        for zi in reversed(range(1, nz)):
+            for bi in range(batches):
+                mu, scale = model.generate(zi)(given=torch.from_numpy(gen[zi][bi * bs: bi * bs + bs]).float())
+                gen[zi - 1][bi * bs: bi * bs + bs] = transform(logistic_eps(mu.shape, device="cpu", bound=1e-30), mu, scale)
+            for bi in range(batches):
+                given = (data[bi * bs: bi * bs + bs] if nz - zi - 1 == 0
+                         else torch.from_numpy(inf[nz - zi - 2][bi * bs: bi * bs + bs]).float())
+                mu, scale = model.infer(nz - zi - 1)(given=given)
+                inf[nz - zi - 1][bi * bs: bi * bs + bs] = transform(logistic_eps(mu.shape, device="cpu", bound=1e-30), mu, scale).numpy()
+    zend = np.zeros((nz, zdim, K - 1))
+    zcen = np.zeros((nz, zdim, K))
+    zb = Bins(torch.zeros((1, 1, zdim)), torch.ones((1, 1, zdim)), quantbits)
+    zend[nz - 1], zcen[nz - 1] = zb.endpoints().numpy(), zb.centres().numpy()
+    mins, maxs = [], []
+    for zi in range(nz - 1):
+        samples = np.concatenate([gen[zi], inf[zi]], axis=0).astype(np.float64)
+        zend[zi], zcen[zi] = discretize_kbins(model, samples, quantbits, strategy="uniform")
+        flat = samples.reshape(-1, zdim)
+        mins.append(flat.min(0))
+        maxs.append(flat.max(0))
+    o = {"sd_" + k: v.numpy() for k, v in model.state_dict().items()}
+    o.update(cfg=np.array(cfg + [quantbits], dtype=np.int64), images=images, order=order.astype(np.int64),
+             noise_seed=np.int64(777), z_mins=np.array(mins), z_maxs=np.array(maxs),
+             z_top_endpoints=zend[nz - 1][0], z_top_centres=zcen[nz - 1][0],
+             zend_layer0_dim5=zend[0][5], zcen_layer0_dim5=zcen[0][5])
+    np.savez_compressed(os.path.join(OUT, "discretize_small.npz"), **o)
+    print("discretize_small.npz: mins", np.array(mins).min(), "maxs", np.array(maxs).max())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "surface":
+        make_surface_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "discretize":
+        make_discretize_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rgb4":
         make_rgb4_chain()
         sys.exit(0)
@@ -504,3 +685,5 @@ if __name__ == "__main__":
     make_model_and_chains()
     make_rgb4_chain()
     make_bits_fixture()
+    make_surface_fixture()
+    make_discretize_fixture()

@@ -206,6 +206,79 @@ def test_tiling_and_container_round_trip():
     assert (st, nb, hh, ww) == ([33, 44, (7 << 32) | 5], 6, 64, 96)               # demo_decompress.py:221-227
 
 
+def test_demo_surface_matches_reference_files(golden, tmp_path):
+    """The on-disk surface against files the REFERENCE wrote (tests/golden/make_golden.py::make_surface_fixture runs
+    the reference's own extract_blocks, demo_compress.compress and demo_decompress.decompress): our tiling gives the
+    same blocks; our Model + lock-step schedule + oracle, untethered, produce the SAME container words
+    (demo_compress.py:159-160,272-283) and the same .npy bytes; reading the reference's container
+    (demo_decompress.py:221-227) and decoding it returns the image; the per-experiment pickle
+    (mnist_compress.py:265-267) is byte-identical."""
+    import pickle
+    g = golden("demo_surface.npz")
+    q = int(g["cfg"][7])
+    blocks, h, w = tiling.extract_blocks(g["image"])
+    assert np.array_equal(blocks, g["blocks"]) and [h, w] == g["hw"].tolist()
+    assert np.array_equal(tiling.unextract_blocks(blocks, h, w), g["crop"])
+    model = load_golden_model(g, conditional_gen_std=True).fold()
+    zend, _, zcen = chain_tables(g)
+    setup = (model, torch.from_numpy(zend), torch.from_numpy(zcen), torch.device("cpu"))
+    # with OUR deterministic CDF the chain follows the reference's word for word until the first table entry where
+    # torch's sigmoid and ours round differently (about 0.1 ppm of the entries: SURVEY 7a); from there on it is a
+    # different, equally long chain.  Same start of the kept words, same trailer, a length within sampling noise.
+    (state, min_words, bpd), = cli.compress_images([blocks], quantbits=q, nz=model.nz, setup=setup,
+                                                   backend=OracleBackend(O.MODE_DET))
+    arr = container.pack(state, min_words, len(blocks), h, w)
+    ref = g["container"]
+    assert arr[-3:].tolist() == ref[-3:].tolist() and abs(len(arr) - len(ref)) <= 64
+    same = int(np.argmin(arr[: min(len(arr), len(ref))] == ref[: min(len(arr), len(ref))]))
+    assert same >= 1000 or np.array_equal(arr, ref)                # at least the whole first block (905 words)
+    # with the reference's formula evaluated by torch itself the words are the reference's, all of them -- provided this
+    # torch build rounds its float64 sigmoid like the one that wrote the fixture
+    probe = torch.sigmoid(torch.from_numpy(np.random.RandomState(99).uniform(-40, 40, 1 << 16))).numpy()
+    if not np.array_equal(probe, g["sigmoid_probe"]):
+        pytest.skip("this torch build rounds float64 sigmoid differently from the one that generated the fixture")
+    ob = OracleBackend(O.MODE_TORCH)
+    (state, min_words, bpd), = cli.compress_images([blocks], quantbits=q, nz=model.nz, setup=setup, backend=ob)
+    arr = container.pack(state, min_words, len(blocks), h, w)
+    assert arr.dtype == np.uint32 and np.array_equal(arr, g["container"])
+    np.save(tmp_path / "img_bitswap", arr)
+    assert open(tmp_path / "img_bitswap.npy", "rb").read() == g["container_npy"].tobytes()
+    assert abs(bpd - 32 * (len(arr) - 5 + 1) / (len(blocks) * 3072)) < 0.05     # (len(state) - (len(restbits)-1)) words
+    # the receiver on the reference's file
+    st, nb, hh, ww = container.unpack(np.load(tmp_path / "img_bitswap.npy"))
+    assert (nb, hh, ww) == (len(blocks), h, w) and st == words_to_state(g["state_words"])
+    out, rest = cli.decompress_image(st, nb, quantbits=q, nz=model.nz, setup=setup, backend=ob)
+    assert np.array_equal(tiling.unextract_blocks(out, hh, ww), g["crop"])
+    assert rest == words_to_state(g["rest_words"]) == reference_init_state()[min_words:]
+    # experiment pickles
+    assert pickle.loads(g["state_pickle"].tobytes()) == st
+    container.save_state(tmp_path / "exp1", st)
+    assert open(tmp_path / "exp1", "rb").read() == g["state_pickle"].tobytes()
+    assert container.load_state(tmp_path / "exp1") == st
+
+
+def test_discretize_replays_reference_sampling(golden):
+    """bins.discretize driven with the reference's noise and data order (tests/golden/make_golden.py::
+    make_discretize_fixture replays discretization.py:55-83 around the imported reference pieces): on the CPU, where our
+    Model is bitwise the reference's, the float16 samples -- hence the per-dimension minima/maxima and all bins -- are
+    identical."""
+    g = golden("discretize_small.npz")
+    cfg = g["cfg"]
+    nz, q = int(cfg[1]), int(cfg[7])
+    model = load_golden_model(g)
+    torch.manual_seed(int(g["noise_seed"]))
+    eps = lambda shape: rand.logistic_eps(shape, device="cpu", bound=1e-30)
+    ze, zc = bins.discretize(nz, q, torch.float64, "cpu", model, "toy", data=torch.from_numpy(g["images"]), ppb=2,
+                             save=False, cache_dir="/nonexistent", eps_fn=eps, order=g["order"])
+    K = 1 << q
+    for zi in range(nz - 1):
+        e, c = bins.uniform_bins(g["z_mins"][zi], g["z_maxs"][zi], q)
+        assert np.array_equal(ze[zi].numpy(), e) and np.array_equal(zc[zi].numpy(), c)
+    assert np.array_equal(ze[0, 5].numpy(), g["zend_layer0_dim5"]) and np.array_equal(zc[0, 5].numpy(), g["zcen_layer0_dim5"])
+    assert np.array_equal(ze[nz - 1, 0].numpy(), g["z_top_endpoints"])
+    assert np.array_equal(zc[nz - 1, 3].numpy(), g["z_top_centres"]) and ze.shape == (nz, 512, K - 1)
+
+
 def test_demo_image_path_with_trimmed_container():
     ob = OracleBackend(O.MODE_DET)
     setup = cli.crop_setup(-1, nz=2, quantbits=6, backend=ob, small=8)
