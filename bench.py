@@ -4,6 +4,7 @@
     python bench.py [--gpus N --steps K --warmup W] [--workload cifar8|imagenet4|mnist2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N            (no torchrun: spawns the N ranks itself)
 
 One step = one 32x32 block of every chain coded in lock-step, sender AND receiver: the timed
 region runs K sender block-steps followed by the K receiver block-steps that undo them, bracketed
@@ -12,14 +13,19 @@ chains (weak scaling: chains never talk to each other; the only collective is th
 finished bitstreams, outside the timed region).  The inputs (blocks, weights, bins, initial
 stacks) are resident in HBM before the timed region starts.
 
-Default workload = BASELINE.json configs[1]: CIFAR-10-shaped 8-latent-layer Bit-Swap model
-(reswidth 252, Z = 2048, X = 3072, K = 1024 / 256), 100 chains, synthetic data and seeded
-random-init weights (no datasets/checkpoints offline).
+Headline workload = BASELINE.json configs[1]: CIFAR-10-shaped 8-latent-layer Bit-Swap model
+(reswidth 252, Z = 2048, X = 3072, K = 1024 / 256), synthetic data and seeded random-init weights
+(no datasets/checkpoints offline).  At N = 1 the same JSON line also carries, under `extra`, the
+ImageNet32 nz=4 shape north_star quotes its target on (configs[2]) and the reference's own 100-chain
+shape (100 "experiments"), each measured by the same procedure with fewer steps.
 
 Extra objects on the JSON line: `roofline` for the dominant hot-path kernel (the fused
 logistic-CDF -> integer-table kernel, decode flavour) from HIP events recorded on the launch stream
-inside the timed region, and `cpu_baseline`: the oracle (C restatement of the reference, libm CDF)
-+ the same conv stacks on the host cores, timed on a bounded sample of the same workload.
+inside the timed region -- per kernel against HBM as the contract asks, plus the whole-path fraction
+ and the VALU-issue fraction the kernel is really bound by -- and `cpu_baseline`: the
+oracle (C restatement of the reference, libm CDF) + the same conv stacks on the host cores, timed on a
+bounded sample of the same workload, next to the committed measurement of the reference's own Python
+path (profiles/r02_ref_cpu_baseline.json, tools/ref_cpu_baseline.py).
 """
 import argparse
 import json
@@ -34,6 +40,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU issue model of k_logistic (the bound it actually runs into): 256 CUs x 4 SIMDs, one 64-lane VALU instruction
+# occupies a 16-lane SIMD for 4 cycles (v_rcp_f64: 16), 2.4 GHz nominal -> 614.4 G wave-instructions / s
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
+# issue slots per (chain, dim) row of the K = 1024 decode-flavour kernel, from `tools/isa_count.py` on the shipped
+# code object: VALU instructions in the per-row loop + 3 extra slots per quarter-rate v_rcp_f64
+VALU_SLOTS_PER_ROW = {2: 469, 1: 692}   # CDF spec 2 (uniform bins) / spec 1
+
+TITLES = {"mnist2": "MNIST-shaped 2-latent-layer", "cifar8": "CIFAR-10-shaped 8-latent-layer",
+          "imagenet4": "ImageNet32-shaped 4-latent-layer", "imagenetcrop4": "ImageNet-crop-shaped 4-latent-layer"}
 
 
 def parse():
@@ -55,6 +70,7 @@ def parse():
                     help="chain groups per GPU on separate HIP streams (serial rANS of one group under the convs of another)")
     ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
                     help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
+    ap.add_argument("--cdf-spec", type=int, default=2, choices=[1, 2])
     return ap.parse_args()
 
 
@@ -80,44 +96,37 @@ def cpu_baseline(args, name):
     outs = [codec.decode_block(state) for _ in range(n)]
     dt = time.perf_counter() - t0
     ok = all(torch.equal(outs[n - 1 - xi], images[:, xi]) for xi in range(n))
-    return {"value": B * n * 1024 / dt, "unit": "pixels/s", "cores": threads, "kind": "port",
-            "sample": f"{B} chains x {n} block(s) of {name}, sender+receiver, oracle C (libm CDF) + torch-CPU convs, "
-                      f"{dt:.1f} s, lossless={ok}"}
+    out = {"value": B * n * 1024 / dt, "unit": "pixels/s", "cores": threads, "kind": "port",
+           "sample": f"{B} chains x {n} block(s) of {name}, sender+receiver, oracle C (libm CDF) + torch-CPU convs, "
+                     f"{dt:.1f} s, lossless={ok}"}
+    # the reference's own Python path (mnist_compress.py:164-358 replayed around the imported reference classes) cannot
+    # travel to the GPU box; its committed measurement rides along, labelled with where it was taken
+    rp = os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json")
+    if os.path.exists(rp):
+        try:
+            out["reference_python"] = json.load(open(rp))
+        except Exception:
+            pass
+    return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        import datetime
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # BENCH_DIST_BACKEND=gloo lets the control flow be exercised with several ranks on ONE device
-        # (RCCL refuses two ranks per GPU); the driver never sets it
-        dist.init_process_group(os.environ.get("BENCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo"),
-                                timeout=datetime.timedelta(seconds=300))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the coding path has no CPU fallback)")
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    torch.backends.cudnn.deterministic = True
-    torch.backends.cudnn.benchmark = False
+def algorithmic_bytes_per_block(codec):
+    """SURVEY.md 8(d), one direction: per z-table op (2nz-1 of them) Z(K-1)8 + 2Z4 + Z4; x-op 2X4 + X; prior Z(8+4)."""
+    Z, X, K, nz = codec.Z, codec.X, codec.K, codec.codecs[0].nz
+    return (2 * nz - 1) * (Z * (K - 1) * 8 + 2 * Z * 4 + Z * 4) + (2 * X * 4 + X) + Z * 12
 
-    from bitswap_amd import hip, workload
+
+def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gather=False):
+    """One measurement by the contract's procedure.  Returns a dict (timings are max over ranks)."""
+    from bitswap_amd import workload
     from bitswap_amd.codec import GroupedCodec, Timeline, initial_states
 
-    name = args.workload
     model, zend, zcen = workload.build(name, dev, quantbits=args.quantbits)
-    B, K, W = args.chains, args.steps, args.warmup
     n = K + W
     images = workload.synthetic_blocks(B * n, model.xs, seed=1000 + rank).view(B, n, -1).to(torch.int32).to(dev)
     tl = Timeline(enabled=not args.no_timeline)
-    codec = GroupedCodec(model, zend, zcen, groups=args.groups, quantbits=args.quantbits, bitswap=bool(args.bitswap),
-                         timeline=tl)
+    codec = GroupedCodec(model, zend, zcen, groups=groups, quantbits=args.quantbits, bitswap=bool(args.bitswap),
+                         timeline=tl, cdf_spec=args.cdf_spec)
     for c in codec.codecs:
         c.tables_on = args.tables_on
     init = initial_states(B, 10000, seed=100 + rank)
@@ -141,7 +150,7 @@ def main():
     codec.encode_blocks(states, images[:, W:], rest_lens if W == 0 else None)
     len_sent = torch.cat([st.len for st in states]).clone()
     # the finished bitstreams (what a sender would ship): device-side snapshot, gathered after the clock stops
-    sent = [(st.stack.clone(), st.len.clone(), st.head.clone()) for st in states]
+    sent = [(st.stack.clone(), st.len.clone(), st.head.clone()) for st in states] if want_gather else None
     decoded = codec.decode_blocks(states, K)
     barrier()
     dt = time.perf_counter() - t0
@@ -159,44 +168,41 @@ def main():
 
     # ---- the path's only exchange (not timed): gather of the finished bitstreams to rank 0 and two scalars
     # for bits/dim -- RCCL over xGMI when world > 1 (bitswap_amd/dist.py), a local no-op otherwise
-    from bitswap_amd import dist as bdist
     gather = None
-    try:
-        streams = []
-        for stack, ln, hd in sent:
-            stack, ln, hd = stack.cpu().numpy().view(np.uint32), ln.cpu().numpy(), hd.cpu().numpy().view(np.uint64)
-            for b in range(stack.shape[0]):   # stream = stack words + the 64-bit head as two words (demo container order)
-                streams.append(np.concatenate([stack[b, : ln[b]], np.array([hd[b] & 0xffffffff, hd[b] >> 32], dtype=np.uint32)]))
-        mine = [rank + world * c for c in range(B)]            # global chain ids, round-robin like shard_chains()
-        tg = time.perf_counter()
-        got = bdist.gather_streams(streams, mine, world * B)
-        tg = time.perf_counter() - tg
-        if rank == 0:
-            words = int(sum(len(a) for a in got))
-            gather = {"chains": len(got), "bytes": 4 * words, "ms": round(tg * 1e3, 2),
-                      "complete": all(a is not None for a in got),
-                      "own_streams_intact": all(np.array_equal(got[c], a) for c, a in zip(mine, streams))}
-    except Exception as e:   # never lose the bench line to the reporting exchange
-        gather = {"error": repr(e)}
+    if want_gather:
+        from bitswap_amd import dist as bdist
+        try:
+            streams = []
+            for stack, ln, hd in sent:
+                stack, ln, hd = stack.cpu().numpy().view(np.uint32), ln.cpu().numpy(), hd.cpu().numpy().view(np.uint64)
+                for b in range(stack.shape[0]):   # stream = stack words + the 64-bit head as two words (demo container order)
+                    streams.append(np.concatenate([stack[b, : ln[b]], np.array([hd[b] & 0xffffffff, hd[b] >> 32], dtype=np.uint32)]))
+            mine = [rank + world * c for c in range(B)]            # global chain ids, round-robin like shard_chains()
+            tg = time.perf_counter()
+            got = bdist.gather_streams(streams, mine, world * B)
+            tg = time.perf_counter() - tg
+            if rank == 0:
+                words = int(sum(len(a) for a in got))
+                gather = {"chains": len(got), "bytes": 4 * words, "ms": round(tg * 1e3, 2),
+                          "complete": all(a is not None for a in got),
+                          "own_streams_intact": all(np.array_equal(got[c], a) for c, a in zip(mine, streams))}
+        except Exception as e:   # never lose the bench line to the reporting exchange
+            gather = {"error": repr(e)}
     if dist is not None:
         tot = torch.tensor([float(bits.sum()), float(B * K * codec.X), float(ok)], device=dev, dtype=torch.float64)
         dist.all_reduce(tot)
         bpd = float(tot[0] / tot[1])
         ok = bool(tot[2].item() == world)
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
     totals = tl.totals()
     roof = None
-    if "tables_z" in totals:
+    if "tables_z" in totals and totals["tables_z"][1]:
         sec, cnt = totals["tables_z"]
         Kb, Z = codec.K, codec.Z
-        rows = B * Z / max(1, args.groups)                # rows one launch processes (one chain group)
+        rows = B * Z / max(1, groups)                     # rows one launch processes (one chain group)
         alg = int(rows * ((Kb - 1) * 8 + 2 * 4 + 4))      # endpoints f64 + mu,scale f32 + symbol i32
-        ach = alg / (sec / cnt) / 1e9
+        avg = sec / cnt
+        ach = alg / avg / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
@@ -205,11 +211,80 @@ def main():
                 traffic = None if per_row is None else int(per_row * rows)   # PMC bytes/row x rows of one launch
             except Exception:
                 traffic = None
-        roof = {"kernel": "k_logistic<16,float,decode> (fused logistic CDF -> integer cdf rows)", "bound": "hbm",
+        a_block = algorithmic_bytes_per_block(codec)
+        path = 2.0 * a_block * world * B * K / dt / 1e9
+        spec = args.cdf_spec if any(s is not None for s in codec.codecs[0].zstep) else 1
+        slots = VALU_SLOTS_PER_ROW[spec] if Kb == 1024 else None
+        roof = {"kernel": f"k_logistic<16,float,decode,{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> integer cdf "
+                          f"rows, CDF spec {spec})", "bound": "hbm",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "launches": cnt, "avg_launch_ms": round(sec / cnt * 1e3, 4),
-                "alg_bytes_per_launch": alg}
+                "traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg * 1e3, 4),
+                "alg_bytes_per_launch": alg,
+                # whole path, SURVEY.md 8(d): 2 * A_block * n_blocks / (t_sender + t_receiver) against the same peak
+                "path_alg_bytes_per_block": a_block, "path_achieved": round(path / world, 1),
+                "path_frac": round(path / world / HBM_PEAK_GBPS, 4),
+                # what bounds the kernel: float64 / integer VALU issue (the endpoint rows are L2 hits, the bytes above
+                # are mostly not moved: see `traffic`)
+                "valu_issue": None if slots is None else {
+                    "slots_per_row": slots, "achieved_Ginstr_s": round(rows * slots / avg / 1e9, 1),
+                    "peak_Ginstr_s": round(VALU_PEAK_GINSTR, 1), "frac": round(rows * slots / avg / 1e9 / VALU_PEAK_GINSTR, 4)}}
     breakdown = {k: round(v[0] / dt, 4) for k, v in sorted(totals.items())} if totals else None
+    res = {"workload": name, "chains_per_gpu": B, "chain_groups": groups, "steps": K, "warmup": W,
+           "value": world * B * K * 1024 / dt, "ms_per_step": dt / K * 1e3, "lossless": ok, "bits_per_dim": bpd,
+           "stream_time_fraction": breakdown, "roofline": roof, "stream_gather": gather,
+           "codec": codec, "model": model}
+    return res
+
+
+def main(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the coding path has no CPU fallback)")
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        # BENCH_DIST_BACKEND=gloo lets the control flow be exercised with several ranks on ONE device
+        # (RCCL refuses two ranks per GPU); the driver never sets it
+        dist.init_process_group(os.environ.get("BENCH_DIST_BACKEND") or "nccl", timeout=datetime.timedelta(seconds=300))
+
+    name = args.workload
+    r = run_workload(args, name, args.chains, args.groups, args.steps, args.warmup, dev, rank, world, dist, want_gather=True)
+    codec, model = r.pop("codec"), r.pop("model")
+    conv_path = (f"{model.conv_algo} (fp32; ResNet/head convs as transform-domain batched GEMMs, BLAS backend "
+                 f"{model.gemm_backend})" if getattr(model, "fused", False) else "torch modules")
+    Z, X = codec.Z, codec.X
+    del codec, model
+
+    extra = None
+    if world == 1 and not args.no_extra and name == "cifar8":
+        # driver-visible numbers for the other shapes DESIGN.md quotes: north_star's target config and the reference's
+        # 100-experiment shape, same procedure, fewer steps
+        extra = []
+        ks, ws = min(args.steps, 6), min(args.warmup, 1)
+        for (wn, ch, gr) in (("imagenet4", 800, 2), ("cifar8", 100, 1)):
+            torch.cuda.empty_cache()
+            try:
+                e = run_workload(args, wn, ch, gr, ks, ws, dev, rank, world, dist)
+                e.pop("codec"), e.pop("model"), e.pop("stream_gather")
+                e["value"], e["ms_per_step"] = round(e["value"], 1), round(e["ms_per_step"], 3)
+                e["bits_per_dim"] = round(e["bits_per_dim"], 4)
+                e["config"] = f"{TITLES[wn]} {'Bit-Swap' if args.bitswap else 'BB-ANS'}, {ch} chains / {gr} group(s)"
+                extra.append(e)
+            except Exception as ex:   # a sub-result never costs the headline
+                extra.append({"workload": wn, "chains_per_gpu": ch, "error": repr(ex)})
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
@@ -218,27 +293,46 @@ def main():
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             cpu = {"value": None, "unit": "pixels/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
 
-    value = world * B * K * 1024 / dt
     out = {
-        "metric": "pixels/s (encode+decode)", "value": round(value, 1), "unit": "pixels/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
+        "metric": "pixels/s (encode+decode)", "value": round(r["value"], 1), "unit": "pixels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": {"mnist2": "MNIST-shaped 2-latent-layer", "cifar8": "CIFAR-10-shaped 8-latent-layer",
-                                "imagenet4": "ImageNet32-shaped 4-latent-layer",
-                                "imagenetcrop4": "ImageNet-crop-shaped 4-latent-layer"}[name] +
-                               f" {'Bit-Swap' if args.bitswap else 'BB-ANS'}, batch of 32x32 blocks",
-                   "chains_per_gpu": B, "chain_groups": args.groups, "blocks_per_chain": K, "quantbits": args.quantbits, "ansbits": 31,
-                   "latent_dims": codec.Z, "pixel_dims": codec.X, "conv_dtype": "f32",
-                   "conv_path": (f"{model.conv_algo} (fp32; ResNet/head convs as transform-domain batched GEMMs, "
-                                 f"BLAS backend {model.gemm_backend})" if getattr(model, "fused", False) else "torch modules"),
+        "config": {"workload": TITLES[name] + f" {'Bit-Swap' if args.bitswap else 'BB-ANS'}, batch of 32x32 blocks",
+                   "chains_per_gpu": args.chains, "chain_groups": args.groups, "blocks_per_chain": args.steps,
+                   "quantbits": args.quantbits, "ansbits": 31, "cdf_spec": args.cdf_spec,
+                   "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32", "conv_path": conv_path,
                    "weights": "seeded random init (no checkpoints offline)"},
-        "lossless": ok, "bits_per_dim": round(bpd, 4), "stream_time_fraction": breakdown,
-        "roofline": roof, "cpu_baseline": cpu, "stream_gather": gather,
+        "lossless": r["lossless"], "bits_per_dim": round(r["bits_per_dim"], 4),
+        "stream_time_fraction": r["stream_time_fraction"],
+        "roofline": r["roofline"], "cpu_baseline": cpu, "stream_gather": r["stream_gather"], "extra": extra,
     }
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
+def _spawned(rank, args, world, port):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    main(args)
+
+
 if __name__ == "__main__":
-    main()
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched without torchrun: start the N ranks ourselves, one process per GPU -- never measure one GPU and call
+        # it N (with BENCH_DIST_BACKEND=gloo the ranks may share a device: control-flow tests only)
+        import socket
+        import torch.multiprocessing as mp
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus and not os.environ.get("BENCH_DIST_BACKEND"):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible")
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_spawned, args=(args, args.gpus, port), nprocs=args.gpus, join=True)
+    else:
+        if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and "WORLD_SIZE" in os.environ:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: using WORLD_SIZE", file=sys.stderr)
+        main(args)
