@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
                     help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
     ap.add_argument("--cdf-spec", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--format", default="reference", choices=["reference", "wave64"],
+                    help="reference: the reference's single-state word stream (default, the headline); wave64: the opt-in "
+                         "64-state format -- table + coding step fused in one launch, one stream (implies --groups 1)")
     return ap.parse_args()
 
 
@@ -125,8 +128,12 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     n = K + W
     images = workload.synthetic_blocks(B * n, model.xs, seed=1000 + rank).view(B, n, -1).to(torch.int32).to(dev)
     tl = Timeline(enabled=not args.no_timeline)
+    backend = None
+    if args.format == "wave64":
+        from bitswap_amd.codec import Hip64Backend
+        backend, groups = Hip64Backend(dev), 1
     codec = GroupedCodec(model, zend, zcen, groups=groups, quantbits=args.quantbits, bitswap=bool(args.bitswap),
-                         timeline=tl, cdf_spec=args.cdf_spec)
+                         timeline=tl, cdf_spec=args.cdf_spec, backend=backend)
     for c in codec.codecs:
         c.tables_on = args.tables_on
     init = initial_states(B, 10000, seed=100 + rank)
@@ -150,7 +157,8 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     codec.encode_blocks(states, images[:, W:], rest_lens if W == 0 else None)
     len_sent = torch.cat([st.len for st in states]).clone()
     # the finished bitstreams (what a sender would ship): device-side snapshot, gathered after the clock stops
-    sent = [(st.stack.clone(), st.len.clone(), st.head.clone()) for st in states] if want_gather else None
+    sent = ([(st.stack.clone(), st.len.clone(), st.head.clone()) for st in states]
+            if (want_gather and args.format == "reference") else None)
     decoded = codec.decode_blocks(states, K)
     barrier()
     dt = time.perf_counter() - t0
@@ -162,14 +170,19 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     # ---- verification (outside the timed region): lossless + stream fully unwound
     codec.check(states, "bench")
     ok = bool(torch.equal(decoded, images[:, W:]))
-    ok = ok and codec.to_lists(states) == init
-    bits = (len_sent.cpu().numpy().astype(np.int64) - np.array([len(s) - 1 for s in init])) * 32
+    if args.format == "wave64":
+        from bitswap_amd.hip import split_state
+        ok = ok and codec.to_lists(states) == [split_state(s) for s in init]
+        bits = (len_sent.cpu().numpy().astype(np.int64) - np.array([len(s) - 64 for s in init])) * 32
+    else:
+        ok = ok and codec.to_lists(states) == init
+        bits = (len_sent.cpu().numpy().astype(np.int64) - np.array([len(s) - 1 for s in init])) * 32
     bpd = float(bits.sum()) / (B * K * codec.X)
 
     # ---- the path's only exchange (not timed): gather of the finished bitstreams to rank 0 and two scalars
     # for bits/dim -- RCCL over xGMI when world > 1 (bitswap_amd/dist.py), a local no-op otherwise
     gather = None
-    if want_gather:
+    if sent is not None:
         from bitswap_amd import dist as bdist
         try:
             streams = []
@@ -264,7 +277,7 @@ def main(args):
     del codec, model
 
     extra = None
-    if world == 1 and not args.no_extra and name == "cifar8":
+    if world == 1 and not args.no_extra and name == "cifar8" and args.format == "reference":
         # driver-visible numbers for the other shapes DESIGN.md quotes: north_star's target config and the reference's
         # 100-experiment shape, same procedure, fewer steps
         extra = []
@@ -299,7 +312,7 @@ def main(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": TITLES[name] + f" {'Bit-Swap' if args.bitswap else 'BB-ANS'}, batch of 32x32 blocks",
                    "chains_per_gpu": args.chains, "chain_groups": args.groups, "blocks_per_chain": args.steps,
-                   "quantbits": args.quantbits, "ansbits": 31, "cdf_spec": args.cdf_spec,
+                   "quantbits": args.quantbits, "ansbits": 31, "cdf_spec": args.cdf_spec, "stream_format": args.format,
                    "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32", "conv_path": conv_path,
                    "weights": "seeded random init (no checkpoints offline)"},
         "lossless": r["lossless"], "bits_per_dim": round(r["bits_per_dim"], 4),

@@ -219,34 +219,52 @@ def crop_setup(gpu, nz=4, quantbits=10, synthetic=False, params=None, outdir="."
     return model, zend, zcen, dev
 
 
+def _format_backend(fmt, backend, dev):
+    """fmt "reference": the reference's single-state stream (HipBackend unless a backend is injected);
+    "wave64": the opt-in 64-state format (Hip64Backend)."""
+    if fmt not in ("reference", "wave64"):
+        raise ValueError(f"unknown stream format {fmt!r}")
+    if backend is None and fmt == "wave64":
+        from .codec import Hip64Backend
+        return Hip64Backend(dev)
+    return backend
+
+
 def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_quirk=False, setup=None, backend=None,
-                    trim=True):
+                    trim=True, fmt="reference"):
     """images_blocks: list of [n_i, 32, 32, 3] uint8 block arrays (one per image; every image is a
     chain, imagenetcrop_compress.py:279-300).  Chains of different length run in lock-step and
-    drop out as they finish.  Returns (list of state lists, list of min_words, bits/dim per image)."""
+    drop out as they finish.  Returns per image (state list, min_words, bits/dim); in the 64-state format the state is
+    a list of 64 sub-state lists and min_words a list of 64."""
     model, zend, zcen, dev = setup
     flat = [torch.from_numpy((tiling.blocks_to_hwc_flat(b) if hwc_quirk else tiling.blocks_to_chw_flat(b)).astype(np.int32))
             for b in images_blocks]
-    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap), backend=backend)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
+                         backend=_format_backend(fmt, backend, dev))
     np.random.seed(100)   # every image starts from the same 'random' stack (imagenetcrop_compress.py:249,122)
     nmax = max(len(f) for f in flat)
     one = initial_states(1, 10000, seed=100)[0]
     state = codec.new_states(len(flat), nmax, states=[list(one) for _ in flat])
-    state.min_len = state.len.clone()
+    state.min_len = (state.len64 if hasattr(state, "len64") else state.len).clone()
     state, order, met = codec.compress_ragged(flat, state=state)
-    mins = state.min_len.cpu().tolist() if getattr(state, "min_len", None) is not None else [0] * len(flat)
+    mins = state.min_len.cpu().tolist()
     lists = state.to_lists()
     results = [None] * len(flat)
     for k, i in enumerate(order):
-        results[i] = (lists[k], int(mins[k]) if trim else 0, float(met["cma"][k]))
+        m = mins[k]
+        m = ([int(v) if trim else 0 for v in m] if isinstance(m, list) else (int(m) if trim else 0))
+        results[i] = (lists[k], m, float(met["cma"][k]))
     return results
 
 
 def decompress_image(state, nblocks, quantbits=10, nz=4, gpu=0, setup=None, backend=None, hwc_quirk=False):
-    """demo_decompress.decompress (:69-148): -> [nblocks, 32, 32, 3] uint8 blocks."""
+    """demo_decompress.decompress (:69-148): -> [nblocks, 32, 32, 3] uint8 blocks.  A state that is a list of 64
+    sub-state lists (container.unpack64) is decoded in the 64-state format."""
     model, zend, zcen, dev = setup
-    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=True, backend=backend)
-    st = codec.backend.new_state([list(state)], len(state) + nblocks * (model.xdim + 64) + 4 * model.zdim_flat)
+    fmt = "wave64" if isinstance(state[0], (list, tuple)) else "reference"
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=True, backend=_format_backend(fmt, backend, dev))
+    nwords = sum(len(s) for s in state) if fmt == "wave64" else len(state)
+    st = codec.backend.new_state([list(state)], nwords + nblocks * (model.xdim + 64) + 4 * model.zdim_flat)
     out = codec.decompress(st, nblocks)[0].cpu().numpy()
     if hwc_quirk:
         return out.reshape(nblocks, 32, 32, 3).astype(np.uint8), st.to_lists()[0]

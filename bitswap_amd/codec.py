@@ -82,6 +82,49 @@ class HipBackend:
         state.check(what)
 
 
+class _LazyTable:
+    """What Hip64Backend.tables() hands to its pop(): the arguments of the fused kernel, not a table."""
+
+    def __init__(self, endpoints, mu, scale, quantbits, step):
+        self.endpoints, self.mu, self.scale, self.quantbits, self.step = endpoints, mu, scale, quantbits, step
+
+
+class Hip64Backend(HipBackend):
+    """The opt-in 64-state stream format (BS_FORMAT_WAVE64, include/bitswap_hip.h): every chain owns 64 rANS states and
+    each coding operation is ONE launch that builds the integer table rows in registers and codes on them
+    (bs_layer_pop64 / bs_layer_push64) -- no cdf rows in HBM, no serial kernels, nothing to overlap, so it is used with
+    a single stream (GroupedCodec(groups=1)).  Streams are not the reference's (64 heads per chain instead of one)."""
+
+    name = "hip-wave64"
+
+    def new_state(self, states, cap):
+        """cap: word capacity the caller wants for a whole chain; a state gets its share of the head-room on top of
+        the longest state present (trimmed containers come back with uneven states)."""
+        nested = [s if isinstance(s[0], (list, tuple)) else hip.split_state(s) for s in states]
+        total = max(sum(len(sub) - 1 for sub in ch) for ch in nested)
+        longest = max(len(sub) - 1 for ch in nested for sub in ch)
+        cap64 = longest + max(int(cap) - total, 0) // hip.NSTATES + 64
+        return hip.RansState64.from_lists(nested, cap=cap64, device=self.device)
+
+    def table_buffer(self, B, D, K):
+        return None
+
+    def tables(self, endpoints, mu, scale, quantbits, bits, out=None, step=None, status=None):
+        return _LazyTable(endpoints, mu, scale, quantbits, step)
+
+    def shared_table(self, endpoints, mu, scale, quantbits, bits, step=None):
+        return _LazyTable(endpoints, mu[0].contiguous(), scale[0].contiguous(), quantbits, step)
+
+    def pop(self, state, t, K, bits, centres=None):
+        return hip.layer_pop64(state, t.endpoints, t.mu, t.scale, bits, t.quantbits, centres=centres, step=t.step)
+
+    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
+        hip.layer_push64(state, endpoints, mu, scale, sym, bits, quantbits, step=step)
+
+    def push_table(self, state, t, sym, K, bits):
+        hip.layer_push64(state, t.endpoints, t.mu, t.scale, sym, bits, t.quantbits, step=t.step)
+
+
 def initial_states(nchains, nwords=10000, seed=100):
     """The reference's stream initialisation (mnist_compress.py:94,158-159): numpy seeded once with
     100, then 10000 'random' uint32 words per experiment, the last shifted up to form the head."""
@@ -255,10 +298,12 @@ class BitSwapCodec:
         words, demo_compress.py:133,159-160).  Enabled by giving the state a `min_len` tensor."""
         ml = getattr(state, "min_len", None)
         if ml is not None:
-            torch.minimum(ml, state.len.to(ml.device), out=ml)
+            cur = getattr(state, "len64", None)          # 64-state format: every state has its own low-water mark
+            cur = state.len if cur is None or ml.dim() == 1 else cur
+            torch.minimum(ml, cur.to(ml.device), out=ml)
 
     def _push_layer(self, state, endpoints, mu, scale, sym, quantbits, key, step=None):
-        if self.serial is None:
+        if self.serial is None or not isinstance(self.backend, HipBackend) or isinstance(self.backend, Hip64Backend):
             with self.tl.span("push_" + key):
                 self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits, step=step)
             return

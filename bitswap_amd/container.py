@@ -4,6 +4,9 @@
   `[stack words that were touched ..., head_lo, head_hi, nblocks, h, w]`; initial words that were
   never popped are trimmed (`del state[0:excess_state_len - 1]`).
 * experiment bitstreams (mnist_compress.py:265-272): the Python list `state` pickled as is.
+* 64-state container (opt-in BS_FORMAT_WAVE64 streams, no reference counterpart): a uint32 .npy
+  `[MAGIC64, version, 64, n_0 .. n_63, kept words of state 0, ..., of state 63, (head_lo, head_hi) x 64, nblocks, h, w]`;
+  the same trimming rule as the reference's container, applied per state.
 """
 import pickle
 
@@ -28,6 +31,49 @@ def unpack(arr):
     hi, lo = vals.pop(), vals.pop()
     vals.append(hi << 32 | lo)
     return vals, nblocks, h, w
+
+
+MAGIC64 = 0x36575342     # "BSW6"
+VERSION64 = 1
+
+
+def pack64(state, min_words, nblocks, h, w):
+    """state: 64 sub-state lists [w0 .. w_{n-1}, head]; min_words: per state the fewest stack words it ever held."""
+    assert len(state) == 64 and len(min_words) == 64
+    kept = [list(sub[:-1][m:]) for sub, m in zip(state, min_words)]
+    out = [MAGIC64, VERSION64, 64] + [len(k) for k in kept]
+    for k in kept:
+        out += k
+    for sub in state:
+        out += [sub[-1] & 0xFFFFFFFF, sub[-1] >> 32]
+    return np.array(out + [nblocks, h, w], dtype=np.uint32)
+
+
+def is_pack64(arr):
+    arr = np.asarray(arr)
+    if arr.dtype != np.uint32 or len(arr) < 3 + 64 + 128 + 3 or int(arr[0]) != MAGIC64 or int(arr[2]) != 64:
+        return False
+    return 3 + 64 + int(arr[3:67].astype(np.int64).sum()) + 128 + 3 == len(arr)
+
+
+def unpack64(arr):
+    """-> (64 sub-state lists, nblocks, h, w)"""
+    arr = np.asarray(arr)
+    if not is_pack64(arr):
+        raise ValueError("not a 64-state Bit-Swap container")
+    if int(arr[1]) != VERSION64:
+        raise ValueError(f"64-state container version {int(arr[1])} not supported")
+    vals = [int(v) for v in arr.tolist()]
+    ns = vals[3:67]
+    off = 67
+    subs = []
+    for n in ns:
+        subs.append(vals[off: off + n])
+        off += n
+    for j in range(64):
+        subs[j].append(vals[off + 2 * j] | (vals[off + 2 * j + 1] << 32))
+    nblocks, h, w = vals[-3:]
+    return subs, nblocks, h, w
 
 
 def save_state(path, state):

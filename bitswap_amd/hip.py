@@ -18,7 +18,8 @@ LAYOUT_LINEAR, LAYOUT_WAVE = 0, 1
 
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
-    "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres",
+    "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres", "bs_layer_pop64",
+    "bs_layer_push64",
     "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
@@ -59,6 +60,8 @@ def load():
     L.bs_rans_push_table.argtypes = [p, p, p, i64, p, i64, i64, i32, p, i32, i32, i32, i32, p, p]
     L.bs_rans_pop.argtypes = [p, p, p, i64, p, i64, i64, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
     L.bs_gather_centres.argtypes = [p, i64, p, i32, i32, i32, p, p]
+    L.bs_layer_pop64.argtypes = [p, p, p, i64, p, i64, p, p, p, i64, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
+    L.bs_layer_push64.argtypes = [p, p, p, i64, p, i64, p, p, p, i64, i32, p, i32, i32, i32, i32, i32, p, p]
     L.bs_selftest.argtypes = [C.POINTER(C.c_int64), p]
     L.bs_sigmoid_f64.argtypes = [p, i64, p, p]
     L.bs_bias_residual_elu_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
@@ -334,6 +337,128 @@ def rans_pop(state, cdf, K, bits=31, centres=None, B=None, layout=None):
                               chain_stride, ld, layout, B, D, K, bits, _ptr(sym), _ptr(centres), cs, _ptr(z),
                               _ptr(state.status), _stream()), "bs_rans_pop")
     return sym, z
+
+
+# ---- BS_FORMAT_WAVE64: 64 rANS states per chain, table + coding step fused (include/bitswap_hip.h) -----------------
+NSTATES = 64
+
+
+def split_state(s, nstates=NSTATES):
+    """A reference-style state list [w0 .. w_{n-2}, head] (head = last initial word << 32, mnist_compress.py:158-159)
+    dealt round-robin onto `nstates` sub-states of the same form: sub-state j gets the words w[j::nstates], its last
+    one shifted up as its head."""
+    words = list(s[:-1]) + [s[-1] >> 32]
+    out = []
+    for j in range(nstates):
+        sub = words[j::nstates]
+        assert len(sub) >= 2, "too few initial words for the 64-state format"
+        out.append(sub[:-1] + [sub[-1] << 32])
+    return out
+
+
+class RansState64:
+    """B chains x 64 independent rANS states resident in HBM: head [B,64] (uint64 bits in int64), stack [B,64,cap]
+    (uint32 bits in int32), len64 [B,64] int32, status [B] int32."""
+
+    def __init__(self, B, cap, device):
+        self.B, self.cap, self.device = B, int(cap), torch.device(device)
+        self.head = torch.zeros((B, NSTATES), dtype=torch.int64, device=device)
+        self.stack = torch.zeros((B, NSTATES, self.cap), dtype=torch.int32, device=device)
+        self.len64 = torch.zeros((B, NSTATES), dtype=torch.int32, device=device)
+        self.status = torch.zeros(B, dtype=torch.int32, device=device)
+
+    @property
+    def len(self):
+        """Stack words of a chain, all states together [B] (what the bit accounting counts)."""
+        return self.len64.sum(1, dtype=torch.int32)
+
+    def prefix(self, k):
+        if k == self.B:
+            return self
+        v = object.__new__(RansState64)
+        v.B, v.cap, v.device = int(k), self.cap, self.device
+        v.head, v.stack, v.len64, v.status = self.head[:k], self.stack[:k], self.len64[:k], self.status[:k]
+        ml = getattr(self, "min_len", None)
+        if ml is not None:
+            v.min_len = ml[:k]
+        return v
+
+    @classmethod
+    def from_lists(cls, states, cap=None, device="cuda"):
+        """states: per chain either a reference-style list (dealt onto the 64 states by split_state) or a list of 64
+        sub-state lists [w0, ..., head]."""
+        import numpy as np
+        nested = [s if isinstance(s[0], (list, tuple)) else split_state(s) for s in states]
+        B = len(nested)
+        n = max(len(sub) - 1 for ch in nested for sub in ch)
+        cap = max(int(cap or 0), n)
+        st = cls(B, cap, device)
+        stack = np.zeros((B, NSTATES, cap), dtype=np.uint32)
+        head = np.zeros((B, NSTATES), dtype=np.uint64)
+        ln = np.zeros((B, NSTATES), dtype=np.int32)
+        for b, ch in enumerate(nested):
+            assert len(ch) == NSTATES
+            for j, sub in enumerate(ch):
+                k = len(sub) - 1
+                stack[b, j, :k] = np.asarray(sub[:-1], dtype=np.uint64).astype(np.uint32)
+                head[b, j] = sub[-1]
+                ln[b, j] = k
+        st.stack.copy_(torch.from_numpy(stack.view(np.int32)))
+        st.head.copy_(torch.from_numpy(head.view(np.int64)))
+        st.len64.copy_(torch.from_numpy(ln))
+        return st
+
+    def to_lists(self):
+        """-> per chain a list of 64 sub-state lists [w0, ..., head]."""
+        import numpy as np
+        stack = self.stack.cpu().numpy().view(np.uint32)
+        head = self.head.cpu().numpy().view(np.uint64)
+        ln = self.len64.cpu().numpy()
+        return [[[int(w) for w in stack[b, j, : ln[b, j]]] + [int(head[b, j])] for j in range(NSTATES)]
+                for b in range(self.B)]
+
+    check = RansState.check
+
+
+def _layer64_args(state, endpoints, mu, scale, step):
+    B, D = (state.B, endpoints.shape[0]) if mu.dim() == 1 or mu.shape[0] == 1 and state.B != 1 else mu.shape
+    K = endpoints.shape[1] + 1
+    endpoints, es = _row_stride(endpoints, K - 1)
+    step = _step(step, D)
+    mu, scale = mu.contiguous(), scale.contiguous()
+    shared = mu.numel() == D and state.B != 1
+    if mu.numel() not in (D, state.B * D):
+        raise BitswapHipError(f"mu/scale must hold {D} (shared) or {state.B}x{D} values")
+    return state.B, D, K, endpoints, es, step, mu, scale, (0 if (shared or state.B == 1 and mu.numel() == D) else D)
+
+
+def layer_pop64(state, endpoints, mu, scale, bits=31, quantbits=10, centres=None, step=None):
+    """64-state format: logistic CDF -> integer table -> pop, one launch; mu/scale [B,D] or [D] / [1,D] (one row set
+    shared by all chains: the prior).  -> (sym [B,D] int32, z [B,D] float32 | None)."""
+    _need_cuda(endpoints, mu, scale, centres, step, state.head)
+    B, D, K, endpoints, es, step, mu, scale, ps = _layer64_args(state, endpoints, mu, scale, step)
+    sym = torch.empty((B, D), dtype=torch.int32, device=mu.device)
+    z, cs = None, 0
+    if centres is not None:
+        centres, cs = _row_stride(centres, K)
+        z = torch.empty((B, D), dtype=torch.float32, device=mu.device)
+    _check(load().bs_layer_pop64(_ptr(state.head), _ptr(state.stack), _ptr(state.len64), state.cap, _ptr(endpoints), es,
+                                 _ptr(step), _ptr(mu), _ptr(scale), ps, _param_dtype(mu), B, D, K, bits, quantbits,
+                                 _ptr(sym), _ptr(centres), cs, _ptr(z), _ptr(state.status), _stream()), "bs_layer_pop64")
+    return sym, z
+
+
+def layer_push64(state, endpoints, mu, scale, sym, bits=31, quantbits=10, step=None):
+    _need_cuda(endpoints, mu, scale, sym, step, state.head)
+    B, D, K, endpoints, es, step, mu, scale, ps = _layer64_args(state, endpoints, mu, scale, step)
+    sym = sym.contiguous()
+    if sym.dtype != torch.int32:
+        sym = sym.to(torch.int32)
+    if tuple(sym.shape) != (B, D):
+        raise BitswapHipError(f"sym must be [{B},{D}]")
+    _check(load().bs_layer_push64(_ptr(state.head), _ptr(state.stack), _ptr(state.len64), state.cap, _ptr(endpoints), es,
+                                  _ptr(step), _ptr(mu), _ptr(scale), ps, _param_dtype(mu), _ptr(sym), B, D, K, bits,
+                                  quantbits, _ptr(state.status), _stream()), "bs_layer_push64")
 
 
 def gather_centres(centres, sym):

@@ -23,6 +23,8 @@ if __name__ == '__main__':
     ap.add_argument('--gpu', default=None, type=int)
     ap.add_argument('--synthetic', action='store_true', help="seeded synthetic weights (no checkpoint offline)")
     ap.add_argument('--params', default=None)
+    ap.add_argument('--format', default="reference", choices=["reference", "wave64"],
+                    help="reference: the reference's stream/container; wave64: the opt-in 64-state format (own container)")
     args = ap.parse_args()
     if args.gpu is None:
         print("Give GPU index (0, 1, 2 etc.).")
@@ -40,8 +42,10 @@ if __name__ == '__main__':
     size_raw = os.path.getsize(os.path.join(d, f"{filename}_uncompressed.npy")) * 8
     print(f"Shape ({old_h}, {old_w}, 3) -> cropped to ({h}, {w}, 3); raw size {size_raw} bits")
     setup = cli.crop_setup(args.gpu, nz=4, quantbits=10, synthetic=args.synthetic, params=args.params)
-    state, min_words, bpd = cli.compress_images([blocks], quantbits=10, nz=4, bitswap=1, gpu=args.gpu, setup=setup)[0]
-    arr = container.pack(state, min_words, blocks.shape[0], h, w)
+    state, min_words, bpd = cli.compress_images([blocks], quantbits=10, nz=4, bitswap=1, gpu=args.gpu, setup=setup,
+                                                fmt=args.format)[0]
+    pack = container.pack64 if args.format == "wave64" else container.pack
+    arr = pack(state, min_words, blocks.shape[0], h, w)
     np.save(os.path.join(d, f"{filename}_bitswap"), arr)
     size_bs = os.path.getsize(os.path.join(d, f"{filename}_bitswap.npy")) * 8
     print(f"Bit-Swap: {filename}_bitswap.npy, {size_bs} bits, ratio {100 * size_bs / size_raw:.2f} %, "

@@ -29,7 +29,8 @@ if __name__ == '__main__':
     if ext != ".npy" or "_bitswap" not in filename:
         raise SystemExit("Expected a <name>_bitswap.npy file")
     cli.seed_everything()
-    state, nblocks, h, w = container.unpack(np.load(args.file))
+    arr = np.load(args.file)
+    state, nblocks, h, w = (container.unpack64 if container.is_pack64(arr) else container.unpack)(arr)
     setup = cli.crop_setup(args.gpu, nz=4, quantbits=10, synthetic=args.synthetic, params=args.params)
     blocks, _ = cli.decompress_image(state, nblocks, quantbits=10, nz=4, gpu=args.gpu, setup=setup)
     img = tiling.unextract_blocks(blocks, h, w)

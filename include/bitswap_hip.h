@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 /* 2: layout argument, BS_LAYOUT_WAVE pivot words, conv-stack epilogue entry points
- * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop */
+ * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop64 / _push64 */
 #define BS_ABI_VERSION 3
 /* highest version of the deterministic logistic-CDF specification this library implements;
  * a stream written with one CDF spec can only be decoded with the same one.
@@ -155,6 +155,30 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
                 const uint32_t* cdf, int64_t chain_stride, int64_t ld, int layout, int B, int D, int K,
                 int bits, int32_t* sym_out, const double* centres, int64_t c_stride, float* centre_out,
                 int32_t* status, void* stream);
+
+/*
+ * BS_FORMAT_WAVE64 -- opt-in 64-state stream format (no reference counterpart).  A chain owns 64 independent rANS
+ * states: head64 [B,64] uint64, stack64 [B,64,cap] uint32, len64 [B,64] int32; symbol d of a coding operation is coded
+ * on state d % 64 with the reference's arithmetic and order inside that state (ANS.encode / ANS.decode,
+ * mnist_compress.py:49-68: pushes ascending d, pops descending d).  Streams in this format are NOT the reference's
+ * word stream (they cost 64 heads instead of one per chain); they exist because the format has no serial chain longer
+ * than D/64 symbols, so one launch does the whole of mnist_compress.py:183-188 (or :198-203) -- logistic CDF, integer
+ * table, rANS step -- with the table row never leaving the registers of the wavefront that built it.
+ *
+ * bs_layer_pop64  -- pop D symbols per chain under Logistic(mu, scale) discretised on `endpoints` (arguments as
+ *   bs_logistic_tables; p_stride = elements between two chains' mu/scale rows, D normally, 0 = one row set shared by
+ *   all chains, the prior); sym_out [B,D], optional bin centres as in bs_rans_pop.  D <= 4096, K in {256, 512, 1024}.
+ * bs_layer_push64 -- push sym [B,D] under the same model.
+ * status [B]: BS_ST_UNDERFLOW / OVERFLOW / BADTABLE / BADSYMBOL, sticky, whichever state of the chain reports first.
+ */
+int bs_layer_pop64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t cap, const double* endpoints,
+                   int64_t e_stride, const double* bin_step, const void* mu, const void* scale, int64_t p_stride,
+                   int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres,
+                   int64_t c_stride, float* centre_out, int32_t* status, void* stream);
+int bs_layer_push64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t cap, const double* endpoints,
+                    int64_t e_stride, const double* bin_step, const void* mu, const void* scale, int64_t p_stride,
+                    int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits, int32_t* status,
+                    void* stream);
 
 /*
  * bs_gather_centres -- centre_out[b,d] = (float) centres[d*c_stride + sym[b,d]]

@@ -160,3 +160,107 @@ class OracleBackend:
         if state.rc.any():
             b = int(np.nonzero(state.rc)[0][0])
             raise RuntimeError(f"{what}: chain {b}: oracle status {int(state.rc[b])}")
+
+
+# ---- the opt-in 64-state stream format (include/bitswap_hip.h, BS_FORMAT_WAVE64) restated on the oracle's primitives ----
+NSTATES = 64
+
+
+def split_state(s, nstates=NSTATES):
+    """Restates bitswap_amd.hip.split_state: initial words dealt round-robin onto the states, last one as the head."""
+    words = list(s[:-1]) + [s[-1] >> 32]
+    return [words[j::nstates][:-1] + [words[j::nstates][-1] << 32] for j in range(nstates)]
+
+
+class OracleState64:
+    def __init__(self, states, cap):
+        nested = [s if isinstance(s[0], (list, tuple)) else split_state(s) for s in states]
+        self.stacks = [[O.Stack(sub, cap=cap) for sub in ch] for ch in nested]
+        self.B = len(states)
+        self.rc = np.zeros(self.B, dtype=np.int32)
+
+    def prefix(self, k):
+        if k == self.B:
+            return self
+        v = object.__new__(OracleState64)
+        v.stacks, v.B, v.rc = self.stacks[:k], int(k), self.rc[:k]
+        if getattr(self, "min_len", None) is not None:
+            v.min_len = self.min_len[:k]
+        return v
+
+    @property
+    def len64(self):
+        return torch.tensor([[int(s.len[0]) for s in ch] for ch in self.stacks], dtype=torch.int32)
+
+    @property
+    def len(self):
+        return self.len64.sum(1, dtype=torch.int32)
+
+    @property
+    def status(self):
+        return torch.from_numpy(self.rc)
+
+    def to_lists(self):
+        return [[s.tolist() for s in ch] for ch in self.stacks]
+
+
+class Oracle64Backend(OracleBackend):
+    """Symbol d of every coding operation is coded on state d % 64 of its chain, with the reference's arithmetic and
+    order inside that state: state j sees the sub-sequence d = j, j + 64, ... -- exactly what the oracle's single-state
+    layer_pop / layer_push (ANS.decode / ANS.encode, mnist_compress.py:49-68) do when handed every 64th row."""
+
+    name = "oracle-wave64"
+
+    def new_state(self, states, cap):
+        return OracleState64(states, (int(cap) + NSTATES - 1) // NSTATES + 64)
+
+    def pop(self, state, t, K, bits, centres=None):
+        D = t.e.shape[0]
+
+        def one(b):
+            sym = np.zeros(D, dtype=np.int32)
+            if state.rc[b]:
+                return sym
+            i = 0 if t.shared else b
+            for j in range(min(NSTATES, D)):
+                sl = slice(j, None, NSTATES)
+                step = None if t.step is None else np.ascontiguousarray(t.step[sl])
+                s, rc = O.layer_pop(state.stacks[b][j], np.ascontiguousarray(t.e[sl]), np.ascontiguousarray(t.mu[i][sl]),
+                                    np.ascontiguousarray(t.scale[i][sl]), bits, t.q, self._mode(t.step), step)
+                if rc:
+                    state.rc[b] = rc
+                    return np.zeros(D, dtype=np.int32)
+                sym[sl] = s
+            return sym
+        sym = torch.from_numpy(np.stack(self._map(one, state.B)))
+        z = self.centres(centres, sym) if centres is not None else None
+        return sym, z
+
+    def _push(self, state, b, e, mu, scale, sym, bits, q, step):
+        for j in range(min(NSTATES, e.shape[0])):
+            sl = slice(j, None, NSTATES)
+            stp = None if step is None else np.ascontiguousarray(step[sl])
+            rc = O.layer_push(state.stacks[b][j], np.ascontiguousarray(e[sl]), np.ascontiguousarray(mu[sl]),
+                              np.ascontiguousarray(scale[sl]), np.ascontiguousarray(sym[sl]), bits, q, self._mode(step), stp)
+            if rc:
+                state.rc[b] = rc
+                return
+
+    def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
+        e, mu, scale = self._np(endpoints).astype(np.float64), self._np(mu).astype(np.float64), self._np(scale).astype(np.float64)
+        sym = self._np(sym).astype(np.int32)
+        step = None if step is None else self._np(step).astype(np.float64)
+
+        def one(b):
+            if not state.rc[b]:
+                self._push(state, b, e, mu[b], scale[b], sym[b], bits, quantbits, step)
+        self._map(one, state.B)
+
+    def push_table(self, state, t, sym, K, bits):
+        sym = self._np(sym).astype(np.int32)
+
+        def one(b):
+            if not state.rc[b]:
+                i = 0 if t.shared else b
+                self._push(state, b, t.e, t.mu[i], t.scale[i], sym[b], bits, t.q, t.step)
+        self._map(one, state.B)

@@ -548,3 +548,66 @@ def test_discretize_on_gpu_against_reference_sampling(golden):
     # the top layer's analytic bins are float32 torch arithmetic on the HOST (discretization.py:25-27): another CPU may
     # round a log differently, which is why bins travel as files (bins/*.pt) and are never recomputed by the receiver
     assert np.allclose(ze[nz - 1, 0].cpu().numpy(), g["z_top_endpoints"], rtol=5e-7, atol=0)
+
+
+@pytest.mark.parametrize("bitswap", [1, 0])
+@pytest.mark.parametrize("name,q", [("mnist2", 10), ("cifar8", 8)])
+def test_wave64_hip_words_equal_oracle(name, q, bitswap):
+    """The opt-in 64-state format on the GPU (Hip64Backend: bs_layer_pop64 / bs_layer_push64, table rows never leave
+    the registers) against its restatement on the oracle's single-state primitives: with the GPU's conv outputs replayed
+    the 64 word streams of every chain are identical; the GPU receiver is lossless and unwinds all 64 x B states."""
+    from oracle.backend import Oracle64Backend
+    from bitswap_amd.codec import Hip64Backend
+    from bitswap_amd.hip import split_state
+    model, zend, zcen = workload.build(name, DEV, quantbits=q, small=16)
+    B, n = 5, 2
+    images = workload.synthetic_blocks(B * n, model.xs, seed=3).view(B, n, -1).to(torch.int32)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=q, bitswap=bool(bitswap), backend=Hip64Backend(DEV))
+    rec, plain_net = record_nets(codec)
+    state, met = codec.compress(images.to(DEV))
+    sent = state.to_lists()
+    it = iter(rec)
+    oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=q, bitswap=bool(bitswap),
+                      backend=Oracle64Backend(O.MODE_DET, threads=4))
+    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    ostate, omet = oc.compress(images)
+    assert ostate.to_lists() == sent
+    assert np.array_equal(omet["cma"], met["cma"]) and np.array_equal(omet["rest_len"], met["rest_len"])
+    codec._net = plain_net
+    out = codec.decompress(state, n)
+    assert torch.equal(out.cpu(), images)
+    assert state.to_lists() == [split_state(s) for s in initial_states(B)]
+
+
+def test_wave64_full_width_and_container_on_gpu():
+    """64-state format at full ImageNet32 width (Z = 2048, X = 3072, K = 1024 / 256, CDF spec 2), 26 chains: words equal
+    the oracle's, lossless; then the demo path with the 64-state container on a small crop model."""
+    from oracle.backend import Oracle64Backend
+    from bitswap_amd.codec import Hip64Backend
+    from bitswap_amd.hip import split_state
+    model, zend, zcen = workload.build("imagenet4", DEV, quantbits=10)
+    B, n = 26, 1
+    images = workload.synthetic_blocks(B * n, model.xs, seed=19).view(B, n, -1).to(torch.int32)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True, backend=Hip64Backend(DEV))
+    rec, plain_net = record_nets(codec)
+    state, met = codec.compress(images.to(DEV))
+    sent = state.to_lists()
+    it = iter(rec)
+    oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=True, backend=Oracle64Backend(O.MODE_DET, threads=16))
+    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    ostate, _ = oc.compress(images)
+    assert ostate.to_lists() == sent
+    codec._net = plain_net
+    out = codec.decompress(state, n)
+    assert torch.equal(out.cpu(), images) and state.to_lists() == [split_state(s) for s in initial_states(B)]
+    # demo path
+    setup = cli.crop_setup(0, nz=2, quantbits=10, small=16)
+    rng = np.random.RandomState(1)
+    blocks, h, w = tiling.extract_blocks(rng.randint(0, 256, (70, 100, 3)).astype(np.uint8))
+    (st, mins, bpd), = cli.compress_images([blocks], quantbits=10, nz=2, setup=setup, fmt="wave64")
+    arr = container.pack64(st, mins, len(blocks), h, w)
+    assert container.is_pack64(arr)
+    st2, nb, hh, ww = container.unpack64(arr)
+    out, rest = cli.decompress_image(st2, nb, quantbits=10, nz=2, setup=setup)
+    assert np.array_equal(tiling.unextract_blocks(out, hh, ww), tiling.unextract_blocks(blocks, h, w))
+    assert rest == [s[m:] for s, m in zip(split_state(reference_init_state()), mins)]

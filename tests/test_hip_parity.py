@@ -586,3 +586,106 @@ def test_degenerate_parameters_are_flagged(spec):
     st2 = h.RansState.from_lists(states, cap=2000, device=DEV)
     h.logistic_fc(dev(e), dev(mu), dev(sc), sym, st2.status, 31, 8, step=step)
     assert st2.status.cpu().tolist() == [0, h.ST_BADTABLE, h.ST_BADTABLE, h.ST_BADTABLE, 0]
+
+
+@pytest.mark.parametrize("K", [256, 512, 1024])
+@pytest.mark.parametrize("spec", [1, 2])
+def test_layer64_kernels_vs_oracle(K, spec):
+    """bs_layer_pop64 / bs_layer_push64 (64 states per chain, table row + rANS step in one launch) against the
+    oracle: state j of a chain codes dims j, j + 64, ... with the single-state arithmetic (ANS.decode / ANS.encode,
+    mnist_compress.py:49-68).  D not a multiple of 64 (ragged residues), 7 chains (partial chain group), float32 and
+    float64 parameters; popped symbols, all 64 x B states, centres, the shared-row (prior) form, and pop-after-push."""
+    from bitswap_amd.bins import uniform_step
+    from oracle.backend import split_state
+    h = hip()
+    q = int(np.log2(K))
+    rng = np.random.RandomState(K + spec)
+    D, B = 200, 7
+    lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
+    e = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
+    step_np = uniform_step(e) if spec == 2 else None
+    step = None if step_np is None else dev(step_np)
+    mode = O.MODE_DET2 if spec == 2 else O.MODE_DET
+    mu = (rng.randn(B, D) * 0.6).astype(np.float32)
+    sc = rng.uniform(0.1, 1.0, (B, D)).astype(np.float32)
+    cen = rng.randn(D, K)
+    states = [reference_init_state(1600, seed=31 + b) for b in range(B)]
+
+    def oracle_pop(stacks, mu_b, sc_b):
+        sym = np.zeros(D, dtype=np.int32)
+        for j in range(64):
+            sl = slice(j, None, 64)
+            s, rc = O.layer_pop(stacks[j], e[sl], mu_b[sl].astype(np.float64), sc_b[sl].astype(np.float64), 31, q, mode,
+                                None if step_np is None else step_np[sl])
+            assert rc == O.OK
+            sym[sl] = s
+        return sym
+
+    for ptype in (torch.float32, torch.float64):
+        st = h.RansState64.from_lists(states, cap=400, device=DEV)
+        assert st.to_lists() == [split_state(s) for s in states]
+        sym, z = h.layer_pop64(st, dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, centres=dev(cen), step=step)
+        st.check()
+        got = st.to_lists()
+        for b in range(B):
+            stacks = [O.Stack(sub) for sub in split_state(states[b])]
+            want = oracle_pop(stacks, mu[b], sc[b])
+            assert np.array_equal(sym[b].cpu().numpy(), want), b
+            assert got[b] == [s_.tolist() for s_ in stacks], b
+            assert np.array_equal(z[b].cpu().numpy(), cen[np.arange(D), want].astype(np.float32))
+        h.layer_push64(st, dev(e), dev(mu, ptype), dev(sc, ptype), sym, 31, q, step=step)   # bits back: restores every state
+        st.check()
+        assert st.to_lists() == [split_state(s) for s in states]
+    # fresh symbols: push, compare with the oracle, pop them back
+    data = rng.randint(0, K, (B, D)).astype(np.int32)
+    st = h.RansState64.from_lists(states, cap=400, device=DEV)
+    h.layer_push64(st, dev(e), dev(mu), dev(sc), dev(data), 31, q, step=step)
+    st.check()
+    got = st.to_lists()
+    for b in range(B):
+        stacks = [O.Stack(sub) for sub in split_state(states[b])]
+        for j in range(64):
+            sl = slice(j, None, 64)
+            assert O.layer_push(stacks[j], e[sl], mu[b][sl].astype(np.float64), sc[b][sl].astype(np.float64),
+                                np.ascontiguousarray(data[b][sl]), 31, q, mode, None if step_np is None else step_np[sl]) == O.OK
+        assert got[b] == [s_.tolist() for s_ in stacks], b
+    back, _ = h.layer_pop64(st, dev(e), dev(mu), dev(sc), 31, q, step=step)
+    st.check()
+    assert torch.equal(back.cpu(), torch.from_numpy(data)) and st.to_lists() == [split_state(s) for s in states]
+    # one row set shared by all chains (the prior): same as expanding it
+    st_a = h.RansState64.from_lists(states, cap=400, device=DEV)
+    st_b = h.RansState64.from_lists(states, cap=400, device=DEV)
+    sa, _ = h.layer_pop64(st_a, dev(e), dev(mu[0]), dev(sc[0]), 31, q, step=step)
+    sb, _ = h.layer_pop64(st_b, dev(e), dev(np.tile(mu[:1], (B, 1))), dev(np.tile(sc[:1], (B, 1))), 31, q, step=step)
+    assert torch.equal(sa, sb) and st_a.to_lists() == st_b.to_lists()
+
+
+def test_layer64_status_codes():
+    h = hip()
+    K, D, B = 256, 128, 3
+    e = np.stack([np.linspace(-4, 4, K + 1)[1:-1]] * D)
+    mu, sc = np.zeros((B, D), dtype=np.float32), np.full((B, D), 0.5, dtype=np.float32)
+    # chain 0: two words per state cannot feed two 8-bit symbols per state forever -> underflow after a few pops
+    states = [reference_init_state(200, seed=1), reference_init_state(3000, seed=2), reference_init_state(3000, seed=3)]
+    st = h.RansState64.from_lists(states, cap=100, device=DEV)
+    for _ in range(8):
+        sym, _ = h.layer_pop64(st, dev(e), dev(mu), dev(sc), 31, 8)
+    assert st.status.cpu().tolist() == [h.ST_UNDERFLOW, 0, 0]
+    with pytest.raises(h.BitswapHipError):
+        st.check()
+    # bad symbol / degenerate parameters / overflow are reported per chain, healthy chains keep going
+    st = h.RansState64.from_lists(states[1:], cap=60, device=DEV)
+    bad = np.zeros((2, D), dtype=np.int32)
+    bad[0, 77] = K
+    h.layer_push64(st, dev(e), dev(mu[:2]), dev(sc[:2]), dev(bad), 31, 8)
+    assert st.status.cpu().tolist() == [h.ST_BADSYMBOL, 0]
+    st.status.zero_()
+    sc2 = sc[:2].copy()
+    sc2[1, 5] = np.nan
+    h.layer_push64(st, dev(e), dev(mu[:2]), dev(sc2), dev(np.zeros((2, D), dtype=np.int32)), 31, 8)
+    assert st.status.cpu().tolist() == [0, h.ST_BADTABLE]
+    st.status.zero_()
+    rare = np.full((2, D), K - 1, dtype=np.int32)           # far tail: ~30 bits per symbol, a word per push
+    for _ in range(40):
+        h.layer_push64(st, dev(e), dev(mu[:2]), dev(sc[:2]), dev(rare), 31, 8)
+    assert st.status.cpu().tolist() == [h.ST_OVERFLOW, h.ST_OVERFLOW]

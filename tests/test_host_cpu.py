@@ -355,3 +355,50 @@ def test_winograd_matrices_and_conv_identity(m, r):
     Y = torch.einsum("ik,klcbts,jl->bctisj", ATt, M, ATt).reshape(N, C, 16, 16)
     ref = torch.nn.functional.conv2d(x, w, padding=p)
     assert float((Y - ref).abs().max()) < 1e-10 * float(ref.abs().max()) + 1e-10
+
+
+@pytest.mark.parametrize("bitswap", [1, 0])
+def test_wave64_format_round_trip_on_oracle(bitswap):
+    """The opt-in 64-state stream format restated on the oracle (oracle/backend.py::Oracle64Backend): symbol d of every
+    operation on state d % 64.  Lossless, every one of the 64 states of every chain unwinds to its share of the
+    initial words, chains stay independent, and the rate is the reference format's up to a constant of a few words per
+    state (64 heads, 64 word-granular low-water marks), whatever the number of blocks."""
+    from oracle.backend import Oracle64Backend, split_state
+    model, zend, zcen = workload.build("cifar8", "cpu", quantbits=8, small=8, nn_batch=2)
+    B, n = 3, 2
+    images = workload.synthetic_blocks(B * n, model.xs, seed=3).view(B, n, -1).to(torch.int32)
+    c64 = BitSwapCodec(model, zend, zcen, quantbits=8, bitswap=bool(bitswap), backend=Oracle64Backend(O.MODE_DET, threads=3))
+    st, met = c64.compress(images)
+    lists = st.to_lists()
+    assert len(lists) == B and all(len(ch) == 64 and all(sub[-1] >= 1 << 32 for sub in ch) for ch in lists)
+    c1 = BitSwapCodec(model, zend, zcen, quantbits=8, bitswap=bool(bitswap), backend=OracleBackend(O.MODE_DET, threads=3))
+    _, met1 = c1.compress(images)
+    # 64 heads and 64 word-granular low-water marks instead of one: a few words per state, once per chain
+    assert np.all(np.abs(met["total"][:, -1] - met1["total"][:, -1]) <= 64 * 4 * 32 + 2000)
+    st1, _ = c64.compress(images[1:2], state=c64.new_states(1, n, states=[initial_states(B)[1]]))
+    assert st1.to_lists()[0] == lists[1]
+    out = c64.decompress(st, n)
+    assert torch.equal(out, images)
+    assert st.to_lists() == [split_state(s) for s in initial_states(B)]
+
+
+def test_wave64_container_and_demo_path():
+    from oracle.backend import Oracle64Backend, split_state
+    ob = Oracle64Backend(O.MODE_DET)
+    setup = cli.crop_setup(-1, nz=2, quantbits=6, backend=ob, small=8)
+    rng = np.random.RandomState(2)
+    blocks = tiling.extract_blocks(rng.randint(0, 256, (64, 96, 3)).astype(np.uint8))[0]
+    (st, mins, bpd), = cli.compress_images([blocks], quantbits=6, nz=2, setup=setup, backend=ob, fmt="wave64")
+    assert len(st) == 64 and len(mins) == 64 and bpd > 0
+    arr = container.pack64(st, mins, len(blocks), 64, 96)
+    assert arr.dtype == np.uint32 and container.is_pack64(arr) and len(arr) < 10000
+    assert not container.is_pack64(container.pack([5, 6, 7 << 32], 0, 1, 32, 32))     # a reference container
+    st2, nb, h, w = container.unpack64(arr)
+    assert (nb, h, w) == (6, 64, 96) and [s[-1] for s in st2] == [s[-1] for s in st]
+    assert all(a == b[m:] for a, b, m in zip(st2, st, mins))
+    out, rest = cli.decompress_image(st2, nb, quantbits=6, nz=2, setup=setup, backend=ob)
+    assert np.array_equal(out, blocks)
+    init = split_state(reference_init_state())
+    assert rest == [s[m:] for s, m in zip(init, mins)]          # every state: the untouched tail of its initial words
+    with pytest.raises(ValueError):
+        container.unpack64(arr[:-1])

@@ -76,14 +76,22 @@ def main():
             r[f"spec{spec}"] = dict(tables_wave_s=t_tab, fc_s=t_fc, pop_wave_s=float(np.median(tp)),
                                     push_s=float(np.median(tq)), tables_alg_GBps=alg / t_tab / 1e9,
                                     fc_alg_GBps=alg / t_fc / 1e9, ns_per_row_tables=t_tab / rows * 1e9)
-            if hasattr(hip, "layer_pop"):
-                cen = torch.from_numpy(rng.randn(D, K)).to(dev)
-                tl = []
-                for _ in range(args.iters):
-                    tl.append(timeit(lambda: hip.layer_pop(st, e, mu, sc, 31, q, centres=cen, step=stp), 1, 0))
-                    hip.rans_push(st, fo[0], fo[1])
-                st.check()
-                r[f"spec{spec}"]["layer_pop_s"] = float(np.median(tl))
+            # 64-state format: table + rANS step fused, one launch per coding operation
+            np.random.seed(1)
+            words = np.random.randint(1 << 16, (1 << 32) - 1, size=(B, 64, 160), dtype=np.uint32)
+            s64 = hip.RansState64(B, 160 + 4 * (D // 64) + 64, dev)
+            s64.stack[:, :, :160] = torch.from_numpy(words.view(np.int32)).to(dev)
+            s64.len64.fill_(159)
+            s64.head.copy_(torch.from_numpy((words[:, :, -1].astype(np.uint64) << np.uint64(32)).view(np.int64)))
+            cen = torch.from_numpy(rng.randn(D, K)).to(dev)
+            tp64, tq64 = [], []
+            for _ in range(args.iters):
+                box = []
+                tp64.append(timeit(lambda: box.append(hip.layer_pop64(s64, e, mu, sc, 31, q, centres=cen, step=stp)), 1, 0))
+                sy = box[0][0]
+                tq64.append(timeit(lambda: hip.layer_push64(s64, e, mu, sc, sy, 31, q, step=stp), 1, 0))
+            s64.check()
+            r[f"spec{spec}"].update(layer_pop64_s=float(np.median(tp64)), layer_push64_s=float(np.median(tq64)))
         res[name] = r
     print(json.dumps(res, indent=1))
 
