@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 if (r < 0) { --q; r += (int64_t)f; }
                 else if (r >= (int64_t)f) { ++q; r -= (int64_t)f; }
                 hh = (q << bits) + (uint64_t)r + cs;
-                h[c] = (uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hh) |
+                h[c] = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)hh) |
                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(hh >> 32)) << 32);
             }
         }
