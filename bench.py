@@ -209,8 +209,13 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
 
     totals = tl.totals()
     roof = None
-    if "tables_z" in totals and totals["tables_z"][1]:
-        sec, cnt = totals["tables_z"]
+    # the roofline kernel: the table kernel of the reference format; in the 64-state format the table is built inside
+    # the fused pop launch, which is then the kernel that carries the algorithmic bytes
+    rkey = "pop_z" if args.format == "wave64" else "tables_z"
+    if args.format == "wave64":
+        totals.pop("tables_z", None), totals.pop("tables_x", None)      # lazy handles: nothing is launched there
+    if rkey in totals and totals[rkey][1]:
+        sec, cnt = totals[rkey]
         Kb, Z = codec.K, codec.Z
         rows = B * Z / max(1, groups)                     # rows one launch processes (one chain group)
         alg = int(rows * ((Kb - 1) * 8 + 2 * 4 + 4))      # endpoints f64 + mu,scale f32 + symbol i32
@@ -218,7 +223,7 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
         ach = alg / avg / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and args.format == "reference":
             try:
                 per_row = json.load(open(tp)).get(name, {}).get("k_logistic_decode_bytes_per_row")
                 traffic = None if per_row is None else int(per_row * rows)   # PMC bytes/row x rows of one launch
@@ -227,9 +232,12 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
         a_block = algorithmic_bytes_per_block(codec)
         path = 2.0 * a_block * world * B * K / dt / 1e9
         spec = args.cdf_spec if any(s is not None for s in codec.codecs[0].zstep) else 1
-        slots = VALU_SLOTS_PER_ROW[spec] if Kb == 1024 else None
-        roof = {"kernel": f"k_logistic<16,float,decode,{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> integer cdf "
-                          f"rows, CDF spec {spec})", "bound": "hbm",
+        slots = VALU_SLOTS_PER_ROW[spec] if (Kb == 1024 and args.format == "reference") else None
+        kname = (f"k_layer64<16,float,{'uniform' if spec == 2 else 'generic'},pop> (logistic CDF -> integer table -> rANS pop in "
+                 f"one launch, rows in registers, CDF spec {spec})" if args.format == "wave64" else
+                 f"k_logistic<16,float,decode,{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> integer cdf "
+                 f"rows, CDF spec {spec})")
+        roof = {"kernel": kname, "bound": "hbm",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg * 1e3, 4),
                 "alg_bytes_per_launch": alg,

@@ -35,8 +35,7 @@ def seed_everything():
     torch.manual_seed(50)
     if torch.cuda.is_available():
         torch.cuda.manual_seed(50)
-    torch.backends.cudnn.deterministic = True
-    torch.backends.cudnn.benchmark = False   # the reference sets True; a fixed algorithm is safer for the decoder
+    # cudnn.deterministic / benchmark (:98-99) are scoped to the codec's conv stacks: codec.deterministic_convs()
 
 
 def load_images(dataset, path, synthetic, xs, n):

@@ -82,6 +82,20 @@ class HipBackend:
         state.check(what)
 
 
+@contextlib.contextmanager
+def deterministic_convs():
+    """The decoder must reproduce the encoder's (mu, scale) bit for bit: MIOpen has to pick the same, deterministic
+    algorithm on both sides (the reference sets the flags process-wide, mnist_compress.py:98-99).  Here they hold for
+    the conv stacks of the codec only and the caller's settings come back afterwards."""
+    be = torch.backends.cudnn
+    prev = (be.deterministic, be.benchmark)
+    be.deterministic, be.benchmark = True, False
+    try:
+        yield
+    finally:
+        be.deterministic, be.benchmark = prev
+
+
 class _LazyTable:
     """What Hip64Backend.tables() hands to its pop(): the arguments of the fused kernel, not a table."""
 
@@ -184,10 +198,6 @@ class BitSwapCodec:
     def __init__(self, model, zendpoints, zcentres, quantbits=10, bitswap=True, ansbits=31, backend=None,
                  timeline=None, cdf_spec=2):
         self.backend = backend if backend is not None else HipBackend(zendpoints.device)
-        # the decoder must reproduce the encoder's (mu, scale) bit for bit: MIOpen has to pick the same,
-        # deterministic algorithm on both sides (the reference sets the same flag, mnist_compress.py:98)
-        torch.backends.cudnn.deterministic = True
-        torch.backends.cudnn.benchmark = False
         self.model = model
         self.nz = model.nz
         self.q, self.K, self.bits = quantbits, 1 << quantbits, ansbits
@@ -317,7 +327,7 @@ class BitSwapCodec:
 
     def _net(self, fn, given):
         self._bulk_waits_serial()
-        with self._on(self.bulk), self.tl.span("net"), torch.no_grad():
+        with self._on(self.bulk), self.tl.span("net"), torch.no_grad(), deterministic_convs():
             mu, scale = fn(given)
             mu, scale = mu.contiguous(), scale.contiguous()
         return mu, scale

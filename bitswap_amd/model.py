@@ -134,24 +134,37 @@ def _resblock(width, kernel_size, padding, nlayers, dropout_p, act):
     return blk
 
 
+def blas_backend_available(name):
+    """Can torch route its GEMMs to `name`?  Probed once when a Model is fused: the route is part of what sender and
+    receiver must share (the GEMM kernels differ in the last float32 bits), so it is decided up front and visibly,
+    never by a silent fallback in the middle of a stream."""
+    import warnings
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            prev = torch.backends.cuda.preferred_blas_library()
+            torch.backends.cuda.preferred_blas_library(name)
+            torch.backends.cuda.preferred_blas_library(prev)
+        return True
+    except Exception:
+        return False
+
+
 class _blas:
-    """Route torch's GEMMs to a BLAS backend for the duration of a block.  The Winograd-domain GEMMs
-    (batch 36/64 of [C x C] x [C x tiles]) run at 102-107 TFLOP/s on the composable_kernel backend where the
-    default heuristic picks a 60-76 TFLOP/s kernel for batch 36 (tools/gemm_probe3.py)."""
+    """Route torch's GEMMs to a BLAS backend for the duration of a block (the previous choice comes back on exit).
+    The Winograd-domain GEMMs (batch 36/64 of [C x C] x [C x tiles]) run at 102-107 TFLOP/s on the composable_kernel
+    backend where the default heuristic picks a 60-76 TFLOP/s kernel for batch 36 (measured in round 1)."""
 
     def __init__(self, name):
         self.name, self.prev = name, None
 
     def __enter__(self):
         if self.name:
-            try:
-                import warnings
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    self.prev = torch.backends.cuda.preferred_blas_library()
-                    torch.backends.cuda.preferred_blas_library(self.name)
-            except Exception:
-                self.prev = None
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.prev = torch.backends.cuda.preferred_blas_library()
+                torch.backends.cuda.preferred_blas_library(self.name)
 
     def __exit__(self, *exc):
         if self.prev is not None:
@@ -282,6 +295,11 @@ class Model(nn.Module):
         """Enable the fused epilogues for compress mode (needs fold(); tensors on a HIP device)."""
         self.fused = bool(enable)
         self._heads = {}
+        if enable and self.gemm_backend and not blas_backend_available(self.gemm_backend):
+            import warnings
+            warnings.warn(f"BLAS backend {self.gemm_backend!r} is not available in this torch build: the Winograd-domain "
+                          "GEMMs use the default backend.  Streams written with one backend only decode with the same one.")
+            self.gemm_backend = None
         if enable:
             assert all(m.dropout_p == 0.0 for m in self.modules() if isinstance(m, ResNetLayer)) or not self.training
             self.fold()
@@ -338,7 +356,7 @@ class Model(nn.Module):
         """5x5 'same' convolution on the x-expanded operand ax [n, Cin*5, H+4, W] (hip.expand_rows5): kernel
         row dy is one strided-batched GEMM on rocBLAS/hipBLASLt (MFMA), accumulated in place.  At 100-200
         images this runs at ~103 TFLOP/s against 74-80 for MIOpen's decomposition of 5x5 into 3x3 Winograd
-        tiles (tools/conv_probe3.py).  No bias."""
+        tiles (measured in round 1).  No bias."""
         n, k5, hp, w = ax.shape
         h = hp - 4
         out = torch.empty((n, m.out_dim, h * w), dtype=ax.dtype, device=ax.device)
