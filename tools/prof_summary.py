@@ -65,7 +65,7 @@ def traffic(fetch_json, write_json, workload, out, rows_per_launch):
     def per(path, counter):
         d = json.load(open(path))
         for k, v in d.items():
-            if "k_logistic<16, float, 3>" in k or "k_logistic<16, float, true" in k:
+            if k.startswith("void k_logistic<16, float, 3"):   # decode flavour, wave layout (spec 2: "..., 3, true>")
                 return v[f"{counter}_per_dispatch"] * 1024.0, v["dispatches"]
         return None, 0
     f, nf = per(fetch_json, "FETCH_SIZE")
