@@ -181,6 +181,14 @@ class _RawConv:
         self.c, self.b = c, b
 
 
+class _RawM:
+    """Output of an input convolution run in the Winograd domain: M [ts*ts, Cout, N*T] = U x V, still without its
+    bias and ELU -- the next fused pass applies A^T M A + b, ELU, and whatever follows."""
+
+    def __init__(self, m, b, ts, shape):
+        self.m, self.b, self.ts, self.shape = m, b, ts, tuple(shape)
+
+
 class _WinoOperand:
     """A block output that only exists as the Winograd operand V [36, C, N*T] of the 3x3 convs that follow."""
 
@@ -205,6 +213,10 @@ class Model(nn.Module):
         # ResNet convs of the fused path: "winograd" (transform-domain batched GEMM, 3x3 and 5x5), "gemm5" (5x5 as
         # five row GEMMs, 3x3 on MIOpen) or "miopen"; below gemm_min_batch images MIOpen always runs them
         self.conv_algo = "winograd"
+        # input convs of the stacks (Cin = zchannels or 4 x image channels) in the Winograd domain too: leaves nothing to
+        # MIOpen from gemm_min_batch blocks per call on, but the K = 8..12 batched GEMMs run no faster than MIOpen's
+        # kernels (profiles/r02g_kernel_stats.txt: 177 vs 177 ms per step), so it is an option, not the default
+        self.wino_inputs = False
         self.gemm_min_batch = 24
         self.gemm_backend = "ck"     # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs
         self._heads, self._heads_u, self._gen_mu_u = {}, {}, None
@@ -318,11 +330,15 @@ class Model(nn.Module):
                 self._heads_u = {k: _tw(w) for k, (w, b) in self._heads.items() if w.shape[-1] == 3}
                 g0 = self.gen_mu[0]
                 self._gen_mu_u = _tw(g0._w) if g0.kernel_size == 3 else None
-                # ResNet convs (3x3 and 5x5, Cin == Cout) in the Winograd domain: U = G w G^T, [36, Cout, Cin]
+                # ResNet convs (3x3 and 5x5, Cin == Cout) in the Winograd domain: U = G w G^T, [36, Cout, Cin]; the input
+                # convs of every stack (Cin = zchannels or 4 x image channels -> reswidth) get their U as well
+                # (Model.wino_inputs)
                 from .winograd import transform_weights
+                ins = [self.infer_in[1], self.gen_in[0]] + [q[0] for q in self.deepinfer_in] + [q[0] for q in self.deepgen_in]
                 for m in self.modules():
-                    if (isinstance(m, WnConv2d) and m.kernel_size in (3, 5) and m.in_dim == m.out_dim
-                            and m.stride == 1 and m.padding == m.kernel_size // 2):
+                    if (isinstance(m, WnConv2d) and m.kernel_size in (3, 5) and m.stride == 1
+                            and m.padding == m.kernel_size // 2
+                            and (m.in_dim == m.out_dim or any(m is q for q in ins))):
                         m._wu = transform_weights(m._w)
                     # 5x5 as five GEMMs (one per kernel row), the alternative path: W_dy [Cout, Cin*5]
                     if isinstance(m, WnConv2d) and m.kernel_size == 5 and m.in_dim == m.out_dim and m.stride == 1:
@@ -341,10 +357,23 @@ class Model(nn.Module):
         if isinstance(mods[0], Squeeze2d):
             x = mods[0](x).contiguous()
             mods = mods[1:]
-        c = self._conv_nb(mods[0], x)
-        if nxt is not None and not isinstance(nxt, Pass) and self._wino_ok(list(nxt[0].children()), c):
-            return _RawConv(c, mods[0].b)
-        return hip.bias_residual_elu(c, mods[0].b)[1]
+        m = mods[0]
+        follows = nxt is not None and not isinstance(nxt, Pass)
+        if (self.conv_algo == "winograd" and self.wino_inputs and m._wu is not None and x.shape[0] >= self.gemm_min_batch
+                and x.shape[-1] % 4 == 0 and x.shape[-2] % 4 == 0):
+            # the input conv itself in the Winograd domain: V = B^T x B (no bias, no activation in front of it),
+            # M = U x V; its bias + ELU ride on the next fused pass
+            ts = int(round(m._wu.shape[0] ** 0.5))
+            shape_out = (x.shape[0], m.out_dim) + tuple(x.shape[2:])
+            v = hip.wino_fused(x.contiguous(), tuple(x.shape), 0, None, None, False, ts_out=ts)[2]
+            raw = _RawM(torch.bmm(m._wu, v), m.b, ts, shape_out)
+            if follows and self._wino_ok(list(nxt[0].children()), torch.empty((shape_out[0], 0, shape_out[2], shape_out[3]))):
+                return raw
+            return hip.wino_fused(raw.m, shape_out, ts, m.b, None, True, want_act=True)[1]      # ELU(A^T M A + b)
+        c = self._conv_nb(m, x)
+        if follows and self._wino_ok(list(nxt[0].children()), c):
+            return _RawConv(c, m.b)
+        return hip.bias_residual_elu(c, m.b)[1]
 
     def _wino_ok(self, layers, h):
         return (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
@@ -387,7 +416,10 @@ class Model(nn.Module):
         6.25x (5x5) fewer multiplications than the direct convolution, all of them on the MFMA units."""
         from . import hip
         ts = int(round(layers[0].conv1._wu.shape[0] ** 0.5))
-        if isinstance(h, _RawConv):     # the input conv's bias + ELU ride along: h = ELU(c + b), V = B^T ELU(h) B
+        if isinstance(h, _RawM):        # same, the input conv still in the Winograd domain: h = ELU(A^T M A + b)
+            shape = h.shape
+            _, h, v = hip.wino_fused(h.m, shape, h.ts, h.b, None, 3, want_act=True, ts_out=ts)
+        elif isinstance(h, _RawConv):   # the input conv's bias + ELU ride along: h = ELU(c + b), V = B^T ELU(h) B
             shape = tuple(h.c.shape)
             _, h, v = hip.wino_fused(h.c, shape, 0, h.b, None, 3, want_act=True, ts_out=ts)
         else:
@@ -423,7 +455,7 @@ class Model(nn.Module):
         if isinstance(seq, Pass):
             return h
         layers = list(seq[0].children())
-        if isinstance(h, _RawConv):
+        if isinstance(h, (_RawConv, _RawM)):
             return self._res_wino(layers, h, want_v)
         if (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
                 and h.shape[-1] % 4 == 0 and h.shape[-2] % 4 == 0):

@@ -147,7 +147,7 @@ def test_winograd_convs_match_torch(ks, small):
     assert float((y.double() - ref).abs().max()) < 3e-5 * float(ref.abs().max()) and torch.equal(y, y2)
 
 
-@pytest.mark.parametrize("algo", ["winograd", "gemm5", "miopen"])
+@pytest.mark.parametrize("algo", ["winograd", "winograd+inputs", "gemm5", "miopen"])
 @pytest.mark.parametrize("name", ["mnist2", "imagenetcrop4"])
 def test_fused_epilogues_match_torch_modules(name, algo):
     """Model.fuse(): one epilogue launch per conv (net_epilogue.hip) against the plain torch modules
@@ -157,7 +157,8 @@ def test_fused_epilogues_match_torch_modules(name, algo):
     model, _, _ = workload.build(name, DEV, quantbits=8, small=24)
     assert model.fused
     model.compress(True)
-    model.conv_algo, model.gemm_min_batch = algo, 1       # ResNet convs: Winograd-domain GEMM / row GEMMs / MIOpen
+    # ResNet convs: Winograd-domain GEMM (optionally the input convs too: no MIOpen call left) / row GEMMs / MIOpen
+    model.conv_algo, model.gemm_min_batch, model.wino_inputs = algo.split("+")[0], 1, algo.endswith("+inputs")
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
         for i in range(model.nz):
