@@ -67,8 +67,24 @@ def load_model(dataset, nz, device, params, synthetic, nn_batch=None):
     raise FileNotFoundError(f"checkpoint {path} not found -- pass --params <file> or --synthetic")
 
 
+def stream_meta(codec, model, chains_in_call):
+    """What a receiver has to share with the sender beyond weights and bins for a stream to decode: the stream
+    format, the CDF specification per table, and the route the conv stacks took (their float32 results differ in the
+    last bits between routes, batch shapes and BLAS backends).  Written next to the bitstreams as stream_meta.json."""
+    from . import hip
+    return {"stream_format": "wave64" if getattr(codec.backend, "name", "") == "hip-wave64" else "reference",
+            "ansbits": codec.bits, "quantbits": codec.q, "bitswap": codec.bitswap,
+            "cdf_spec": {"z": [2 if s is not None else 1 for s in codec.zstep], "x": 2 if codec.xstep is not None else 1},
+            "library_abi": hip.ABI_VERSION, "backend": getattr(codec.backend, "name", "?"),
+            "conv_route": {"fused": bool(getattr(model, "fused", False)), "conv_algo": model.conv_algo,
+                           "wino_inputs": bool(model.wino_inputs), "gemm_backend": model.gemm_backend,
+                           "gemm_min_batch": model.gemm_min_batch, "nn_batch": model.nn_batch,
+                           "chains_per_call": int(chains_in_call)}}
+
+
 def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndatapoints=100, decompress=False,
-             synthetic=False, data=None, params=None, outdir=".", backend=None, small=None, verbose=True):
+             synthetic=False, data=None, params=None, outdir=".", backend=None, small=None, verbose=True,
+             save_bins=False):
     """One (dataset, nz, quantbits, scheme) experiment set.  Returns dict of the metric arrays on
     rank 0 (None on other ranks)."""
     rank, world = dist.init()
@@ -85,8 +101,10 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
         model = load_model(dataset, nz, dev, params, synthetic)
     images = load_images(dataset, data, synthetic or bool(small), model.xs, max(experiments * ndatapoints, 512))
     bins_data = images[: min(len(images), 4096)].view((-1,) + tuple(model.xs))
-    # the bins cache is written by rank 0 only; the other ranks wait and load it (no concurrent writers)
-    keep = not (synthetic or small)
+    # bins fitted here come from the first test images, not from the training set the reference samples
+    # (discretization.py:34-40): they are only written under the reference's cache names on request (--save-bins).
+    # The cache is written by rank 0 only; the other ranks wait and load it (no concurrent writers)
+    keep = bool(save_bins) and not (synthetic or small)
     if world > 1 and keep and rank != 0:
         dist.barrier()
     zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, dataset, data=bins_data,
@@ -128,6 +146,10 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
     os.makedirs(sdir, exist_ok=True)
     for c, s in zip(mine, sent):
         container.save_state(os.path.join(sdir, f"{scheme}_{quantbits}bits_nz{nz}_experiment{c + 1}"), s)
+    if rank == 0:
+        import json
+        with open(os.path.join(sdir, "stream_meta.json"), "w") as fp:
+            json.dump(dict(stream_meta(codec, model, len(mine)), world_size=world), fp, indent=1)
 
     t_recv = 0.0
     if decompress:
@@ -175,12 +197,14 @@ def dataset_main(dataset, default_nz, nz_loop=None):
     p.add_argument('--data', default=None, help="uint8 .npy test images")
     p.add_argument('--params', default=None, help="reference checkpoint (state_dict)")
     p.add_argument('--outdir', default=".")
+    p.add_argument('--save-bins', action='store_true',
+                   help="write bins fitted on the given test images under the reference's cache names (bins/*.pt)")
     args = p.parse_args()
     print(args)
     for nz in (nz_loop or [args.nz]):      # imagenet_compress.py:382 ignores --nz and runs [2, 4]
         compress(args.quantbits, nz, args.bitswap, args.gpu, dataset=dataset, experiments=args.experiments,
                  ndatapoints=args.ndatapoints, decompress=bool(args.decompress), synthetic=args.synthetic,
-                 data=args.data, params=args.params, outdir=args.outdir)
+                 data=args.data, params=args.params, outdir=args.outdir, save_bins=args.save_bins)
 
 
 # ---------------------------------------------------------------------------------------------
