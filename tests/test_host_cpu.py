@@ -187,7 +187,7 @@ def test_cli_experiment_artefacts(tmp_path):
         assert isinstance(st, list) and st[-1] >= 1 << 32
     import json
     meta = json.load(open(tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap" / "stream_meta.json"))
-    assert meta["stream_format"] == "reference" and meta["cdf_spec"] == {"z": [1, 1], "x": 1}   # K = 64: no spec 2
+    assert meta["stream_format"] == "reference" and meta["cdf_spec"] == {"z": [1, 1], "x": 2}   # latents K = 64: no spec 2; pixels K = 256: spec 2
     assert meta["conv_route"]["chains_per_call"] == 3 and meta["world_size"] == 1
     # net bit rate formula (:254,258): cumulative nets * xdim * ndatapoints = words added * 32
     assert np.all(r["total"] > 0) and np.isfinite(r["elbos"]).all()
