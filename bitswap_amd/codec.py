@@ -12,6 +12,7 @@ constructs only `HipBackend` (HIP kernels through the C ABI, no fallback).  test
 cpu_baseline leg may pass the oracle-backed stand-in from oracle/backend.py to run the very same
 schedule code on the CPU.
 """
+import collections
 import contextlib
 
 import numpy as np
@@ -187,6 +188,36 @@ class _Span:
             self.tl.spans.setdefault(self.key, []).append((self.a, b))
 
 
+class _StepGraph:
+    """One lock-step block step (sender or receiver) of a fixed set of chains as a hipGraph.
+
+    With few chains per GPU (config 4 on 8 GPUs: 13 images per rank; a single demo image) a block step is ~600 short
+    launches and the host cannot enqueue them as fast as the GPU retires them.  The step is a fixed sequence of
+    launches on fixed buffers -- the rANS state is updated in place, every temporary comes from the graph's private
+    pool -- so it is captured once and replayed per block: one hipGraphLaunch instead of ~600 launches.  The pixel
+    block of the step is copied into a static tensor first (sender); the decoded block is read from one (receiver)."""
+
+    def __init__(self, codec, state, sender):
+        self.graph = torch.cuda.CUDAGraph()
+        self.x = torch.zeros((state.B, codec.X), dtype=torch.int32, device=codec.device)
+        self.out = None
+        tl, codec.tl = codec.tl, Timeline(False)          # no timing events inside a capture
+        try:
+            with torch.cuda.graph(self.graph):
+                if sender:
+                    codec.encode_block(state, self.x)
+                else:
+                    self.out = codec.decode_block(state)
+        finally:
+            codec.tl = tl
+
+    def replay(self, x=None):
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
 class BitSwapCodec:
     """Sender and receiver for B chains.
 
@@ -222,6 +253,11 @@ class BitSwapCodec:
         self.xstep = stepper(self.xend)
         self.tl = timeline or Timeline(False)
         self._cdf_bufs = {}
+        # hipGraph replay of the block step: "auto" = when the chains are few enough for the step to be launch-bound
+        # (single stream only; a failed capture falls back to eager launches for good)
+        self.use_graphs = "auto"
+        self.graph_max_chains = 128
+        self._graphs = collections.OrderedDict()      # (state, direction) -> _StepGraph | None, the newest 4
         # optional stream split (GroupedCodec): convs + table kernels on `bulk`, the serial rANS kernels
         # on `serial`; None = everything on the caller's current stream
         self.bulk = self.serial = None
@@ -346,6 +382,49 @@ class BitSwapCodec:
             pass
         return out
 
+    def _graph_ok(self, state):
+        if not self.use_graphs or self.serial is not None or self.bulk is not None or not isinstance(self.backend, HipBackend):
+            return False
+        return self.use_graphs is True or state.B <= self.graph_max_chains
+
+    def _graphed(self, state, sender):
+        """The captured step for this state (same tensors on every replay), or None if capture is not possible."""
+        key = (id(state.head), state.B, sender)
+        g = self._graphs.get(key)
+        if g is None and key not in self._graphs:
+            try:
+                torch.cuda.synchronize()
+                g = _StepGraph(self, state, sender)
+                g._keep = state                      # the graph holds raw pointers into the state's tensors
+            except Exception as e:                   # e.g. a library call that cannot be captured on this stack
+                import warnings
+                warnings.warn(f"hipGraph capture of the block step failed ({e!r}); running eagerly")
+                torch.cuda.synchronize()
+                self.use_graphs, g = False, None
+            self._graphs[key] = g
+            while len(self._graphs) > 4:             # a graph pins its state and a private memory pool
+                self._graphs.popitem(last=False)
+        return g
+
+    def prepare_graphs(self, state):
+        """Capture both block-step graphs for `state` now (nothing is executed), e.g. before a timed region.  The
+        eager path must have run once in each direction before (library warm-up, buffers)."""
+        if self._graph_ok(state):
+            self._graphed(state, True)
+            self._graphed(state, False)
+
+    def encode_block_fast(self, state, x, first=False):
+        """encode_block, replayed from a hipGraph when that pays (never for the block that records restbits)."""
+        g = self._graphed(state, True) if (not first and self._graph_ok(state)) else None
+        if g is None:
+            self.encode_block(state, x)
+        else:
+            g.replay(x)
+
+    def decode_block_fast(self, state):
+        g = self._graphed(state, False) if self._graph_ok(state) else None
+        return self.decode_block(state) if g is None else g.replay().clone()
+
     def _snap(self, dst, state):
         with self._on(self.serial):
             dst.copy_(state.len)
@@ -451,7 +530,10 @@ class BitSwapCodec:
         rest_len = torch.zeros_like(state.len)
         lens = torch.zeros((n, B), dtype=torch.int32, device=state.len.device)
         for xi in range(n):
-            self.encode_block(state, images[:, xi], rest_len if xi == 0 else None)
+            if xi == 0:
+                self.encode_block(state, images[:, xi], rest_len)      # eager: records restbits, warms every library up
+            else:
+                self.encode_block_fast(state, images[:, xi])
             self._snap(lens[xi], state)
         self.backend.check(state, "compress")
         lens, init_len, rest_len = lens.cpu().numpy().T.astype(np.int64), init_len.cpu().numpy(), rest_len.cpu().numpy()
@@ -514,7 +596,8 @@ class BitSwapCodec:
         """-> images [B, nblocks, X] int32 (blocks in original order); state is unwound in place."""
         out = [None] * nblocks
         for xi in reversed(range(nblocks)):
-            out[xi] = self.decode_block(state)
+            # the first step runs eagerly (library warm-up before a capture), the rest replay the graph when it pays
+            out[xi] = self.decode_block(state) if xi == nblocks - 1 else self.decode_block_fast(state)
         self.backend.check(state, "decompress")
         return torch.stack(out, dim=1)
 
@@ -590,6 +673,14 @@ class GroupedCodec:
         """images [B, n, X]: n block steps of every group, enqueue order interleaved per coding op."""
         B, n, _ = images.shape
         sls = self.split(B)
+        if len(self.codecs) == 1:        # one stream: block after block, replayed from a hipGraph when launch-bound
+            c, st = self.codecs[0], states[0]
+            for xi in range(n):
+                if rest_lens is not None and xi == 0:
+                    c.encode_block(st, images[:, xi], rest_lens[0])
+                else:
+                    c.encode_block_fast(st, images[:, xi], first=(xi == 0 and not c._graphs))
+            return
         self._fork()
 
         def chain_of_blocks(g):
@@ -603,6 +694,14 @@ class GroupedCodec:
     def decode_blocks(self, states, n):
         """-> [B, n, X] int32, blocks in original order."""
         outs = [[None] * n for _ in self.codecs]
+        if len(self.codecs) == 1:
+            c, st = self.codecs[0], states[0]
+            for xi in reversed(range(n)):
+                warm = any(k[2] is False for k in c._graphs)        # the first receiver step ever runs eagerly
+                outs[0][xi] = c.decode_block_fast(st) if warm or not c._graph_ok(st) else c.decode_block(st)
+                if not warm and c._graph_ok(st):
+                    c._graphed(st, False)
+            return torch.stack(outs[0], dim=1)
         self._fork()
 
         def chain_of_blocks(g):

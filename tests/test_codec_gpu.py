@@ -14,6 +14,7 @@ DEV = "cuda"
 
 
 def record_nets(codec):
+    codec.use_graphs = False        # every conv output is wanted, block by block: no graph replay
     rec, orig = [], codec._net
 
     def wrapped(fn, given):
@@ -612,3 +613,33 @@ def test_wave64_full_width_and_container_on_gpu():
     out, rest = cli.decompress_image(st2, nb, quantbits=10, nz=2, setup=setup)
     assert np.array_equal(tiling.unextract_blocks(out, hh, ww), tiling.unextract_blocks(blocks, h, w))
     assert rest == [s[m:] for s, m in zip(split_state(reference_init_state()), mins)]
+
+
+@pytest.mark.parametrize("fmt", ["reference", "wave64"])
+@pytest.mark.parametrize("bitswap", [1, 0])
+def test_block_step_graph_equals_eager(fmt, bitswap):
+    """The lock-step block step replayed from a hipGraph (few chains per GPU: launch-bound) gives the streams of the
+    eager launches, word for word, in both directions and both stream formats; the receiver is lossless."""
+    from bitswap_amd.codec import Hip64Backend, HipBackend
+    model, zend, zcen = workload.build("cifar8", DEV, quantbits=8, small=16)
+    B, n = 4, 5
+    images = workload.synthetic_blocks(B * n, model.xs, seed=77).view(B, n, -1).to(torch.int32).to(DEV)
+    mk = (lambda: Hip64Backend(DEV)) if fmt == "wave64" else (lambda: HipBackend(DEV))
+    eager = BitSwapCodec(model, zend, zcen, quantbits=8, bitswap=bool(bitswap), backend=mk())
+    eager.use_graphs = False
+    graphed = BitSwapCodec(model, zend, zcen, quantbits=8, bitswap=bool(bitswap), backend=mk())
+    graphed.use_graphs = True
+    s1, m1 = eager.compress(images)
+    s2, m2 = graphed.compress(images)
+    assert any(g is not None for g in graphed._graphs.values()), "the block step was not captured"
+    assert s1.to_lists() == s2.to_lists() and np.array_equal(m1["cma"], m2["cma"])
+    out = graphed.decompress(s2, n)
+    assert sum(g is not None for g in graphed._graphs.values()) == 2
+    assert torch.equal(out, images)
+    init = initial_states(B)
+    if fmt == "wave64":
+        from bitswap_amd.hip import split_state
+        init = [split_state(s) for s in init]
+    assert s2.to_lists() == init
+    out1 = eager.decompress(s1, n)
+    assert torch.equal(out1, images)
