@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
                     help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
     ap.add_argument("--cdf-spec", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--no-graphs", action="store_true", help="never replay the block step from a hipGraph (single-stream runs)")
     ap.add_argument("--format", default="reference", choices=["reference", "wave64"],
                     help="reference: the reference's single-state word stream (default, the headline); wave64: the opt-in "
                          "64-state format -- table + coding step fused in one launch, one stream (implies --groups 1)")
@@ -136,6 +137,8 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                          timeline=tl, cdf_spec=args.cdf_spec, backend=backend)
     for c in codec.codecs:
         c.tables_on = args.tables_on
+        if args.no_graphs:
+            c.use_graphs = False
     init = initial_states(B, 10000, seed=100 + rank)
     states = codec.new_states(B, n, states=init)
     rest_lens = [torch.zeros_like(st.len) for st in states]

@@ -257,7 +257,8 @@ class BitSwapCodec:
         # (single stream only; a failed capture falls back to eager launches for good)
         self.use_graphs = "auto"
         self.graph_max_chains = 128
-        self._graphs = collections.OrderedDict()      # (state, direction) -> _StepGraph | None, the newest 4
+        self._graphs = collections.OrderedDict()      # (state, direction) -> _StepGraph | None, the newest few
+        self._graph_cap = 4
         # optional stream split (GroupedCodec): convs + table kernels on `bulk`, the serial rANS kernels
         # on `serial`; None = everything on the caller's current stream
         self.bulk = self.serial = None
@@ -402,9 +403,13 @@ class BitSwapCodec:
                 torch.cuda.synchronize()
                 self.use_graphs, g = False, None
             self._graphs[key] = g
-            while len(self._graphs) > 4:             # a graph pins its state and a private memory pool
+            while len(self._graphs) > self._graph_cap:   # a graph pins its state and a private memory pool
                 self._graphs.popitem(last=False)
         return g
+
+    def _graph_room(self, n):
+        """Let up to n graphs coexist (ragged runs: one per distinct number of active chains and direction)."""
+        self._graph_cap = max(4, min(int(n), 64))
 
     def prepare_graphs(self, state):
         """Capture both block-step graphs for `state` now (nothing is executed), e.g. before a timed region.  The
@@ -567,9 +572,16 @@ class BitSwapCodec:
         init_len = state.len.clone()
         rest_len = torch.zeros_like(state.len)
         active = [sum(1 for m in ns if m > xi) for xi in range(nmax)]
+        runs = collections.Counter(active)       # blocks coded with k chains active: a graph per k that is worth one
+        self._graph_room(2 * sum(1 for v in runs.values() if v >= 4))
         for xi in range(nmax):
             k = active[xi]
-            self.encode_block(state.prefix(k), x[:k, xi], rest_len if xi == 0 else None)
+            if xi == 0:
+                self.encode_block(state.prefix(k), x[:k, xi], rest_len)
+            elif runs[k] >= 4:
+                self.encode_block_fast(state.prefix(k), x[:k, xi])
+            else:
+                self.encode_block(state.prefix(k), x[:k, xi])
         self.backend.check(state, "compress_ragged")
         lens, init_len, rest_len = state.len.cpu().numpy().astype(np.int64), init_len.cpu().numpy(), rest_len.cpu().numpy()
         nsa = np.array(ns, dtype=np.int64)
@@ -584,9 +596,13 @@ class BitSwapCodec:
         assert all(a >= b for a, b in zip(ns, ns[1:])), "chains must be sorted by decreasing length"
         nmax = ns[0]
         out = [[None] * m for m in ns]
+        active = [sum(1 for m in ns if m > xi) for xi in range(nmax)]
+        runs = collections.Counter(active)
+        self._graph_room(2 * sum(1 for v in runs.values() if v >= 4))
         for xi in reversed(range(nmax)):
-            k = sum(1 for m in ns if m > xi)
-            xb = self.decode_block(state.prefix(k))
+            k = active[xi]
+            eager = xi == nmax - 1 or runs[k] < 4           # the first receiver step warms the libraries up
+            xb = self.decode_block(state.prefix(k)) if eager else self.decode_block_fast(state.prefix(k))
             for c in range(k):
                 out[c][xi] = xb[c]
         self.backend.check(state, "decompress_ragged")

@@ -246,11 +246,15 @@ class RansState:
         length drop out of a lock-step run from the back: codec.compress_ragged)."""
         if k == self.B:
             return self
-        v = object.__new__(RansState)
-        v.B, v.cap, v.device = int(k), self.cap, self.device
-        v.head, v.stack, v.len, v.status = self.head[:k], self.stack[:k], self.len[:k], self.status[:k]
+        cache = self.__dict__.setdefault("_prefixes", {})
+        v = cache.get(int(k))        # the same view object every time: a captured block step (hipGraph) pins its tensors
+        if v is None:
+            v = object.__new__(RansState)
+            v.B, v.cap, v.device = int(k), self.cap, self.device
+            v.head, v.stack, v.len, v.status = self.head[:k], self.stack[:k], self.len[:k], self.status[:k]
+            cache[int(k)] = v
         ml = getattr(self, "min_len", None)
-        if ml is not None:
+        if ml is not None and getattr(v, "min_len", None) is None:
             v.min_len = ml[:k]
         return v
 
@@ -375,11 +379,15 @@ class RansState64:
     def prefix(self, k):
         if k == self.B:
             return self
-        v = object.__new__(RansState64)
-        v.B, v.cap, v.device = int(k), self.cap, self.device
-        v.head, v.stack, v.len64, v.status = self.head[:k], self.stack[:k], self.len64[:k], self.status[:k]
+        cache = self.__dict__.setdefault("_prefixes", {})
+        v = cache.get(int(k))
+        if v is None:
+            v = object.__new__(RansState64)
+            v.B, v.cap, v.device = int(k), self.cap, self.device
+            v.head, v.stack, v.len64, v.status = self.head[:k], self.stack[:k], self.len64[:k], self.status[:k]
+            cache[int(k)] = v
         ml = getattr(self, "min_len", None)
-        if ml is not None:
+        if ml is not None and getattr(v, "min_len", None) is None:
             v.min_len = ml[:k]
         return v
 

@@ -19,11 +19,13 @@ What is different, MI355X-first:
   * `fuse()`: on a HIP device in compress mode the pointwise work between the convolutions (bias,
     ELU, residual add, the scale heads) runs as ONE launch per convolution
     (bitswap_amd/csrc/net_epilogue.hip) and the mu/std head pair is a single convolution with
-    stacked filters.  From `gemm_min_batch` blocks per call on, the 3x3 / 5x5 ResNet and head convolutions
+    stacked filters.  The 3x3 / 5x5 ResNet and head convolutions
     themselves run in the Winograd domain (`conv_algo = "winograd"`, bitswap_amd/winograd.py): HIP transform
     kernels around one batched GEMM per convolution.  Sender and receiver must both use the same route: the
     parameters differ from the unfused path in the last float32 bits.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -211,13 +213,15 @@ class Model(nn.Module):
         self.nn_batch = nn_batch
         self.fused = False
         # ResNet convs of the fused path: "winograd" (transform-domain batched GEMM, 3x3 and 5x5), "gemm5" (5x5 as
-        # five row GEMMs, 3x3 on MIOpen) or "miopen"; below gemm_min_batch images MIOpen always runs them
+        # five row GEMMs, 3x3 on MIOpen) or "miopen"; below gemm_min_batch images MIOpen always runs them.  Since round 2
+        # the Winograd route wins at every batch size (13 chains: 19.8 -> 13.1 ms per step, one chain: 12.9 -> 10.4,
+        # profiles/r02j), so the threshold is 1; BITSWAP_GEMM_MIN_BATCH overrides it for experiments
         self.conv_algo = "winograd"
         # input convs of the stacks (Cin = zchannels or 4 x image channels) in the Winograd domain too: leaves nothing to
         # MIOpen from gemm_min_batch blocks per call on, but the K = 8..12 batched GEMMs run no faster than MIOpen's
         # kernels (profiles/r02g_kernel_stats.txt: 177 vs 177 ms per step), so it is an option, not the default
-        self.wino_inputs = False
-        self.gemm_min_batch = 24
+        self.wino_inputs = os.environ.get("BITSWAP_WINO_INPUTS", "0") == "1"
+        self.gemm_min_batch = int(os.environ.get("BITSWAP_GEMM_MIN_BATCH", "1"))
         self.gemm_backend = "ck"     # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs
         self._heads, self._heads_u, self._gen_mu_u = {}, {}, None
         self.conditional_gen_std = conditional_gen_std

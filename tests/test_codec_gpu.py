@@ -643,3 +643,26 @@ def test_block_step_graph_equals_eager(fmt, bitswap):
     assert s2.to_lists() == init
     out1 = eager.decompress(s1, n)
     assert torch.equal(out1, images)
+
+
+def test_ragged_chains_with_graph_replay():
+    """config 4 / demo path: chains of different lengths in lock-step, every run of >= 4 blocks with the same number of
+    active chains replayed from its own hipGraph (prefix views of the state are cached so that a graph's tensors stay
+    put): same streams as eager launches, lossless, in both stream formats."""
+    from bitswap_amd.codec import Hip64Backend, HipBackend
+    model, zend, zcen = workload.build("imagenetcrop4", DEV, quantbits=10, small=16, nn_batch=4)
+    lens = [9, 2, 14, 9, 6]
+    chains = [workload.synthetic_blocks(n, model.xs, seed=90 + i).to(torch.int32) for i, n in enumerate(lens)]
+    for mk in (lambda: HipBackend(DEV), lambda: Hip64Backend(DEV)):
+        res = {}
+        for graphs in (False, True):
+            codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True, backend=mk())
+            codec.use_graphs = graphs
+            state, order, met = codec.compress_ragged(chains)
+            res[graphs] = (state.to_lists(), met["total"].copy())
+            if graphs:
+                assert sum(g is not None for g in codec._graphs.values()) >= 2
+                out = codec.decompress_ragged(state, met["nblocks"])
+                for k, i in enumerate(order):
+                    assert torch.equal(out[k].cpu(), chains[i])
+        assert res[True][0] == res[False][0] and np.array_equal(res[True][1], res[False][1])
