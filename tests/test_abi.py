@@ -39,6 +39,12 @@ def test_argument_validation_needs_no_gpu():
     # null pointers / bad sizes are rejected on the host before any launch
     assert L.bs_rans_push(None, None, None, 0, None, None, 1, 1, 31, None, None) == hip.EINVAL
     assert L.bs_table_rows_f64(None, 1, 16, 31, 4, None, None, 17, None, None) == hip.EINVAL
+    assert L.bs_logistic_tables(None, 0, None, None, None, 0, 1, 1, 256, 31, 8, None, 260, 0, None, None) == hip.EINVAL
+    assert L.bs_layer_pop64(None, None, None, 0, None, 0, None, None, None, 0, 0, 1, 64, 256, 31, 8, None, None, 0, None,
+                            None, None) == hip.EINVAL
+    assert L.bs_layer_push64(None, None, None, 0, None, 0, None, None, None, 0, 0, None, 1, 64, 256, 31, 8, None,
+                             None) == hip.EINVAL
+    assert L.bs_cdf_spec() == 2
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
