@@ -626,18 +626,36 @@ class Model(nn.Module):
         return logrecon, logdec, logenc, zsamples
 
 
-def elbo_bits(model, x):
+def elbo_bits(model, x, batch=256):
     """Per-image negative ELBO in bits, [B]: what the reference computes with a batch of one as
-    `-logrecon + sum(-logdec + logenc)` (mnist_compress.py:170-174) for its `elbos` metric."""
+    `-logrecon + sum(-logdec + logenc)` (mnist_compress.py:170-174) for its `elbos` metric.  Model.loss()
+    (mnist_train.py:441-490) averages its terms over the batch; here the same terms are kept per image, so one pass
+    over a batch gives every image's value (the reference's loop makes 10,000 batch-1 passes for 100 x 100 images)."""
+    from . import rand as random
     was = model.compressing
     model.compress(False)
     try:
         with torch.no_grad():
             out = []
-            for i in range(x.shape[0]):   # loss() averages over the batch: keep the reference's per-image call
-                logrecon, logdec, logenc, _ = model.loss(x[i:i + 1])
-                out.append(-logrecon + torch.sum(-logdec + logenc))
-            return torch.stack(out)
+            for s in range(0, x.shape[0], batch):
+                xb = x[s:s + batch]
+                n = xb.shape[0]
+                total = torch.zeros(n, device=xb.device)
+                z = None
+                for i in range(model.nz):
+                    mu, scale = model.infer(i)(given=xb if i == 0 else z)
+                    z_next = random.transform(random.logistic_eps(mu.shape, device=mu.device), mu, scale)
+                    total += random.logistic_logp(mu, scale, z_next).flatten(1).sum(1)               # + logenc_i
+                    mu, scale = model.generate(i)(given=z_next)
+                    if i == 0:
+                        total -= random.discretized_logistic_logp(mu, scale, xb).sum(1)             # - logrecon
+                    else:
+                        total -= random.logistic_logp(mu, scale, z).flatten(1).sum(1)               # - logdec_{i-1}
+                    z = z_next
+                one, zero = torch.ones(1, device=xb.device), torch.zeros(1, device=xb.device)
+                total -= random.logistic_logp(zero, one, z).flatten(1).sum(1)                       # - logdec_{nz-1}
+                out.append(total * model.bitsscale)
+            return torch.cat(out)
     finally:
         model.compress(was)
 

@@ -406,3 +406,17 @@ def test_wave64_container_and_demo_path():
     assert rest == [s[m:] for s, m in zip(init, mins)]          # every state: the untouched tail of its initial words
     with pytest.raises(ValueError):
         container.unpack64(arr[:-1])
+
+
+def test_elbo_metric_batched_equals_per_image_loss(monkeypatch):
+    """model.elbo_bits (the `elbos` metric of the CLIs, mnist_compress.py:170-174) in one batched pass against the
+    reference's formulation -- Model.loss() on one image at a time -- with the sampling noise pinned."""
+    from bitswap_amd.model import elbo_bits
+    m = workload.synthetic_model("cifar", 2, "cpu", small=8)
+    x = workload.synthetic_blocks(5, m.xs, seed=1).view(-1, *m.xs).float()
+    monkeypatch.setattr(rand, "logistic_eps", lambda shape, device, bound=1e-5: torch.full(shape, 0.3, device=device))
+    got = elbo_bits(m, x, batch=2)
+    m.compress(False)
+    with torch.no_grad():
+        want = torch.stack([(-lr + torch.sum(-ld + le)) for lr, ld, le, _ in (m.loss(x[i:i + 1]) for i in range(5))])
+    assert torch.allclose(got, want, rtol=1e-5)
