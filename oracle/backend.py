@@ -73,13 +73,29 @@ class OracleBackend:
     def table_buffer(self, B, D, K):
         return None
 
+    @staticmethod
+    def uniform_step(endpoints, tol_ulps=8.0):
+        """Independent restatement of the product's decision rule (bitswap_amd.bins.uniform_step, tests compare the
+        two): bin width h = (e[K-2] - e[0]) / (K - 2) per row if every endpoint lies within tol_ulps units in the last
+        place of e[0] + j*h -- uniform-width bins, discretization.py:105-118 -- else None."""
+        e = np.asarray(endpoints.detach().cpu().numpy() if torch.is_tensor(endpoints) else endpoints, dtype=np.float64)
+        if e.ndim != 2 or e.shape[1] < 3:
+            return None
+        n = e.shape[1] - 1
+        with np.errstate(all="ignore"):
+            h = (e[:, -1] - e[:, 0]) / np.float64(n)
+            if not np.all(np.isfinite(h)) or not np.all(h > 0):
+                return None
+            dev = np.abs(e - (e[:, :1] + np.arange(n + 1, dtype=np.float64)[None] * h[:, None]))
+            lim = tol_ulps * np.spacing(np.maximum(np.abs(e[:, 0]), np.abs(e[:, -1])))
+        return np.ascontiguousarray(h) if np.all(dev <= lim[:, None]) else None
+
     def bin_step(self, endpoints):
-        """Same decision as HipBackend.bin_step (bitswap_amd.bins.uniform_step); only the deterministic mode has a
-        spec 2 -- the libm / torch modes restate the reference formula and ignore it."""
-        from bitswap_amd.bins import uniform_step
+        """Same decision as HipBackend.bin_step; only the deterministic mode has a spec 2 -- the libm / torch modes
+        restate the reference formula and ignore it."""
         if self.mode != O.MODE_DET or endpoints.shape[1] + 1 < 256:
             return None
-        return uniform_step(endpoints)
+        return self.uniform_step(endpoints)
 
     def _mode(self, step):
         return O.MODE_DET2 if (step is not None and self.mode == O.MODE_DET) else self.mode

@@ -98,6 +98,10 @@ def test_uniform_step_decides_the_cdf_spec():
     bad = e.copy()
     bad[3, 500] += 1e-9
     assert bins.uniform_step(bad) is None
+    # the oracle decides on its own, and identically
+    for tab in (e, te, xe, bad):
+        a, b = bins.uniform_step(tab), OracleBackend.uniform_step(tab)
+        assert (a is None and b is None) or np.array_equal(a, b)
     # the codec: spec 2 on the uniform layers and the pixels, spec 1 on the top layer; cdf_spec=1 turns it off
     model, zend, zcen = workload.build("cifar8", "cpu", quantbits=8, small=8)
     c2 = BitSwapCodec(model, zend, zcen, quantbits=8, backend=OracleBackend(O.MODE_DET))
