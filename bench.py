@@ -43,9 +43,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 # VALU issue model of k_logistic (the bound it actually runs into): 256 CUs x 4 SIMDs, one 64-lane VALU instruction
 # occupies a 16-lane SIMD for 4 cycles (v_rcp_f64: 16), 2.4 GHz nominal -> 614.4 G wave-instructions / s
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
-# issue slots per (chain, dim) row of the K = 1024 decode-flavour kernel, from `tools/isa_count.py` on the shipped
-# code object: VALU instructions in the per-row loop + 3 extra slots per quarter-rate v_rcp_f64
-VALU_SLOTS_PER_ROW = {2: 469, 1: 692}   # CDF spec 2 (uniform bins) / spec 1
+# issue slots per (chain, dim) row of the K = 1024 decode-flavour kernel, from `tools/isa_count.py` ("largest loop") on
+# the shipped code object: VALU instructions of the per-row loop + 3 extra slots per quarter-rate v_rcp_f64.  Under
+# sustained float64 load the chip runs at about 4/4.9 of the nominal clock (tools/instr_rate.hip), so 0.82 here is the
+# practical ceiling
+VALU_SLOTS_PER_ROW = {2: 399, 1: 648}   # CDF spec 2 (uniform bins) / spec 1
 
 TITLES = {"mnist2": "MNIST-shaped 2-latent-layer", "cifar8": "CIFAR-10-shaped 8-latent-layer",
           "imagenet4": "ImageNet32-shaped 4-latent-layer", "imagenetcrop4": "ImageNet-crop-shaped 4-latent-layer"}

@@ -115,6 +115,13 @@ __device__ __forceinline__ double det_exp(double a) {
 
 __device__ __forceinline__ double det_sigmoid(double t) { return recip_1_to_huge(1.0 + det_exp(-t)); }
 
+// RN(1 / scale): the same Newton sequence.  It is invariant under scaling by powers of two as long as x and 1/x stay
+// normal, which every positive finite scale a model head can emit satisfies by hundreds of binades; zero, negative,
+// Inf, NaN and subnormal scales come out as NaN / Inf / a negative number and the caller's validity check (scale > 0,
+// rs > 0) flags the chain, as it would after IEEE division.  Saves the v_div_scale / v_div_fmas / v_div_fixup
+// scaffolding per row.
+__device__ __forceinline__ double recip_scale(double x) { return recip_1_to_huge(x); }
+
 // ------------------------------------------------------------------------------------------
 // integer tail shared by the table kernels.  A lane holds t[i] = trunc(pmf * M) of NPL consecutive bins
 // (the reference's frequency is f = t + 1, mnist_compress.py:30,33; the +1 is folded into the sums and
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
     for (int b = b0; b < b1; ++b) {
         const int64_t row = (int64_t)b * D + d;
         const double m_ = (double)mu_n;
-        const double rs = 1.0 / (double)sc_n;
+        const double rs = recip_scale((double)sc_n);
         // NaN / Inf / non-positive parameters (a broken checkpoint) would still produce a well-formed table of
         // garbage: flag the chain instead (first error sticks; later launches skip it)
         const bool okp = ((double)sc_n > 0.0) && (rs > 0.0) && (fabs(m_) < __builtin_huge_val());
@@ -1114,7 +1121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const int64_t prow = (int64_t)b * p_stride + d;
             const double m_ = (double)mu[prow];
             const double sc_ = (double)scale[prow];
-            const double rs = 1.0 / sc_;
+            const double rs = recip_scale(sc_);
             const bool okp = (sc_ > 0.0) && (rs > 0.0) && (fabs(m_) < __builtin_huge_val());
             Bins<NPL> bn;
             logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);

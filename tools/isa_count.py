@@ -21,20 +21,36 @@ def body(lines, name):
     return None
 
 
+def mix(ins, tag):
+    c = Counter(l.split()[0] for l in ins)
+    pick = lambda f: sum(v for k, v in c.items() if f(k))
+    valu, rcp = pick(lambda k: k.startswith('v_')), pick(lambda k: k.startswith('v_rcp_f64'))
+    print(f"{tag}: total {len(ins)}  valu {valu}  f64 {pick(lambda k: 'f64' in k)}  rcp_f64 {rcp}  "
+          f"issue slots (valu + 3 per quarter-rate rcp) {valu + 3 * rcp}  readlane {pick(lambda k: k.startswith('v_readlane'))}  "
+          f"salu {pick(lambda k: k.startswith('s_'))}  ds {pick(lambda k: k.startswith('ds_'))}  "
+          f"vmem {pick(lambda k: k.startswith(('global_', 'buffer_', 'flat_')))}")
+
+
 def main():
+    import re
     lines = open(sys.argv[1]).read().split('\n')
     for name in sys.argv[2:]:
         b = body(lines, name)
         if b is None:
             print(name, "not found")
             continue
-        ins = [l for l in b if l and not l.startswith(('.', ';', '//')) and not l.split(';')[0].rstrip().endswith(':')]
-        c = Counter(l.split()[0] for l in ins)
-        pick = lambda f: sum(v for k, v in c.items() if f(k))
-        print(f"{name}: total {len(ins)}  valu {pick(lambda k: k.startswith('v_'))}  f64 {pick(lambda k: 'f64' in k)}  "
-              f"rcp_f64 {pick(lambda k: k.startswith('v_rcp_f64'))}  readlane {pick(lambda k: k.startswith('v_readlane'))}  "
-              f"salu {pick(lambda k: k.startswith('s_'))}  ds {pick(lambda k: k.startswith('ds_'))}  "
-              f"vmem {pick(lambda k: k.startswith(('global_', 'buffer_', 'flat_')))}")
+        real = lambda seq: [l for l in seq if l and not l.startswith(('.', ';', '//')) and not l.split(';')[0].rstrip().endswith(':')]
+        mix(real(b), name + " [whole kernel]")
+        # the largest backward-branch region = the per-row loop of the table kernels (what the issue model counts)
+        labels = {l.split(':')[0]: i for i, l in enumerate(b) if re.match(r'^\.LBB\d+_\d+:', l)}
+        loops = []
+        for i, l in enumerate(b):
+            m = re.match(r'^s_c?branch\w*\s+(\.LBB\d+_\d+)', l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops.append((labels[m.group(1)], i))
+        if loops:
+            a, e = max(loops, key=lambda t: t[1] - t[0])
+            mix(real(b[a:e + 1]), name + " [largest loop]")
 
 
 if __name__ == "__main__":
