@@ -54,7 +54,9 @@ class WnConv2d(nn.Module):
         nn.init.zeros_(self.b)
         self._w = None      # folded weight (fold())
         self._w5 = None     # per-kernel-row GEMM operands of a 5x5 conv (Model.fuse())
-        self._wu = None     # Winograd-domain weights U [36, Cout, Cin] (Model.fuse())
+        self._wu = None     # Winograd-domain weights U [36, Cout, Cin] (Model.fuse()); channel-padded, see Model.fuse
+        self._wp = None     # input convs: weight with zero filters appended (padded output channels)
+        self._bp = None     # bias with zeros appended
 
     def weight(self):
         g = softplus(self.gain) if self.loggain else self.gain
@@ -66,14 +68,18 @@ class WnConv2d(nn.Module):
             self._w = self.weight().contiguous()
 
     def unfold(self):
-        self._w = self._w5 = self._wu = None
+        self._w = self._w5 = self._wu = self._wp = self._bp = None
+
+    def bias_p(self):
+        """Bias of the Winograd route (zero-padded to the padded channel count when there is one)."""
+        return self._bp if self._bp is not None else self.b
 
     def forward(self, x):
         w = self._w if self._w is not None else self.weight()
         return F.conv2d(x, w, self.b, stride=self.stride, padding=self.padding)
 
     def _load_from_state_dict(self, *a, **k):
-        self._w = self._w5 = self._wu = None
+        self._w = self._w5 = self._wu = self._wp = self._bp = None
         return super()._load_from_state_dict(*a, **k)
 
 
@@ -221,8 +227,16 @@ class Model(nn.Module):
         # MIOpen from gemm_min_batch blocks per call on, but the K = 8..12 batched GEMMs run no faster than MIOpen's
         # kernels (profiles/r02g_kernel_stats.txt: 177 vs 177 ms per step), so it is an option, not the default
         self.wino_inputs = os.environ.get("BITSWAP_WINO_INPUTS", "0") == "1"
+        # Winograd route: run with the ResNet width padded to the next multiple of 64 when that costs at most 8 dead
+        # channels (252, 254, 255 -> 256).  The batched GEMMs of [C x C] x [C x tiles] are 15-20 % faster at C = 256
+        # (tile quantisation: 3 row tiles of 96 for 252 rows; profiles/r02m), the transform kernels pay 1.6 % more
+        # traffic.  The dead channels carry zero weights and zero biases, so they stay exactly zero through ELU and the
+        # residual adds and never reach a result.
+        self.pad_channels = os.environ.get("BITSWAP_PAD_CHANNELS", "1") == "1"
+        self._cp = reswidth
         self.gemm_min_batch = int(os.environ.get("BITSWAP_GEMM_MIN_BATCH", "1"))
-        self.gemm_backend = "ck"     # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs
+        # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs ("" = torch's default)
+        self.gemm_backend = os.environ.get("BITSWAP_GEMM_BACKEND", "ck") or None
         self._heads, self._heads_u, self._gen_mu_u = {}, {}, None
         self.conditional_gen_std = conditional_gen_std
         pad5, pad = 2, (kernel_size - 1) // 2
@@ -329,11 +343,26 @@ class Model(nn.Module):
                     self._heads[f"gen{i + 1}"] = stack(self.deepgen_mu[i], self.deepgen_std[i])
                 if not self.conditional_gen_std:
                     self._gen_scale = (((2. / 255.) / 8.) + softplus(self.gen_std)).contiguous()
-                # the head convs (3x3) in the Winograd domain as well: U [36, Cout, W]
+                W = self.reswidth
+                cp = (W + 63) // 64 * 64
+                self._cp = cp if (self.pad_channels and 0 < cp - W <= 8) else W
+                extra = self._cp - W
+
+                def padw(w, cout=False, cin=False):
+                    """Zero filters / zero input planes appended where a dimension is the ResNet width."""
+                    if extra and cout and w.shape[0] == W:
+                        w = torch.cat([w, w.new_zeros((extra,) + tuple(w.shape[1:]))], 0)
+                    if extra and cin and w.shape[1] == W:
+                        w = torch.cat([w, w.new_zeros((w.shape[0], extra) + tuple(w.shape[2:]))], 1)
+                    return w.contiguous()
+
+                def padb(b):
+                    return torch.cat([b, b.new_zeros(extra)]).contiguous() if (extra and b.shape[0] == W) else b
+                # the head convs (3x3) in the Winograd domain as well: U [36, Cout, W (padded)]
                 from .winograd import transform_weights as _tw
-                self._heads_u = {k: _tw(w) for k, (w, b) in self._heads.items() if w.shape[-1] == 3}
+                self._heads_u = {k: _tw(padw(w, cin=True)) for k, (w, b) in self._heads.items() if w.shape[-1] == 3}
                 g0 = self.gen_mu[0]
-                self._gen_mu_u = _tw(g0._w) if g0.kernel_size == 3 else None
+                self._gen_mu_u = _tw(padw(g0._w, cin=True)) if g0.kernel_size == 3 else None
                 # ResNet convs (3x3 and 5x5, Cin == Cout) in the Winograd domain: U = G w G^T, [36, Cout, Cin]; the input
                 # convs of every stack (Cin = zchannels or 4 x image channels -> reswidth) get their U as well
                 # (Model.wino_inputs)
@@ -343,15 +372,23 @@ class Model(nn.Module):
                     if (isinstance(m, WnConv2d) and m.kernel_size in (3, 5) and m.stride == 1
                             and m.padding == m.kernel_size // 2
                             and (m.in_dim == m.out_dim or any(m is q for q in ins))):
-                        m._wu = transform_weights(m._w)
+                        m._wu = transform_weights(padw(m._w, cout=True, cin=True))
+                        m._bp = padb(m.b.detach())
+                        if any(m is q for q in ins):
+                            m._wp = padw(m._w, cout=True)
                     # 5x5 as five GEMMs (one per kernel row), the alternative path: W_dy [Cout, Cin*5]
                     if isinstance(m, WnConv2d) and m.kernel_size == 5 and m.in_dim == m.out_dim and m.stride == 1:
                         m._w5 = [m._w[:, :, dy, :].reshape(m.out_dim, m.in_dim * 5).contiguous() for dy in range(5)]
         return self
 
     @staticmethod
-    def _conv_nb(m, x):
-        return F.conv2d(x, m._w, None, stride=m.stride, padding=m.padding)
+    def _conv_nb(m, x, padded=False):
+        return F.conv2d(x, m._wp if (padded and m._wp is not None) else m._w, None, stride=m.stride, padding=m.padding)
+
+    def _unpad(self, h):
+        """NCHW activation leaving the Winograd route towards an unpadded consumer: drop the dead channels."""
+        return h[:, : self.reswidth].contiguous() if (torch.is_tensor(h) and h.dim() == 4 and h.shape[1] == self._cp
+                                                      and self._cp != self.reswidth) else h
 
     def _fused_in(self, seq, x, nxt=None):
         """Sequential([Squeeze2d,] WnConv2d, act) -> ELU(conv(x) + b), one epilogue launch.  If the block `nxt`
@@ -370,14 +407,14 @@ class Model(nn.Module):
             ts = int(round(m._wu.shape[0] ** 0.5))
             shape_out = (x.shape[0], m.out_dim) + tuple(x.shape[2:])
             v = hip.wino_fused(x.contiguous(), tuple(x.shape), 0, None, None, False, ts_out=ts)[2]
-            raw = _RawM(torch.bmm(m._wu, v), m.b, ts, shape_out)
+            shape_out = (x.shape[0], m._wu.shape[1]) + tuple(x.shape[2:])        # padded channel count
+            raw = _RawM(torch.bmm(m._wu, v), m.bias_p(), ts, shape_out)
             if follows and self._wino_ok(list(nxt[0].children()), torch.empty((shape_out[0], 0, shape_out[2], shape_out[3]))):
                 return raw
-            return hip.wino_fused(raw.m, shape_out, ts, m.b, None, True, want_act=True)[1]      # ELU(A^T M A + b)
-        c = self._conv_nb(m, x)
-        if follows and self._wino_ok(list(nxt[0].children()), c):
-            return _RawConv(c, m.b)
-        return hip.bias_residual_elu(c, m.b)[1]
+            return self._unpad(hip.wino_fused(raw.m, shape_out, ts, m.bias_p(), None, True, want_act=True)[1])  # ELU(A^T M A + b)
+        if follows and self._wino_ok(list(nxt[0].children()), x):
+            return _RawConv(self._conv_nb(m, x, padded=True), m.bias_p())       # zero filters appended: padded width
+        return hip.bias_residual_elu(self._conv_nb(m, x), m.b)[1]
 
     def _wino_ok(self, layers, h):
         return (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
@@ -427,29 +464,33 @@ class Model(nn.Module):
             shape = tuple(h.c.shape)
             _, h, v = hip.wino_fused(h.c, shape, 0, h.b, None, 3, want_act=True, ts_out=ts)
         else:
+            cin = layers[0].conv1._wu.shape[2]
+            if h.shape[1] < cin:            # an unpadded activation entering the padded route: append the dead channels
+                h = torch.cat([h, h.new_zeros((h.shape[0], cin - h.shape[1]) + tuple(h.shape[2:]))], 1)
             shape = tuple(h.shape)
             if ts - layers[0].conv1.kernel_size + 1 != 4:          # F(2x2,5x5) alternative: separate transforms
                 return self._res_wino_unfused(layers, h, (ts, ts - layers[0].conv1.kernel_size + 1))
             v = hip.wino_fused(h, shape, 0, None, None, True, ts_out=ts)[2]                   # B^T ELU(h) B
         for k, L in enumerate(layers):
-            v = hip.wino_fused(torch.bmm(L.conv1._wu, v), shape, ts, L.conv1.b, None, True, ts_out=ts)[2]
+            b1, b2 = L.conv1.bias_p(), L.conv2.bias_p()
+            v = hip.wino_fused(torch.bmm(L.conv1._wu, v), shape, ts, b1, None, True, ts_out=ts)[2]
             m2 = torch.bmm(L.conv2._wu, v)
             if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
                 if want_v:                # ... and only as the operand of the 3x3 head convs
-                    return _WinoOperand(hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, ts_out=6)[2], shape)
-                return hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, want_act=True)[1]
-            h, _, v = hip.wino_fused(m2, shape, ts, L.conv2.b, h, True, want_sum=True, ts_out=ts)
+                    return _WinoOperand(hip.wino_fused(m2, shape, ts, b2, h, True, ts_out=6)[2], shape)
+                return hip.wino_fused(m2, shape, ts, b2, h, True, want_act=True)[1]
+            h, _, v = hip.wino_fused(m2, shape, ts, b2, h, True, want_sum=True, ts_out=ts)
 
     def _res_wino_unfused(self, layers, h, cfg):
         from . import hip
         shape = tuple(h.shape)
         for k, L in enumerate(layers):
             m1 = torch.bmm(L.conv1._wu, hip.wino_in(h, None, True, cfg))              # conv1(ELU(h))
-            t = hip.wino_out(m1, shape, L.conv1.b, None, False, True, cfg)[1]         # ELU(. + b1)
+            t = hip.wino_out(m1, shape, L.conv1.bias_p(), None, False, True, cfg)[1]  # ELU(. + b1)
             m2 = torch.bmm(L.conv2._wu, hip.wino_in(t, None, False, cfg))
             if k == len(layers) - 1:
-                return hip.wino_out(m2, shape, L.conv2.b, h, False, True, cfg)[1]
-            h = hip.wino_out(m2, shape, L.conv2.b, h, True, False, cfg)[0]
+                return hip.wino_out(m2, shape, L.conv2.bias_p(), h, False, True, cfg)[1]
+            h = hip.wino_out(m2, shape, L.conv2.bias_p(), h, True, False, cfg)[0]
 
     def _fused_res(self, seq, h, want_v=False):
         """Sequential(ResNetBlock, act) on an activated input h (Pass: identity).  Per layer
@@ -464,6 +505,7 @@ class Model(nn.Module):
         if (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
                 and h.shape[-1] % 4 == 0 and h.shape[-2] % 4 == 0):
             return self._res_wino(layers, h, want_v and layers[0].conv1._wu.shape[0] in (36, 64))
+        h = self._unpad(h)
         if (self.conv_algo in ("winograd", "gemm5") and layers[0].conv1.kernel_size == 5
                 and h.shape[0] >= self.gemm_min_batch and h.shape[-1] % 4 == 0 and layers[0].conv1._w5 is not None):
             return self._res5_gemm(layers, h)
@@ -482,7 +524,7 @@ class Model(nn.Module):
             x = hip.wino_fused(torch.bmm(self._heads_u[key], h.v), (h.shape[0], w.shape[0]) + h.shape[2:], 6, None,
                                None, False, want_sum=True)[0]
             return hip.head_params(x, b, mode)
-        return hip.head_params(F.conv2d(h, w, None, stride=1, padding=(w.shape[-1] - 1) // 2), b, mode)
+        return hip.head_params(F.conv2d(self._unpad(h), w, None, stride=1, padding=(w.shape[-1] - 1) // 2), b, mode)
 
     def _infer_stack_fused(self, i, h):
         from . import hip
@@ -503,6 +545,7 @@ class Model(nn.Module):
                 x = hip.wino_fused(torch.bmm(self._gen_mu_u, h.v), (h.shape[0], g0.out_dim) + h.shape[2:], 6, g0.b,
                                    None, False, want_sum=True)[0]
                 return self.gen_mu[1](x), self._gen_scale
+            h = self._unpad(h)
             mu = self.gen_mu(h)
             if self.conditional_gen_std:
                 scale = ((2. / 255.) / 8.) + softplus(self.gen_std(h))
