@@ -14,6 +14,7 @@ schedule code on the CPU.
 """
 import collections
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -256,7 +257,7 @@ class BitSwapCodec:
         # hipGraph replay of the block step: "auto" = when the chains are few enough for the step to be launch-bound
         # (single stream only; a failed capture falls back to eager launches for good)
         self.use_graphs = "auto"
-        self.graph_max_chains = 128
+        self.graph_max_chains = int(os.environ.get("BITSWAP_GRAPH_MAX_CHAINS", "128"))
         self._graphs = collections.OrderedDict()      # (state, direction) -> _StepGraph | None, the newest few
         self._graph_cap = 4
         # optional stream split (GroupedCodec): convs + table kernels on `bulk`, the serial rANS kernels
