@@ -292,6 +292,7 @@ class BitSwapCodec:
         if buf is None or buf.shape[0] < B:
             buf = self.backend.table_buffer(B, D, K)
             self._cdf_bufs[key] = buf
+            self._graphs.clear()           # captured block steps hold pointers into the buffer that just went away
         return buf if buf is None or buf.shape[0] == B else buf[:B]
 
     # ---- stream split helpers ---------------------------------------------------------------------
