@@ -211,12 +211,14 @@ def dataset_main(dataset, default_nz, nz_loop=None):
 # single-image path: imagenetcrop_compress.compress / demo_compress.compress / demo_decompress.decompress
 # ---------------------------------------------------------------------------------------------
 def crop_setup(gpu, nz=4, quantbits=10, synthetic=False, params=None, outdir=".", backend=None, small=None,
-               nn_batch=32):
+               nn_batch=None):
     """Model + bins of the crop/demo scripts.  nn_batch: the conv stacks always run on micro-batches of
     exactly this many blocks (zero padded), so a block's (mu, scale) bits do not depend on which other
     images are coded next to it -- an image compressed in a lock-step batch of many can be decompressed
     on its own (demo_decompress.py) and vice versa.  32: enough columns for the Winograd-domain GEMM
     path (4.2 vs 2.3 Mpixel/s for 100 images on one GPU), 0.4 s to decode a single 80-block image."""
+    if nn_batch is None:
+        nn_batch = int(os.environ.get("BITSWAP_CROP_NN_BATCH", "32"))
     rank, world = dist.init() if backend is None else (0, 1)
     if backend is not None:
         dev = torch.device("cpu")

@@ -574,13 +574,17 @@ class BitSwapCodec:
         init_len = state.len.clone()
         rest_len = torch.zeros_like(state.len)
         active = [sum(1 for m in ns if m > xi) for xi in range(nmax)]
-        runs = collections.Counter(active)       # blocks coded with k chains active: a graph per k that is worth one
-        self._graph_room(2 * sum(1 for v in runs.values() if v >= 4))
+        # blocks coded with k chains active: a graph per k that is worth one.  Captures cost tens of ms each, so only for
+        # a handful of chains with long runs (a single demo image: 8.0 -> 5.4 ms per block in the 64-state format); with
+        # many images the active count changes every few blocks and eager launches win (profiles/r02o_crop_runs.txt)
+        runs = collections.Counter(active)
+        worth = {k for k, v in runs.items() if v >= 8} if B <= 16 else set()
+        self._graph_room(2 * len(worth))
         for xi in range(nmax):
             k = active[xi]
             if xi == 0:
                 self.encode_block(state.prefix(k), x[:k, xi], rest_len)
-            elif runs[k] >= 4:
+            elif k in worth:
                 self.encode_block_fast(state.prefix(k), x[:k, xi])
             else:
                 self.encode_block(state.prefix(k), x[:k, xi])
@@ -600,10 +604,11 @@ class BitSwapCodec:
         out = [[None] * m for m in ns]
         active = [sum(1 for m in ns if m > xi) for xi in range(nmax)]
         runs = collections.Counter(active)
-        self._graph_room(2 * sum(1 for v in runs.values() if v >= 4))
+        worth = {k for k, v in runs.items() if v >= 8} if len(ns) <= 16 else set()
+        self._graph_room(2 * len(worth))
         for xi in reversed(range(nmax)):
             k = active[xi]
-            eager = xi == nmax - 1 or runs[k] < 4           # the first receiver step warms the libraries up
+            eager = xi == nmax - 1 or k not in worth        # the first receiver step warms the libraries up
             xb = self.decode_block(state.prefix(k)) if eager else self.decode_block_fast(state.prefix(k))
             for c in range(k):
                 out[c][xi] = xb[c]

@@ -646,12 +646,12 @@ def test_block_step_graph_equals_eager(fmt, bitswap):
 
 
 def test_ragged_chains_with_graph_replay():
-    """config 4 / demo path: chains of different lengths in lock-step, every run of >= 4 blocks with the same number of
+    """config 4 / demo path: chains of different lengths in lock-step, every run of >= 8 blocks with the same number of
     active chains replayed from its own hipGraph (prefix views of the state are cached so that a graph's tensors stay
     put): same streams as eager launches, lossless, in both stream formats."""
     from bitswap_amd.codec import Hip64Backend, HipBackend
     model, zend, zcen = workload.build("imagenetcrop4", DEV, quantbits=10, small=16, nn_batch=4)
-    lens = [9, 2, 14, 9, 6]
+    lens = [17, 2, 30, 17, 9]
     chains = [workload.synthetic_blocks(n, model.xs, seed=90 + i).to(torch.int32) for i, n in enumerate(lens)]
     for mk in (lambda: HipBackend(DEV), lambda: Hip64Backend(DEV)):
         res = {}
