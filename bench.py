@@ -116,6 +116,14 @@ def cpu_baseline(args, name):
     return out
 
 
+def _valu_busy(spec):
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "valu_busy.json")))["kernels"]
+        return d["k_logistic<16,float,decode,uniform>" if spec == 2 else "k_logistic<16,float,decode,generic>"]["valu_busy"]
+    except Exception:
+        return None
+
+
 def algorithmic_bytes_per_block(codec):
     """SURVEY.md 8(d), one direction: per z-table op (2nz-1 of them) Z(K-1)8 + 2Z4 + Z4; x-op 2X4 + X; prior Z(8+4)."""
     Z, X, K, nz = codec.Z, codec.X, codec.K, codec.codecs[0].nz
@@ -256,7 +264,10 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                 # are mostly not moved: see `traffic`)
                 "valu_issue": None if slots is None else {
                     "slots_per_row": slots, "achieved_Ginstr_s": round(rows * slots / avg / 1e9, 1),
-                    "peak_Ginstr_s": round(VALU_PEAK_GINSTR, 1), "frac": round(rows * slots / avg / 1e9 / VALU_PEAK_GINSTR, 4)}}
+                    "peak_Ginstr_s": round(VALU_PEAK_GINSTR, 1), "frac": round(rows * slots / avg / 1e9 / VALU_PEAK_GINSTR, 4),
+                    # measured by SQ counters (profiles/valu_busy.json, tools/pmc_valu.sh): share of the SIMD cycles the
+                    # VALU pipe is busy while the kernel runs, at the clock the chip actually holds under float64 load
+                    "valu_busy_pmc": _valu_busy(spec)}}
     breakdown = {k: round(v[0] / dt, 4) for k, v in sorted(totals.items())} if totals else None
     res = {"workload": name, "chains_per_gpu": B, "chain_groups": groups, "steps": K, "warmup": W,
            "value": world * B * K * 1024 / dt, "ms_per_step": dt / K * 1e3, "lossless": ok, "bits_per_dim": bpd,
