@@ -290,10 +290,23 @@ class BitSwapCodec:
         key = (D, K)
         buf = self._cdf_bufs.get(key)
         if buf is None or buf.shape[0] < B:
+            if buf is not None and self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                # replacing the buffer would free memory other captured steps point into, in the middle of a capture:
+                # refuse (the capture fails, the codec falls back to eager launches); callers that know the largest
+                # chain count reserve the buffers first (_reserve_tables)
+                raise RuntimeError("cdf-row buffer too small inside a hipGraph capture")
+            if buf is not None and self._graphs:
+                torch.cuda.synchronize()   # no replay in flight while its graph is destroyed
+                self._graphs.clear()       # captured block steps hold pointers into the buffer that is going away
             buf = self.backend.table_buffer(B, D, K)
             self._cdf_bufs[key] = buf
-            self._graphs.clear()           # captured block steps hold pointers into the buffer that just went away
         return buf if buf is None or buf.shape[0] == B else buf[:B]
+
+    def _reserve_tables(self, B):
+        """Size the cdf-row buffers for B chains now, so that no later, larger call replaces them under a captured step
+        (ragged receivers start with the longest chain alone and grow)."""
+        self._cdf(B, self.Z, self.K)
+        self._cdf(B, self.X, 256)
 
     # ---- stream split helpers ---------------------------------------------------------------------
     def _on(self, stream):
@@ -406,6 +419,7 @@ class BitSwapCodec:
                 self.use_graphs, g = False, None
             self._graphs[key] = g
             while len(self._graphs) > self._graph_cap:   # a graph pins its state and a private memory pool
+                torch.cuda.synchronize()
                 self._graphs.popitem(last=False)
         return g
 
@@ -604,6 +618,7 @@ class BitSwapCodec:
         out = [[None] * m for m in ns]
         active = [sum(1 for m in ns if m > xi) for xi in range(nmax)]
         runs = collections.Counter(active)
+        self._reserve_tables(len(ns))
         worth = {k for k, v in runs.items() if v >= 8} if len(ns) <= 16 else set()
         self._graph_room(2 * len(worth))
         for xi in reversed(range(nmax)):
