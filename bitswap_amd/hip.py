@@ -429,15 +429,17 @@ class RansState64:
 
 
 def _layer64_args(state, endpoints, mu, scale, step):
-    B, D = (state.B, endpoints.shape[0]) if mu.dim() == 1 or mu.shape[0] == 1 and state.B != 1 else mu.shape
+    """mu/scale hold either one row set per chain [B, D] or a single one shared by all chains ([D] or [1, D]: the
+    prior) -- p_stride D or 0."""
+    B, D = state.B, endpoints.shape[0]
     K = endpoints.shape[1] + 1
     endpoints, es = _row_stride(endpoints, K - 1)
     step = _step(step, D)
     mu, scale = mu.contiguous(), scale.contiguous()
-    shared = mu.numel() == D and state.B != 1
-    if mu.numel() not in (D, state.B * D):
-        raise BitswapHipError(f"mu/scale must hold {D} (shared) or {state.B}x{D} values")
-    return state.B, D, K, endpoints, es, step, mu, scale, (0 if (shared or state.B == 1 and mu.numel() == D) else D)
+    if mu.shape != scale.shape or mu.numel() not in (D, B * D):
+        raise BitswapHipError(f"mu/scale must both hold {D} (shared) or {B}x{D} values")
+    ps = D if (mu.numel() == B * D and mu.dim() == 2) else 0
+    return B, D, K, endpoints, es, step, mu, scale, ps
 
 
 def layer_pop64(state, endpoints, mu, scale, bits=31, quantbits=10, centres=None, step=None):
