@@ -72,7 +72,7 @@ def stream_meta(codec, model, chains_in_call):
     format, the CDF specification per table, and the route the conv stacks took (their float32 results differ in the
     last bits between routes, batch shapes and BLAS backends).  Written next to the bitstreams as stream_meta.json."""
     from . import hip
-    return {"stream_format": "wave64" if getattr(codec.backend, "name", "") == "hip-wave64" else "reference",
+    return {"stream_format": "wave64" if getattr(codec.backend, "name", "").endswith("wave64") else "reference",
             "ansbits": codec.bits, "quantbits": codec.q, "bitswap": codec.bitswap,
             "cdf_spec": {"z": [2 if s is not None else 1 for s in codec.zstep], "x": 2 if codec.xstep is not None else 1},
             "library_abi": hip.ABI_VERSION, "backend": getattr(codec.backend, "name", "?"),
@@ -84,9 +84,10 @@ def stream_meta(codec, model, chains_in_call):
 
 def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndatapoints=100, decompress=False,
              synthetic=False, data=None, params=None, outdir=".", backend=None, small=None, verbose=True,
-             save_bins=False):
+             save_bins=False, fmt="reference"):
     """One (dataset, nz, quantbits, scheme) experiment set.  Returns dict of the metric arrays on
-    rank 0 (None on other ranks)."""
+    rank 0 (None on other ranks).  fmt "wave64": the opt-in 64-state stream format (pickles then hold 64 sub-state
+    lists per experiment and carry the suffix _wave64)."""
     rank, world = dist.init()
     dev = torch.device("cpu") if backend is not None else (torch.device("cuda", gpu) if world == 1 else dist.local_device())
     if dev.type == "cuda":
@@ -128,7 +129,9 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
 
     mine = dist.shard_chains(experiments, world, rank)
     inits = initial_states(experiments, 10000, seed=100)        # experiment ei gets the ei-th draw (:158)
-    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap), backend=backend)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
+                         backend=_format_backend(fmt, backend, dev))
+    wave64 = hasattr(codec.backend.new_state([inits[0]], 16), "len64") if fmt == "wave64" else False
     x = images[torch.from_numpy(randindices[mine].reshape(-1))].view(len(mine), ndatapoints, -1).to(torch.int32)
     state = codec.new_states(len(mine), ndatapoints, states=[inits[c] for c in mine])
 
@@ -145,7 +148,8 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
     sdir = os.path.join(outdir, "bitstreams", dataset, f"nz{nz}", scheme)
     os.makedirs(sdir, exist_ok=True)
     for c, s in zip(mine, sent):
-        container.save_state(os.path.join(sdir, f"{scheme}_{quantbits}bits_nz{nz}_experiment{c + 1}"), s)
+        container.save_state(os.path.join(sdir, f"{scheme}_{quantbits}bits_nz{nz}_experiment{c + 1}"
+                                          + ("_wave64" if wave64 else "")), s)
     if rank == 0:
         import json
         with open(os.path.join(sdir, "stream_meta.json"), "w") as fp:
@@ -157,11 +161,17 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
         out = codec.decompress(state, ndatapoints)
         t_recv = time.perf_counter() - t0
         assert torch.equal(out.cpu(), x), "decoded datapoint does not match"            # (:319,354)
-        assert state.to_lists() == [inits[c] for c in mine], "initial state not restored"  # (:358)
+        want = [inits[c] for c in mine]
+        if wave64:
+            from .hip import split_state
+            want = [split_state(s) for s in want]
+        assert state.to_lists() == want, "initial state not restored"                       # (:358)
 
     rows = {k: dist.gather_rows(v, mine, experiments) for k, v in
             dict(nets=met["nets"], elbos=elbos, cmas=met["cma"], total=met["total"]).items()}
-    words = dist.gather_streams([container.pack(s, 0, ndatapoints, 32, 32)[:-3] for s in sent], mine, experiments)
+    packer = (lambda s: container.pack64(s, [0] * 64, ndatapoints, 32, 32)[:-3]) if wave64 else \
+             (lambda s: container.pack(s, 0, ndatapoints, 32, 32)[:-3])
+    words = dist.gather_streams([packer(s) for s in sent], mine, experiments)
     tot = dist.allreduce_sum([float(met["total"][:, -1].sum()), float(len(mine) * ndatapoints * model.xdim),
                               t_send + t_recv])
     if rank != 0:
@@ -197,6 +207,8 @@ def dataset_main(dataset, default_nz, nz_loop=None):
     p.add_argument('--data', default=None, help="uint8 .npy test images")
     p.add_argument('--params', default=None, help="reference checkpoint (state_dict)")
     p.add_argument('--outdir', default=".")
+    p.add_argument('--format', default="reference", choices=["reference", "wave64"],
+                   help="stream format: the reference's single-state stream, or the opt-in 64-state format")
     p.add_argument('--save-bins', action='store_true',
                    help="write bins fitted on the given test images under the reference's cache names (bins/*.pt)")
     args = p.parse_args()
@@ -204,7 +216,7 @@ def dataset_main(dataset, default_nz, nz_loop=None):
     for nz in (nz_loop or [args.nz]):      # imagenet_compress.py:382 ignores --nz and runs [2, 4]
         compress(args.quantbits, nz, args.bitswap, args.gpu, dataset=dataset, experiments=args.experiments,
                  ndatapoints=args.ndatapoints, decompress=bool(args.decompress), synthetic=args.synthetic,
-                 data=args.data, params=args.params, outdir=args.outdir, save_bins=args.save_bins)
+                 data=args.data, params=args.params, outdir=args.outdir, save_bins=args.save_bins, fmt=args.format)
 
 
 # ---------------------------------------------------------------------------------------------

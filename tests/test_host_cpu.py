@@ -390,6 +390,18 @@ def test_wave64_format_round_trip_on_oracle(bitswap):
     assert st.to_lists() == [split_state(s) for s in initial_states(B)]
 
 
+def test_cli_experiments_in_wave64_format(tmp_path):
+    from oracle.backend import Oracle64Backend
+    r = cli.compress(6, 2, 1, 0, dataset="mnist", experiments=2, ndatapoints=2, decompress=True, outdir=str(tmp_path),
+                     backend=Oracle64Backend(O.MODE_DET), small=8, verbose=False, fmt="wave64")
+    assert r["cmas"].shape == (2, 2) and np.all(r["total"] > 0)
+    st = container.load_state(tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap" / "Bit-Swap_6bits_nz2_experiment1_wave64")
+    assert len(st) == 64 and all(sub[-1] >= 1 << 32 for sub in st)
+    import json
+    meta = json.load(open(tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap" / "stream_meta.json"))
+    assert meta["backend"] == "oracle-wave64" and meta["stream_format"] == "wave64"
+
+
 def test_wave64_container_and_demo_path():
     from oracle.backend import Oracle64Backend, split_state
     ob = Oracle64Backend(O.MODE_DET)
@@ -424,3 +436,37 @@ def test_elbo_metric_batched_equals_per_image_loss(monkeypatch):
     with torch.no_grad():
         want = torch.stack([(-lr + torch.sum(-ld + le)) for lr, ld, le, _ in (m.loss(x[i:i + 1]) for i in range(5))])
     assert torch.allclose(got, want, rtol=1e-5)
+
+
+def test_container_tiling_and_sharding_properties():
+    """Randomised round trips of the host-side formats: tiling of arbitrary image sizes, both containers with arbitrary
+    trimming, LPT / round-robin sharding (every chain exactly once, LPT never worse than 4/3 of the ideal makespan + the
+    largest item)."""
+    from bitswap_amd import dist
+    rng = np.random.RandomState(123)
+    for _ in range(25):
+        h, w = rng.randint(32, 200, size=2)
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        blocks, hh, ww = tiling.extract_blocks(img)
+        assert (hh, ww) == (h - h % 32, w - w % 32) and blocks.shape == ((hh // 32) * (ww // 32), 32, 32, 3)
+        assert np.array_equal(tiling.unextract_blocks(blocks, hh, ww), img[:hh, :ww])
+        assert np.array_equal(tiling.chw_flat_to_blocks(tiling.blocks_to_chw_flat(blocks)), blocks)
+        n = int(rng.randint(2, 300))
+        state = [int(v) for v in rng.randint(0, 1 << 32, size=n, dtype=np.uint64)] + [int(rng.randint(1 << 32, 1 << 62))]
+        m = int(rng.randint(0, n))
+        arr = container.pack(state, m, len(blocks), hh, ww)
+        st, nb, a, b = container.unpack(arr)
+        assert st == state[m:] and (nb, a, b) == (len(blocks), hh, ww) and not container.is_pack64(arr)
+        subs = [[int(v) for v in rng.randint(0, 1 << 32, size=rng.randint(1, 9), dtype=np.uint64)] +
+                [int(rng.randint(1 << 32, 1 << 62))] for _ in range(64)]
+        mins = [int(rng.randint(0, len(s_))) for s_ in subs]
+        arr = container.pack64(subs, mins, 7, 64, 96)
+        got, nb, a, b = container.unpack64(arr)
+        assert container.is_pack64(arr) and got == [s_[mm:] for s_, mm in zip(subs, mins)] and (nb, a, b) == (7, 64, 96)
+        nch, world = int(rng.randint(1, 40)), int(rng.randint(1, 9))
+        wts = [int(v) for v in rng.randint(1, 300, size=nch)]
+        for weights in (None, wts):
+            owners = [dist.shard_chains(nch, world, r, weights=weights) for r in range(world)]
+            assert sorted(c for o in owners for c in o) == list(range(nch))
+        loads = [sum(wts[c] for c in o) for o in owners]
+        assert max(loads) <= (4 / 3) * (sum(wts) / world) + max(wts)
