@@ -17,7 +17,8 @@ Headline workload = BASELINE.json configs[1]: CIFAR-10-shaped 8-latent-layer Bit
 (reswidth 252, Z = 2048, X = 3072, K = 1024 / 256), synthetic data and seeded random-init weights
 (no datasets/checkpoints offline).  At N = 1 the same JSON line also carries, under `extra`, the
 ImageNet32 nz=4 shape north_star quotes its target on (configs[2]) and the reference's own 100-chain
-shape (100 "experiments"), each measured by the same procedure with fewer steps.
+shape (100 "experiments"), and the opt-in 64-state stream format at 800 and at 13 chains, each measured by the same
+procedure with fewer steps.
 
 Extra objects on the JSON line: `roofline` for the dominant hot-path kernel (the fused
 logistic-CDF -> integer-table kernel, decode flavour) from HIP events recorded on the launch stream
@@ -309,17 +310,23 @@ def main(args):
         # 100-experiment shape, same procedure, fewer steps
         extra = []
         ks, ws = min(args.steps, 6), min(args.warmup, 1)
-        for (wn, ch, gr) in (("imagenet4", 800, 2), ("cifar8", 100, 1)):
+        import copy
+        for (wn, ch, gr, fmt) in (("imagenet4", 800, 2, "reference"), ("cifar8", 100, 1, "reference"),
+                                  ("cifar8", 800, 1, "wave64"), ("cifar8", 13, 1, "wave64")):
             torch.cuda.empty_cache()
             try:
-                e = run_workload(args, wn, ch, gr, ks, ws, dev, rank, world, dist)
+                a2 = copy.copy(args)
+                a2.format = fmt
+                e = run_workload(a2, wn, ch, gr, ks, max(ws, 2) if fmt == "wave64" else ws, dev, rank, world, dist)
                 e.pop("codec"), e.pop("model"), e.pop("stream_gather")
                 e["value"], e["ms_per_step"] = round(e["value"], 1), round(e["ms_per_step"], 3)
                 e["bits_per_dim"] = round(e["bits_per_dim"], 4)
-                e["config"] = f"{TITLES[wn]} {'Bit-Swap' if args.bitswap else 'BB-ANS'}, {ch} chains / {gr} group(s)"
+                e["stream_format"] = fmt
+                e["config"] = (f"{TITLES[wn]} {'Bit-Swap' if args.bitswap else 'BB-ANS'}, {ch} chains / {gr} group(s)"
+                               + (", opt-in 64-state stream format (not the reference's word stream)" if fmt == "wave64" else ""))
                 extra.append(e)
             except Exception as ex:   # a sub-result never costs the headline
-                extra.append({"workload": wn, "chains_per_gpu": ch, "error": repr(ex)})
+                extra.append({"workload": wn, "chains_per_gpu": ch, "stream_format": fmt, "error": repr(ex)})
 
     if rank != 0:
         if dist is not None:
