@@ -49,6 +49,10 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # sustained float64 load the chip runs at about 4/4.9 of the nominal clock (tools/instr_rate.hip), so 0.82 here is the
 # practical ceiling
 VALU_SLOTS_PER_ROW = {2: 399, 1: 648}   # CDF spec 2 (uniform bins) / spec 1
+# float64 flops of one row (64 lanes x [2 per fma + 1 per add/mul/rcp] in that loop): SURVEY 8(d) asks for the FP64
+# utilisation next to the HBM figure.  Vector FP64 peak 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
+FP64_FLOPS_PER_ROW = {2: 353 * 64, 1: 699 * 64}
+FP64_PEAK_TFLOPS = 78.6
 
 TITLES = {"mnist2": "MNIST-shaped 2-latent-layer", "cifar8": "CIFAR-10-shaped 8-latent-layer",
           "imagenet4": "ImageNet32-shaped 4-latent-layer", "imagenetcrop4": "ImageNet-crop-shaped 4-latent-layer"}
@@ -268,7 +272,10 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                     "peak_Ginstr_s": round(VALU_PEAK_GINSTR, 1), "frac": round(rows * slots / avg / 1e9 / VALU_PEAK_GINSTR, 4),
                     # measured by SQ counters (profiles/valu_busy.json, tools/pmc_valu.sh): share of the SIMD cycles the
                     # VALU pipe is busy while the kernel runs, at the clock the chip actually holds under float64 load
-                    "valu_busy_pmc": _valu_busy(spec)}}
+                    "valu_busy_pmc": _valu_busy(spec)},
+                "fp64": None if slots is None else {
+                    "flops_per_row": FP64_FLOPS_PER_ROW[spec], "achieved_TFLOPs": round(rows * FP64_FLOPS_PER_ROW[spec] / avg / 1e12, 2),
+                    "peak_TFLOPs": FP64_PEAK_TFLOPS, "frac": round(rows * FP64_FLOPS_PER_ROW[spec] / avg / 1e12 / FP64_PEAK_TFLOPS, 4)}}
     breakdown = {k: round(v[0] / dt, 4) for k, v in sorted(totals.items())} if totals else None
     res = {"workload": name, "chains_per_gpu": B, "chain_groups": groups, "steps": K, "warmup": W,
            "value": world * B * K * 1024 / dt, "ms_per_step": dt / K * 1e3, "lossless": ok, "bits_per_dim": bpd,
