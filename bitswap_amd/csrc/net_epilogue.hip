@@ -398,6 +398,47 @@ int launch_bre(const float* x, const float* bias, const float* res, float* sum_o
     return launch_rc();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_small_k_gemm: M[t] = U[t] x V[t] for the INPUT convolutions of the stacks in the Winograd domain -- Cin = zchannels
+// or 4 x image channels (8, 12: the reduction is a dozen terms), Cout = ResNet width.  The product is a write of
+// M [T, Cout, cols] and nothing else worth a matrix core; a library GEMM spends 4-5x the time of that write on it
+// (profiles/r02g).  Thread = 4 consecutive columns x CO output channels; V rows arrive as 16-byte loads, U through
+// the scalar cache (wave-uniform), M leaves as 16-byte stores.
+// ------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void k_small_k_gemm(const float* __restrict__ U, const float* __restrict__ V,
+                                                      float* __restrict__ M, int Cout, int Cin, int64_t cols) {
+    const int t = blockIdx.z;
+    const int co0 = blockIdx.y * CO;
+    const int64_t c4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c4 >= cols) return;
+    const float* u = U + ((int64_t)t * Cout + co0) * Cin;
+    const float* v = V + (int64_t)t * Cin * cols + c4;
+    float4 acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 x = *reinterpret_cast<const float4*>(v + (int64_t)ci * cols);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const float w = (co0 + o < Cout) ? u[o * Cin + ci] : 0.f;
+            acc[o].x = fmaf(w, x.x, acc[o].x);
+            acc[o].y = fmaf(w, x.y, acc[o].y);
+            acc[o].z = fmaf(w, x.z, acc[o].z);
+            acc[o].w = fmaf(w, x.w, acc[o].w);
+        }
+    }
+    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+        if (co0 + o < Cout) {
+            v4f r;
+            r.x = acc[o].x; r.y = acc[o].y; r.z = acc[o].z; r.w = acc[o].w;
+            *reinterpret_cast<v4f*>(M + ((int64_t)t * Cout + co0 + o) * cols + c4) = r;   // read next by the fused pass: keep it cacheable
+        }
+}
+
 }  // namespace
 
 extern "C" {
@@ -428,6 +469,15 @@ int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t 
 
 static bool wino_cfg_ok(int ts, int ms, int H, int W) {
     return ((ts == 6 && (ms == 4 || ms == 2)) || (ts == 8 && ms == 4)) && H >= ms && W >= ms && H % ms == 0 && W % ms == 0;
+}
+
+int bs_small_k_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream) {
+    if (!U || !V || !M || T < 0 || Cout < 1 || Cin < 1 || Cin > 64 || cols < 0 || cols % 4 != 0) return BS_EINVAL;
+    if (T == 0 || cols == 0) return BS_OK;
+    constexpr int CO = 8;
+    dim3 grid((unsigned)((cols / 4 + 255) / 256), (unsigned)((Cout + CO - 1) / CO), (unsigned)T), block(256);
+    hipLaunchKernelGGL((k_small_k_gemm<CO>), grid, block, 0, S(stream), U, V, M, Cout, Cin, cols);
+    return launch_rc();
 }
 
 int bs_wino_in_f32(const float* in, const float* bias, float* V, int64_t N, int C, int H, int W, int ts, int ms,

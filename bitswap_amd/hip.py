@@ -21,6 +21,7 @@ SYMBOLS = [
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres", "bs_layer_pop64",
     "bs_layer_push64",
     "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
+    "bs_small_k_gemm_f32",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
@@ -69,6 +70,7 @@ def load():
     L.bs_expand_rows5_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, p]
     L.bs_wino_fused_f32.argtypes = [p, i32, p, p, i32, p, p, p, i32, i64, i32, i32, i32, p]
     L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
+    L.bs_small_k_gemm_f32.argtypes = [p, p, p, i32, i32, i32, i64, p]
     L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     for n in SYMBOLS:
         if n != "bs_strerror":
@@ -551,6 +553,19 @@ def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, cfg=(
     _check(load().bs_wino_out_f32(_ptr(M), _ptr(bias), _ptr(res), _ptr(s_out), _ptr(a_out), N, Cc, H, W, ts, ms,
                                   _stream()), "bs_wino_out_f32")
     return s_out, a_out
+
+
+def small_k_gemm(U, V):
+    """M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols], float32, small Cin (the stacks' input convs in the
+    Winograd domain): a dedicated kernel that costs the write of M."""
+    _need_cuda(U, V)
+    assert U.dtype == V.dtype == torch.float32 and U.is_contiguous() and V.is_contiguous()
+    T, Cout, Cin = U.shape
+    assert V.shape[0] == T and V.shape[1] == Cin
+    cols = V.shape[2]
+    M = torch.empty((T, Cout, cols), dtype=torch.float32, device=V.device)
+    _check(load().bs_small_k_gemm_f32(_ptr(U), _ptr(V), _ptr(M), T, Cout, Cin, cols, _stream()), "bs_small_k_gemm_f32")
+    return M
 
 
 def wino_fused(src, shape, ts_in=0, bias=None, res=None, act=True, want_sum=False, want_act=False, ts_out=0):

@@ -408,7 +408,8 @@ class Model(nn.Module):
             shape_out = (x.shape[0], m.out_dim) + tuple(x.shape[2:])
             v = hip.wino_fused(x.contiguous(), tuple(x.shape), 0, None, None, False, ts_out=ts)[2]
             shape_out = (x.shape[0], m._wu.shape[1]) + tuple(x.shape[2:])        # padded channel count
-            raw = _RawM(torch.bmm(m._wu, v), m.bias_p(), ts, shape_out)
+            mm = hip.small_k_gemm(m._wu, v) if (m._wu.shape[2] <= 64 and v.shape[2] % 4 == 0) else torch.bmm(m._wu, v)
+            raw = _RawM(mm, m.bias_p(), ts, shape_out)
             if follows and self._wino_ok(list(nxt[0].children()), torch.empty((shape_out[0], 0, shape_out[2], shape_out[3]))):
                 return raw
             return self._unpad(hip.wino_fused(raw.m, shape_out, ts, m.bias_p(), None, True, want_act=True)[1])  # ELU(A^T M A + b)

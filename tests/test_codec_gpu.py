@@ -666,3 +666,16 @@ def test_ragged_chains_with_graph_replay():
                 for k, i in enumerate(order):
                     assert torch.equal(out[k].cpu(), chains[i])
         assert res[True][0] == res[False][0] and np.array_equal(res[True][1], res[False][1])
+
+
+def test_small_k_gemm_matches_bmm():
+    """bs_small_k_gemm_f32 (the input convs' Winograd-domain product, Cin = 8 / 12) against torch.bmm in float64."""
+    from bitswap_amd import hip
+    g = torch.Generator().manual_seed(4)
+    for T, Cout, Cin, cols in ((36, 256, 8, 416), (64, 252, 12, 208), (36, 19, 3, 64)):
+        U = torch.randn((T, Cout, Cin), generator=g).to(DEV)
+        V = torch.randn((T, Cin, cols), generator=g).to(DEV)
+        M = hip.small_k_gemm(U, V)
+        want = torch.bmm(U.double(), V.double())
+        assert M.shape == want.shape and float((M.double() - want).abs().max()) < 1e-5
+        assert torch.equal(M, hip.small_k_gemm(U, V))
