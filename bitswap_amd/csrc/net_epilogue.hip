@@ -400,6 +400,112 @@ int launch_bre(const float* x, const float* bias, const float* res, float* sum_o
 
 
 // ------------------------------------------------------------------------------------------
+// k_conv3_wino<TS_OUT>: the INPUT convolution of a stack fused with everything up to the first GEMM of the block that
+// follows it: h = ELU(conv3x3(x, w) + b) for Cin = zchannels input planes (8: a dozen KB of weights, 1 GMAC per 400
+// blocks -- not matrix-core work), act_out = h, V = B^T ELU(h) B.  Replaces an MIOpen launch (243 us at 400 blocks) plus
+// k_wino_fused<0, TS_OUT> (112 us) and the round trip of the conv output between them.  Same thread layout as
+// k_wino_fused: thread = (image, 4x4 tile), block = one output channel x IMG images; the input planes pass through the
+// (zero-haloed) LDS tile one at a time, the 9 x Cin weights of the channel sit in scalar registers.
+// ------------------------------------------------------------------------------------------
+template <int TS_OUT>
+__global__ __launch_bounds__(256) void k_conv3_wino(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ act_out,
+                                                    float* __restrict__ V, int64_t N, int Cin, int C, int H, int W, int act) {
+    constexpr int LW_PAD = 8;
+    extern __shared__ float lds[];                  // [IMG][H+4][W+8], zero halo
+    const int ntx = W / 4, T = (H / 4) * ntx;
+    const int IMG = 256 / T;
+    const int LW = W + LW_PAD, LP = (H + 4) * LW;
+    const int tid = threadIdx.x;
+    const int img = tid / T, tile = tid - img * T;
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)blockIdx.y * IMG + img;
+    const int64_t ncols = N * T;
+    const int64_t col = n * T + tile;
+    const bool live = n < N;
+    for (int k = tid; k < IMG * LP; k += 256) lds[k] = 0.0f;
+    float v[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[r][q] = 0.0f;
+    float* mine = lds + img * LP + (ty * 4 + 2) * LW + tx * 4 + 4;   // this tile's interior position
+    const float* wc = w + (int64_t)c * Cin * 9;
+    for (int ci = 0; ci < Cin; ++ci) {
+        __syncthreads();                             // previous plane fully consumed (first trip: halo zeroed)
+        if (live) {
+            const float* xp = x + ((n * Cin + ci) * (int64_t)H + ty * 4) * W + tx * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4*>(mine + r * LW) = *reinterpret_cast<const float4*>(xp + (int64_t)r * W);
+        }
+        __syncthreads();
+        float p[6][6];                               // the 6x6 input window of this thread's 4x4 outputs
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) p[r][q] = mine[(r - 1) * LW + q - 1];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float wk = wc[ci * 9 + ky * 3 + kx];   // wave-uniform: scalar load
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[r][q] = fmaf(wk, p[r + ky][q + kx], v[r][q]);
+            }
+    }
+    __syncthreads();                                 // all windows read: the tile now takes the activations
+    const int64_t pbase = ((n * C + c) * (int64_t)H + ty * 4) * W + tx * 4;
+    if (live) {
+        const float b = bias ? bias[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[r][q] += b;
+                if (act & 1) v[r][q] = elu1(v[r][q]);
+            }
+            if (act_out) *reinterpret_cast<float4*>(act_out + pbase + (int64_t)r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            if (act & 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[r][q] = elu1(v[r][q]);
+            }
+            *reinterpret_cast<float4*>(mine + r * LW) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(mine + r * LW) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    constexpr int TO = TS_OUT;
+    constexpr int PAD = (TO - 4) / 2;
+    __syncthreads();
+    if (!live) return;
+    const float* wbase = lds + img * LP + (ty * 4 - PAD + 2) * LW + tx * 4 - PAD + 4;
+    float t1[TO][TO];
+#pragma unroll
+    for (int q = 0; q < TO; ++q) {
+        float colv[TO], o[TO];
+#pragma unroll
+        for (int r = 0; r < TO; ++r) colv[r] = wbase[r * LW + q];
+        wino_bt<TO>(colv, o);
+#pragma unroll
+        for (int r = 0; r < TO; ++r) t1[r][q] = o[r];
+    }
+    float* out = V + (int64_t)c * ncols + col;
+    const int64_t tstride = (int64_t)C * ncols;
+#pragma unroll
+    for (int r = 0; r < TO; ++r) {
+        float o[TO];
+        wino_bt<TO>(t1[r], o);
+#pragma unroll
+        for (int q = 0; q < TO; ++q) out[(int64_t)(r * TO + q) * tstride] = o[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_small_k_gemm: M[t] = U[t] x V[t] for the INPUT convolutions of the stacks in the Winograd domain -- Cin = zchannels
 // or 4 x image channels (8, 12: the reduction is a dozen terms), Cout = ResNet width.  The product is a write of
 // M [T, Cout, cols] and nothing else worth a matrix core; a library GEMM spends 4-5x the time of that write on it
@@ -469,6 +575,23 @@ int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t 
 
 static bool wino_cfg_ok(int ts, int ms, int H, int W) {
     return ((ts == 6 && (ms == 4 || ms == 2)) || (ts == 8 && ms == 4)) && H >= ms && W >= ms && H % ms == 0 && W % ms == 0;
+}
+
+int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act, float* act_out, float* V, int ts_out,
+                      int64_t N, int Cin, int C, int H, int W, void* stream) {
+    if (!x || !w || !V || N < 0 || Cin < 1 || C < 1 || H < 4 || W < 4 || H % 4 || W % 4 || (ts_out != 6 && ts_out != 8))
+        return BS_EINVAL;
+    const int T = (H / 4) * (W / 4);
+    if (T > 256 || 256 % T) return BS_EUNSUPPORTED;
+    if (N == 0) return BS_OK;
+    const int IMG = 256 / T;
+    dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
+    const size_t shm = (size_t)IMG * (H + 4) * (W + 8) * sizeof(float);
+    if (ts_out == 6)
+        hipLaunchKernelGGL((k_conv3_wino<6>), grid, block, shm, S(stream), x, w, bias, act_out, V, N, Cin, C, H, W, act);
+    else
+        hipLaunchKernelGGL((k_conv3_wino<8>), grid, block, shm, S(stream), x, w, bias, act_out, V, N, Cin, C, H, W, act);
+    return launch_rc();
 }
 
 int bs_small_k_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream) {

@@ -21,7 +21,7 @@ SYMBOLS = [
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres", "bs_layer_pop64",
     "bs_layer_push64",
     "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
-    "bs_small_k_gemm_f32",
+    "bs_small_k_gemm_f32", "bs_conv3_wino_f32",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
@@ -71,6 +71,7 @@ def load():
     L.bs_wino_fused_f32.argtypes = [p, i32, p, p, i32, p, p, p, i32, i64, i32, i32, i32, p]
     L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.bs_small_k_gemm_f32.argtypes = [p, p, p, i32, i32, i32, i64, p]
+    L.bs_conv3_wino_f32.argtypes = [p, p, p, i32, p, p, i32, i64, i32, i32, i32, i32, p]
     L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     for n in SYMBOLS:
         if n != "bs_strerror":
@@ -553,6 +554,23 @@ def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, cfg=(
     _check(load().bs_wino_out_f32(_ptr(M), _ptr(bias), _ptr(res), _ptr(s_out), _ptr(a_out), N, Cc, H, W, ts, ms,
                                   _stream()), "bs_wino_out_f32")
     return s_out, a_out
+
+
+def conv3_wino(x, w, bias, act=3, want_act=True, ts_out=6):
+    """Input conv of a stack fused with the first transform: x [N,Cin,H,W], w [C,Cin,3,3] -> (h [N,C,H,W] | None,
+    V [ts_out^2, C, N*T]) with h = ELU(conv3x3(x) + bias) (act & 1) and V = B^T ELU(h) B (act & 2); see
+    include/bitswap_hip.h, bs_conv3_wino_f32."""
+    _need_cuda(x, w, bias)
+    assert x.dtype == w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous() and x.dim() == 4
+    N, Cin, H, W = x.shape
+    Cc = w.shape[0]
+    assert tuple(w.shape) == (Cc, Cin, 3, 3)
+    T = (H // 4) * (W // 4)
+    h = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device) if want_act else None
+    V = torch.empty((ts_out * ts_out, Cc, N * T), dtype=torch.float32, device=x.device)
+    _check(load().bs_conv3_wino_f32(_ptr(x), _ptr(w), _ptr(bias), int(act), _ptr(h), _ptr(V), ts_out, N, Cin, Cc, H, W,
+                                    _stream()), "bs_conv3_wino_f32")
+    return h, V
 
 
 def small_k_gemm(U, V):

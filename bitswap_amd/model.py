@@ -197,6 +197,14 @@ class _RawM:
         self.m, self.b, self.ts, self.shape = m, b, ts, tuple(shape)
 
 
+class _ConvDone:
+    """An input convolution already taken through bias, ELU and the forward transform of the block that follows
+    (hip.conv3_wino): h = ELU(conv(x) + b) and V = B^T ELU(h) B."""
+
+    def __init__(self, h, v):
+        self.h, self.v = h, v
+
+
 class _WinoOperand:
     """A block output that only exists as the Winograd operand V [36, C, N*T] of the 3x3 convs that follow."""
 
@@ -227,6 +235,9 @@ class Model(nn.Module):
         # MIOpen from gemm_min_batch blocks per call on, but the K = 8..12 batched GEMMs run no faster than MIOpen's
         # kernels (profiles/r02g_kernel_stats.txt: 177 vs 177 ms per step), so it is an option, not the default
         self.wino_inputs = os.environ.get("BITSWAP_WINO_INPUTS", "0") == "1"
+        # 3x3 input convs (Cin = zchannels) as a direct fp32 convolution fused with bias, ELU and the forward transform of
+        # the block behind them (bs_conv3_wino_f32) instead of an MIOpen launch + a transform pass
+        self.fused_inputs = os.environ.get("BITSWAP_FUSED_INPUTS", "1") == "1"
         # Winograd route: run with the ResNet width padded to the next multiple of 64 when that costs at most 8 dead
         # channels (252, 254, 255 -> 256).  The batched GEMMs of [C x C] x [C x tiles] are 15-20 % faster at C = 256
         # (tile quantisation: 3 row tiles of 96 for 252 rows; profiles/r02m), the transform kernels pay 1.6 % more
@@ -414,6 +425,11 @@ class Model(nn.Module):
                 return raw
             return self._unpad(hip.wino_fused(raw.m, shape_out, ts, m.bias_p(), None, True, want_act=True)[1])  # ELU(A^T M A + b)
         if follows and self._wino_ok(list(nxt[0].children()), x):
+            nts = int(round(list(nxt[0].children())[0].conv1._wu.shape[0] ** 0.5))
+            if self.fused_inputs and m.kernel_size == 3 and m.in_dim <= 16 and m.stride == 1 and m.padding == 1:
+                # direct 3x3 conv on the fp32 VALU + bias + ELU + forward transform in one launch (no MIOpen call)
+                wp = m._wp if m._wp is not None else m._w
+                return _ConvDone(*hip.conv3_wino(x.contiguous(), wp, m.bias_p(), 3, True, nts))
             return _RawConv(self._conv_nb(m, x, padded=True), m.bias_p())       # zero filters appended: padded width
         return hip.bias_residual_elu(self._conv_nb(m, x), m.b)[1]
 
@@ -458,7 +474,10 @@ class Model(nn.Module):
         6.25x (5x5) fewer multiplications than the direct convolution, all of them on the MFMA units."""
         from . import hip
         ts = int(round(layers[0].conv1._wu.shape[0] ** 0.5))
-        if isinstance(h, _RawM):        # same, the input conv still in the Winograd domain: h = ELU(A^T M A + b)
+        if isinstance(h, _ConvDone):
+            h, v = h.h, h.v
+            shape = tuple(h.shape)
+        elif isinstance(h, _RawM):      # same, the input conv still in the Winograd domain: h = ELU(A^T M A + b)
             shape = h.shape
             _, h, v = hip.wino_fused(h.m, shape, h.ts, h.b, None, 3, want_act=True, ts_out=ts)
         elif isinstance(h, _RawConv):   # the input conv's bias + ELU ride along: h = ELU(c + b), V = B^T ELU(h) B
@@ -501,7 +520,7 @@ class Model(nn.Module):
         if isinstance(seq, Pass):
             return h
         layers = list(seq[0].children())
-        if isinstance(h, (_RawConv, _RawM)):
+        if isinstance(h, (_RawConv, _RawM, _ConvDone)):
             return self._res_wino(layers, h, want_v)
         if (self.conv_algo == "winograd" and h.shape[0] >= self.gemm_min_batch and layers[0].conv1._wu is not None
                 and h.shape[-1] % 4 == 0 and h.shape[-2] % 4 == 0):

@@ -237,6 +237,10 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *     ts_out != 0: V [ts_out^2, C, N*T] <- B^T a' B, a' = (act & 2) ? ELU(a) : a   (the operand of the next GEMM)
  *   A layer x + conv2(ELU(conv1(ELU(x)) + b1)) + b2 is: GEMM, fused(ts,ts), GEMM, fused(ts,ts | 0).
  *
+ * bs_conv3_wino_f32 -- the 3x3 'same' INPUT convolution of a stack (x [N,Cin,H,W], w [C,Cin,3,3], small Cin) fused with
+ *   what follows it up to the first GEMM of the next block: h = (act & 1) ? ELU(conv(x) + bias[c]) : conv(x) + bias[c];
+ *   act_out [N,C,H,W] = h (nullable); V [ts_out^2, C, N*T] = B^T h' B with h' = (act & 2) ? ELU(h) : h.  ts_out 6 or 8.
+ *
  * bs_small_k_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols] for small Cin (<= 64): the batched product
  *   of the INPUT convolutions of the stacks in the Winograd domain (Cin = zchannels or 4 x image channels); a write of M
  *   with a dozen multiply-adds per element.  cols % 4 == 0, 16-byte aligned operands.
@@ -249,6 +253,8 @@ int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scal
                        int HW, int mode, void* stream);
 int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W,
                         int act, void* stream);
+int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act, float* act_out, float* V, int ts_out,
+                      int64_t N, int Cin, int C, int H, int W, void* stream);
 int bs_small_k_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream);
 int bs_wino_fused_f32(const float* src, int ts_in, const float* bias, const float* res, int act, float* sum_out,
                       float* act_out, float* V, int ts_out, int64_t N, int C, int H, int W, void* stream);

@@ -679,3 +679,23 @@ def test_small_k_gemm_matches_bmm():
         want = torch.bmm(U.double(), V.double())
         assert M.shape == want.shape and float((M.double() - want).abs().max()) < 1e-5
         assert torch.equal(M, hip.small_k_gemm(U, V))
+
+
+@pytest.mark.parametrize("ts", [6, 8])
+def test_conv3_wino_matches_conv_plus_transform(ts):
+    """bs_conv3_wino_f32 (input conv of a stack, Cin = 8, fused with bias + ELU + the forward transform) against
+    F.conv2d in float64 followed by the separate transform pass; a partial image block (N not a multiple of 16)."""
+    from bitswap_amd import hip
+    g = torch.Generator().manual_seed(ts)
+    N, Cin, C = 21, 8, 40
+    x = torch.randn((N, Cin, 16, 16), generator=g).to(DEV)
+    w = (torch.randn((C, Cin, 3, 3), generator=g) / 8).to(DEV)
+    b = torch.randn(C, generator=g).to(DEV)
+    h, V = hip.conv3_wino(x, w, b, 3, True, ts)
+    want = torch.nn.functional.elu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    assert float((h.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    _, h2, V2 = hip.wino_fused(torch.nn.functional.conv2d(x, w, None, padding=1), (N, C, 16, 16), 0, b, None, 3,
+                               want_act=True, ts_out=ts)
+    assert float((h - h2).abs().max()) < 1e-5 and float((V - V2).abs().max()) < 1e-4 * float(V2.abs().max())
+    h3, V3 = hip.conv3_wino(x, w, b, 3, True, ts)
+    assert torch.equal(h, h3) and torch.equal(V, V3)
