@@ -425,37 +425,49 @@ __global__ __launch_bounds__(256) void k_conv3_wino(const float* __restrict__ x,
     const int64_t col = n * T + tile;
     const bool live = n < N;
     for (int k = tid; k < IMG * LP; k += 256) lds[k] = 0.0f;
+    float* wsh = lds + IMG * LP;                     // the 9 x Cin weights of this channel, staged once
+    const float* wc = w + (int64_t)c * Cin * 9;
+    for (int k = tid; k < Cin * 9; k += 256) wsh[k] = wc[k];
     float v[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[r][q] = 0.0f;
-    float* mine = lds + img * LP + (ty * 4 + 2) * LW + tx * 4 + 4;   // this tile's interior position
-    const float* wc = w + (int64_t)c * Cin * 9;
+    float* mine = lds + img * LP + (ty * 4 + 2) * LW + tx * 4 + 4;   // this tile's interior position (16-byte aligned)
+    const float* xp = x + ((n * Cin) * (int64_t)H + ty * 4) * W + tx * 4;
+    const int64_t plane = (int64_t)H * W;
+    float4 nxt[4];                                   // the next input plane's tile, in flight while this one is used
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nxt[r] = live ? *reinterpret_cast<const float4*>(xp + (int64_t)r * W) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ci = 0; ci < Cin; ++ci) {
-        __syncthreads();                             // previous plane fully consumed (first trip: halo zeroed)
-        if (live) {
-            const float* xp = x + ((n * Cin + ci) * (int64_t)H + ty * 4) * W + tx * 4;
+        __syncthreads();                             // previous plane fully consumed (first trip: halo zeroed, weights in)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<float4*>(mine + r * LW) = *reinterpret_cast<const float4*>(xp + (int64_t)r * W);
-        }
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(mine + r * LW) = nxt[r];
         __syncthreads();
-        float p[6][6];                               // the 6x6 input window of this thread's 4x4 outputs
+        if (live && ci + 1 < Cin) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+            for (int r = 0; r < 4; ++r) nxt[r] = *reinterpret_cast<const float4*>(xp + (ci + 1) * plane + (int64_t)r * W);
+        }
+        float wk[9];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) p[r][q] = mine[(r - 1) * LW + q - 1];
+        for (int k = 0; k < 9; ++k) wk[k] = wsh[ci * 9 + k];   // same address in every lane: one LDS broadcast each
+        float p[6][6];                               // the 6x6 input window of this thread's 4x4 outputs: 3 aligned reads per row
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const float* row = mine + (r - 1) * LW;
+            const float4 a = *reinterpret_cast<const float4*>(row - 4);
+            const float4 m4 = *reinterpret_cast<const float4*>(row);
+            const float4 z = *reinterpret_cast<const float4*>(row + 4);
+            p[r][0] = a.w; p[r][1] = m4.x; p[r][2] = m4.y; p[r][3] = m4.z; p[r][4] = m4.w; p[r][5] = z.x;
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float wk = wc[ci * 9 + ky * 3 + kx];   // wave-uniform: scalar load
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[r][q] = fmaf(wk, p[r + ky][q + kx], v[r][q]);
-            }
+                    for (int q = 0; q < 4; ++q) v[r][q] = fmaf(wk[ky * 3 + kx], p[r + ky][q + kx], v[r][q]);
     }
     __syncthreads();                                 // all windows read: the tile now takes the activations
     const int64_t pbase = ((n * C + c) * (int64_t)H + ty * 4) * W + tx * 4;
@@ -586,7 +598,7 @@ int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act
     if (N == 0) return BS_OK;
     const int IMG = 256 / T;
     dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
-    const size_t shm = (size_t)IMG * (H + 4) * (W + 8) * sizeof(float);
+    const size_t shm = ((size_t)IMG * (H + 4) * (W + 8) + (size_t)Cin * 9) * sizeof(float);
     if (ts_out == 6)
         hipLaunchKernelGGL((k_conv3_wino<6>), grid, block, shm, S(stream), x, w, bias, act_out, V, N, Cin, C, H, W, act);
     else
