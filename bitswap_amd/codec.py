@@ -659,8 +659,9 @@ class GroupedCodec:
         self.bulk = None
         if groups > 1:
             self.bulk = torch.cuda.Stream(device=self.device)
+            own = os.environ.get("BITSWAP_BULK_PER_GROUP", "1") == "1"    # experiment: every group its own bulk stream
             for c in self.codecs:
-                c.bulk = self.bulk
+                c.bulk = torch.cuda.Stream(device=self.device) if own else self.bulk
                 c.serial = torch.cuda.Stream(device=self.device)
 
     def split(self, n):
@@ -676,7 +677,7 @@ class GroupedCodec:
                 for c, sl in zip(self.codecs, self.split(nchains))]
 
     def _streams(self):
-        return [] if self.bulk is None else [self.bulk] + [c.serial for c in self.codecs]
+        return [] if self.bulk is None else list({id(t): t for t in [c.bulk for c in self.codecs] + [c.serial for c in self.codecs]}.values())
 
     def _fork(self):
         cur = torch.cuda.current_stream(self.device)

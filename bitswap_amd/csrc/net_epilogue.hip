@@ -10,6 +10,7 @@
 // on its own inputs only), which is all the decoder needs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/bitswap_hip.h"
 
@@ -401,119 +402,157 @@ int launch_bre(const float* x, const float* bias, const float* res, float* sum_o
 
 // ------------------------------------------------------------------------------------------
 // k_conv3_wino<TS_OUT>: the INPUT convolution of a stack fused with everything up to the first GEMM of the block that
-// follows it: h = ELU(conv3x3(x, w) + b) for Cin = zchannels input planes (8: a dozen KB of weights, 1 GMAC per 400
+// follows it: h = ELU(conv3x3(x, w) + b) for Cin = zchannels input planes (8: a dozen KB of weights, 2 GMAC per 400
 // blocks -- not matrix-core work), act_out = h, V = B^T ELU(h) B.  Replaces an MIOpen launch (243 us at 400 blocks) plus
-// k_wino_fused<0, TS_OUT> (112 us) and the round trip of the conv output between them.  Same thread layout as
-// k_wino_fused: thread = (image, 4x4 tile), block = one output channel x IMG images; the input planes pass through the
-// (zero-haloed) LDS tile one at a time, the 9 x Cin weights of the channel sit in scalar registers.
+// k_wino_fused<0, TS_OUT> (112 us) and the round trip of the conv output between them; what is left is the write of h
+// and V (341 MB at 400 blocks).
+//   block = the 64 / T images of one wavefront (T tiles of 4x4 per plane) x `cpb` output channels.  ALL Cin planes of
+//   those images are staged once in LDS (zero halo; rows are W + 4 apart, so a row's right halo IS the next row's left
+//   halo and a thread's three aligned 16-byte reads per window row are bank-conflict free), then each of the 4
+//   wavefronts walks its share of the channels two at a time: the 6x6 window of a plane is read once for both, the
+//   2 x 9 weights are wave-uniform (scalar loads), no block barrier inside the channel loop.  The activated tile goes
+//   through a wave-private LDS tile (LDS is in order within a wavefront) to reach the neighbours' windows for B^T d B.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_wave_sync() {
+    // a wavefront's LDS operations execute in issue order: all that is needed is that the compiler keeps them in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the TS x TS window whose 4x4 centre starts at `mine` (a 16-byte aligned interior position), PAD = (TS - 4) / 2
+template <int TS>
+__device__ __forceinline__ void lds_window(const float* mine, int LW, float (&p)[TS][TS]) {
+    constexpr int PAD = (TS - 4) / 2;
+#pragma unroll
+    for (int r = 0; r < TS; ++r) {
+        const float* row = mine + (r - PAD) * LW;
+        const float4 a = *reinterpret_cast<const float4*>(row - 4);
+        const float4 m = *reinterpret_cast<const float4*>(row);
+        const float4 z = *reinterpret_cast<const float4*>(row + 4);
+        if (PAD == 1) {
+            p[r][0] = a.w; p[r][1] = m.x; p[r][2] = m.y; p[r][3] = m.z; p[r][4] = m.w; p[r][TS - 1] = z.x;
+        } else {
+            p[r][0] = a.z; p[r][1] = a.w; p[r][2] = m.x; p[r][3] = m.y; p[r][4] = m.z; p[r][5] = m.w;
+            p[r][(TS == 8) ? 6 : 0] = z.x; p[r][(TS == 8) ? 7 : 0] = z.y;
+        }
+    }
+}
+
+template <int TS_OUT>
+__device__ __forceinline__ void conv3_tail(float (&v)[4][4], float b, int act, bool live, float* __restrict__ act_plane,
+                                           float* __restrict__ vout, int64_t tstride, float* smine, int LW, int W) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[r][q] += b;
+            if (act & 1) v[r][q] = elu1(v[r][q]);
+        }
+        if (act_plane && live) *reinterpret_cast<float4*>(act_plane + r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        if (act & 2) {  // act_out is the residual stream of a block whose first conv sees ELU of it again
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[r][q] = elu1(v[r][q]);
+        }
+        *reinterpret_cast<float4*>(smine + r * LW) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+    }
+    lds_wave_sync();
+    float d[TS_OUT][TS_OUT], t1[TS_OUT][TS_OUT];
+    lds_window<TS_OUT>(smine, LW, d);
+    lds_wave_sync();                                 // the tile may be overwritten by the next channel from here on
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < TS_OUT; ++q) {               // B^T d, column by column
+        float colv[TS_OUT], o[TS_OUT];
+#pragma unroll
+        for (int r = 0; r < TS_OUT; ++r) colv[r] = d[r][q];
+        wino_bt<TS_OUT>(colv, o);
+#pragma unroll
+        for (int r = 0; r < TS_OUT; ++r) t1[r][q] = o[r];
+    }
+#pragma unroll
+    for (int r = 0; r < TS_OUT; ++r) {
+        float o[TS_OUT];
+        wino_bt<TS_OUT>(t1[r], o);
+#pragma unroll
+        for (int q = 0; q < TS_OUT; ++q) vout[(int64_t)(r * TS_OUT + q) * tstride] = o[q];
+    }
+}
+
 template <int TS_OUT>
 __global__ __launch_bounds__(256) void k_conv3_wino(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ act_out,
-                                                    float* __restrict__ V, int64_t N, int Cin, int C, int H, int W, int act) {
-    constexpr int LW_PAD = 8;
-    extern __shared__ float lds[];                  // [IMG][H+4][W+8], zero halo
+                                                    float* __restrict__ V, int64_t N, int Cin, int C, int H, int W, int act,
+                                                    int cpb) {
+    extern __shared__ float lds[];
     const int ntx = W / 4, T = (H / 4) * ntx;
-    const int IMG = 256 / T;
-    const int LW = W + LW_PAD, LP = (H + 4) * LW;
-    const int tid = threadIdx.x;
-    const int img = tid / T, tile = tid - img * T;
+    const int IMG = 64 / T;                          // images of one wavefront = images of the block
+    const int LW = W + 4, LP = (H + 4) * LW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = lane / T, tile = lane - img * T;
     const int ty = tile / ntx, tx = tile - ty * ntx;
-    const int c = blockIdx.x;
-    const int64_t n = (int64_t)blockIdx.y * IMG + img;
-    const int64_t ncols = N * T;
-    const int64_t col = n * T + tile;
+    const int64_t n0 = (int64_t)blockIdx.x * IMG;
+    const int64_t n = n0 + img;
     const bool live = n < N;
-    for (int k = tid; k < IMG * LP; k += 256) lds[k] = 0.0f;
-    float* wsh = lds + IMG * LP;                     // the 9 x Cin weights of this channel, staged once
-    const float* wc = w + (int64_t)c * Cin * 9;
-    for (int k = tid; k < Cin * 9; k += 256) wsh[k] = wc[k];
-    float v[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[r][q] = 0.0f;
-    float* mine = lds + img * LP + (ty * 4 + 2) * LW + tx * 4 + 4;   // this tile's interior position (16-byte aligned)
-    const float* xp = x + ((n * Cin) * (int64_t)H + ty * 4) * W + tx * 4;
-    const int64_t plane = (int64_t)H * W;
-    float4 nxt[4];                                   // the next input plane's tile, in flight while this one is used
-#pragma unroll
-    for (int r = 0; r < 4; ++r) nxt[r] = live ? *reinterpret_cast<const float4*>(xp + (int64_t)r * W) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int ci = 0; ci < Cin; ++ci) {
-        __syncthreads();                             // previous plane fully consumed (first trip: halo zeroed, weights in)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(mine + r * LW) = nxt[r];
-        __syncthreads();
-        if (live && ci + 1 < Cin) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) nxt[r] = *reinterpret_cast<const float4*>(xp + (ci + 1) * plane + (int64_t)r * W);
-        }
-        float wk[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = wsh[ci * 9 + k];   // same address in every lane: one LDS broadcast each
-        float p[6][6];                               // the 6x6 input window of this thread's 4x4 outputs: 3 aligned reads per row
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const float* row = mine + (r - 1) * LW;
-            const float4 a = *reinterpret_cast<const float4*>(row - 4);
-            const float4 m4 = *reinterpret_cast<const float4*>(row);
-            const float4 z = *reinterpret_cast<const float4*>(row + 4);
-            p[r][0] = a.w; p[r][1] = m4.x; p[r][2] = m4.y; p[r][3] = m4.z; p[r][4] = m4.w; p[r][5] = z.x;
-        }
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[r][q] = fmaf(wk[ky * 3 + kx], p[r + ky][q + kx], v[r][q]);
-    }
-    __syncthreads();                                 // all windows read: the tile now takes the activations
-    const int64_t pbase = ((n * C + c) * (int64_t)H + ty * 4) * W + tx * 4;
-    if (live) {
-        const float b = bias ? bias[c] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[r][q] += b;
-                if (act & 1) v[r][q] = elu1(v[r][q]);
-            }
-            if (act_out) *reinterpret_cast<float4*>(act_out + pbase + (int64_t)r * W) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
-            if (act & 2) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[r][q] = elu1(v[r][q]);
-            }
-            *reinterpret_cast<float4*>(mine + r * LW) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(mine + r * LW) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    constexpr int TO = TS_OUT;
-    constexpr int PAD = (TO - 4) / 2;
+    const int nin = IMG * Cin * LP + 4;              // input planes (+ the last row's right halo)
+    const int nscr = IMG * LP + 4;                   // one wavefront's activation tile
+    for (int k = tid * 4; k < nin + 4 * nscr; k += 1024) *reinterpret_cast<float4*>(lds + k) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    if (!live) return;
-    const float* wbase = lds + img * LP + (ty * 4 - PAD + 2) * LW + tx * 4 - PAD + 4;
-    float t1[TO][TO];
-#pragma unroll
-    for (int q = 0; q < TO; ++q) {
-        float colv[TO], o[TO];
-#pragma unroll
-        for (int r = 0; r < TO; ++r) colv[r] = wbase[r * LW + q];
-        wino_bt<TO>(colv, o);
-#pragma unroll
-        for (int r = 0; r < TO; ++r) t1[r][q] = o[r];
+    {   // x[n0 .. n0+IMG) is one contiguous run of IMG*Cin*H*W floats
+        const int w4 = W / 4, per_plane4 = H * w4;
+        const int64_t avail = (N - n0 < IMG ? N - n0 : IMG) * (int64_t)Cin * per_plane4;
+        const float4* xs = reinterpret_cast<const float4*>(x + n0 * Cin * (int64_t)H * W);
+        for (int k = tid; k < avail; k += 256) {
+            const int pl = k / per_plane4, rem = k - pl * per_plane4;
+            const int row = rem / w4, c4 = rem - row * w4;
+            *reinterpret_cast<float4*>(lds + pl * LP + (row + 2) * LW + 4 + c4 * 4) = xs[k];
+        }
     }
-    float* out = V + (int64_t)c * ncols + col;
+    __syncthreads();
+    const int toff = (ty * 4 + 2) * LW + tx * 4 + 4;  // this tile's interior position (16-byte aligned)
+    const float* tin = lds + img * Cin * LP + toff;
+    float* smine = lds + nin + wave * nscr + img * LP + toff;
+    const int64_t ncols = N * T, col = n * T + tile;
     const int64_t tstride = (int64_t)C * ncols;
+    const int cbase = blockIdx.y * cpb;
+    const int cend = cbase + cpb < C ? cbase + cpb : C;
+    for (int c0 = cbase + 2 * wave; c0 < cend; c0 += 8) {
+        const bool two = c0 + 1 < cend;
+        const int c1 = two ? c0 + 1 : c0;
+        float v0[4][4], v1[4][4];
 #pragma unroll
-    for (int r = 0; r < TO; ++r) {
-        float o[TO];
-        wino_bt<TO>(t1[r], o);
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < TO; ++q) out[(int64_t)(r * TO + q) * tstride] = o[q];
+            for (int q = 0; q < 4; ++q) { v0[r][q] = 0.0f; v1[r][q] = 0.0f; }
+        const float* w0 = w + (int64_t)c0 * Cin * 9;
+        const float* w1 = w + (int64_t)c1 * Cin * 9;
+        for (int ci = 0; ci < Cin; ++ci) {
+            float p[6][6];
+            lds_window<6>(tin + ci * LP, LW, p);
+            float k0[9], k1[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { k0[k] = w0[ci * 9 + k]; k1[k] = w1[ci * 9 + k]; }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v0[r][q] = fmaf(k0[ky * 3 + kx], p[r + ky][q + kx], v0[r][q]);
+                            v1[r][q] = fmaf(k1[ky * 3 + kx], p[r + ky][q + kx], v1[r][q]);
+                        }
+        }
+        const int64_t pix = (int64_t)(ty * 4) * W + tx * 4;
+        conv3_tail<TS_OUT>(v0, bias ? bias[c0] : 0.0f, act, live,
+                           act_out ? act_out + (n * C + c0) * (int64_t)H * W + pix : nullptr,
+                           V + (int64_t)c0 * ncols + col, tstride, smine, LW, W);
+        if (two)
+            conv3_tail<TS_OUT>(v1, bias ? bias[c1] : 0.0f, act, live,
+                               act_out ? act_out + (n * C + c1) * (int64_t)H * W + pix : nullptr,
+                               V + (int64_t)c1 * ncols + col, tstride, smine, LW, W);
     }
 }
 
@@ -557,6 +596,20 @@ __global__ __launch_bounds__(256) void k_small_k_gemm(const float* __restrict__ 
         }
 }
 
+template <int TS_OUT>
+int launch_conv3(const float* x, const float* w, const float* bias, int act, float* act_out, float* V, int64_t N, int Cin,
+                 int C, int H, int W, int cpb, dim3 grid, size_t shm, hipStream_t st) {
+    static size_t granted = 0;                       // dynamic LDS above 64 KB has to be granted per kernel
+    if (shm > granted) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_wino<TS_OUT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            return BS_EUNSUPPORTED;
+        granted = shm;
+    }
+    hipLaunchKernelGGL((k_conv3_wino<TS_OUT>), grid, dim3(256), shm, st, x, w, bias, act_out, V, N, Cin, C, H, W, act, cpb);
+    return launch_rc();
+}
+
 }  // namespace
 
 extern "C" {
@@ -594,16 +647,21 @@ int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act
     if (!x || !w || !V || N < 0 || Cin < 1 || C < 1 || H < 4 || W < 4 || H % 4 || W % 4 || (ts_out != 6 && ts_out != 8))
         return BS_EINVAL;
     const int T = (H / 4) * (W / 4);
-    if (T > 256 || 256 % T) return BS_EUNSUPPORTED;
+    if (T > 64 || 64 % T) return BS_EUNSUPPORTED;
+    const int IMG = 64 / T;
+    const size_t LP = (size_t)(H + 4) * (W + 4);
+    const size_t shm = ((size_t)IMG * Cin * LP + 4 + 4 * ((size_t)IMG * LP + 4)) * sizeof(float);
+    if (shm > 160 * 1024) return BS_EUNSUPPORTED;
     if (N == 0) return BS_OK;
-    const int IMG = 256 / T;
-    dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
-    const size_t shm = ((size_t)IMG * (H + 4) * (W + 8) + (size_t)Cin * 9) * sizeof(float);
-    if (ts_out == 6)
-        hipLaunchKernelGGL((k_conv3_wino<6>), grid, block, shm, S(stream), x, w, bias, act_out, V, N, Cin, C, H, W, act);
-    else
-        hipLaunchKernelGGL((k_conv3_wino<8>), grid, block, shm, S(stream), x, w, bias, act_out, V, N, Cin, C, H, W, act);
-    return launch_rc();
+    const int64_t groups = (N + IMG - 1) / IMG;
+    // channels per block: as many as leave the launch a few blocks per CU slot (2 blocks fit a CU at 77 KB each)
+    static const int forced = [] { const char* e = getenv("BITSWAP_CONV3_CPB"); return e ? atoi(e) : 0; }();
+    int cpb = 64;
+    while (cpb > 8 && groups * ((C + cpb - 1) / cpb) < 1536) cpb /= 2;
+    if (forced >= 8 && forced % 8 == 0) cpb = forced;
+    dim3 grid((unsigned)groups, (unsigned)((C + cpb - 1) / cpb));
+    if (ts_out == 6) return launch_conv3<6>(x, w, bias, act, act_out, V, N, Cin, C, H, W, cpb, grid, shm, S(stream));
+    return launch_conv3<8>(x, w, bias, act, act_out, V, N, Cin, C, H, W, cpb, grid, shm, S(stream));
 }
 
 int bs_small_k_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream) {

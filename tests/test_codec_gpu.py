@@ -681,21 +681,29 @@ def test_small_k_gemm_matches_bmm():
         assert torch.equal(M, hip.small_k_gemm(U, V))
 
 
-@pytest.mark.parametrize("ts", [6, 8])
-def test_conv3_wino_matches_conv_plus_transform(ts):
+@pytest.mark.parametrize("ts,N,C,hw", [(6, 21, 40, 16), (8, 21, 40, 16), (6, 7, 9, 8), (8, 3, 17, 32), (6, 400, 256, 16)])
+def test_conv3_wino_matches_conv_plus_transform(ts, N, C, hw):
     """bs_conv3_wino_f32 (input conv of a stack, Cin = 8, fused with bias + ELU + the forward transform) against
-    F.conv2d in float64 followed by the separate transform pass; a partial image block (N not a multiple of 16)."""
+    F.conv2d in float64 followed by the separate transform pass; partial image groups (N not a multiple of the images
+    per wavefront), odd channel counts (a wavefront walks channels in pairs), 8x8 / 16x16 / 32x32 planes, and the
+    bench's own shape (400 blocks x 256 channels)."""
     from bitswap_amd import hip
     g = torch.Generator().manual_seed(ts)
-    N, Cin, C = 21, 8, 40
-    x = torch.randn((N, Cin, 16, 16), generator=g).to(DEV)
+    Cin = 8
+    x = torch.randn((N, Cin, hw, hw), generator=g).to(DEV)
     w = (torch.randn((C, Cin, 3, 3), generator=g) / 8).to(DEV)
     b = torch.randn(C, generator=g).to(DEV)
     h, V = hip.conv3_wino(x, w, b, 3, True, ts)
     want = torch.nn.functional.elu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
     assert float((h.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
-    _, h2, V2 = hip.wino_fused(torch.nn.functional.conv2d(x, w, None, padding=1), (N, C, 16, 16), 0, b, None, 3,
+    _, h2, V2 = hip.wino_fused(torch.nn.functional.conv2d(x, w, None, padding=1), (N, C, hw, hw), 0, b, None, 3,
                                want_act=True, ts_out=ts)
     assert float((h - h2).abs().max()) < 1e-5 and float((V - V2).abs().max()) < 1e-4 * float(V2.abs().max())
     h3, V3 = hip.conv3_wino(x, w, b, 3, True, ts)
     assert torch.equal(h, h3) and torch.equal(V, V3)
+    _, V4 = hip.conv3_wino(x, w, b, 3, False, ts)        # without the activation output
+    assert torch.equal(V, V4)
+    if N > 4:                                            # a block's images do not see each other: batch invariance
+        h5, V5 = hip.conv3_wino(x[1:4].contiguous(), w, b, 3, True, ts)
+        T = (hw // 4) ** 2
+        assert torch.equal(h5, h[1:4]) and torch.equal(V5, V[:, :, T:4 * T])
