@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true", help="never replay the block step from a hipGraph (single-stream runs)")
     ap.add_argument("--format", default="reference", choices=["reference", "wave64"],
                     help="reference: the reference's single-state word stream (default, the headline); wave64: the opt-in "
-                         "64-state format -- table + coding step fused in one launch, one stream (implies --groups 1)")
+                         "64-state format -- table + coding step fused in one launch, one stream per chain group")
     return ap.parse_args()
 
 
@@ -147,7 +147,7 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     backend = None
     if args.format == "wave64":
         from bitswap_amd.codec import Hip64Backend
-        backend, groups = Hip64Backend(dev), 1
+        backend = Hip64Backend(dev)          # groups > 1: one stream per group, the groups overlap each other
     codec = GroupedCodec(model, zend, zcen, groups=groups, quantbits=args.quantbits, bitswap=bool(args.bitswap),
                          timeline=tl, cdf_spec=args.cdf_spec, backend=backend)
     for c in codec.codecs:
@@ -319,7 +319,7 @@ def main(args):
         ks, ws = min(args.steps, 6), min(args.warmup, 1)
         import copy
         for (wn, ch, gr, fmt) in (("imagenet4", 800, 2, "reference"), ("cifar8", 100, 1, "reference"),
-                                  ("cifar8", 800, 1, "wave64"), ("cifar8", 13, 1, "wave64")):
+                                  ("cifar8", 800, 2, "wave64"), ("cifar8", 13, 1, "wave64")):
             torch.cuda.empty_cache()
             try:
                 a2 = copy.copy(args)

@@ -108,8 +108,10 @@ class _LazyTable:
 class Hip64Backend(HipBackend):
     """The opt-in 64-state stream format (BS_FORMAT_WAVE64, include/bitswap_hip.h): every chain owns 64 rANS states and
     each coding operation is ONE launch that builds the integer table rows in registers and codes on them
-    (bs_layer_pop64 / bs_layer_push64) -- no cdf rows in HBM, no serial kernels, nothing to overlap, so it is used with
-    a single stream (GroupedCodec(groups=1)).  Streams are not the reference's (64 heads per chain instead of one)."""
+    (bs_layer_pop64 / bs_layer_push64) -- no cdf rows in HBM, no serial kernels to split off: GroupedCodec gives every
+    chain group ONE stream and lets the groups overlap each other (HBM-bound transforms and float64 coding kernels of
+    one group under the matrix-core GEMMs of the other: +10 % at 800 chains, profiles/r02y).  Streams are not the
+    reference's (64 heads per chain instead of one)."""
 
     name = "hip-wave64"
 
@@ -645,10 +647,11 @@ class GroupedCodec:
 
     The serial rANS kernels keep one wavefront busy per chain -- a few percent of an MI355X at 100
     chains -- while the conv stacks and the table kernels want the whole chip.  The chains are split
-    into G groups.  All groups share ONE bulk stream (convs, fused logistic/table kernels: they run one
-    after another at full width and never compete with each other) and each group has its own serial
-    stream for pop/push.  The enqueue order is interleaved at coding-operation granularity, so while
-    group A's pop runs on its serial stream the bulk stream is already executing group B's convs.
+    into G groups.  Each group has a bulk stream (convs, fused logistic/table kernels) and a serial stream
+    (pop/push).  The enqueue order is interleaved at coding-operation granularity, so while group A's pop
+    runs on its serial stream group B's convs are already executing, and the HBM-bound transform passes
+    and the float64 table kernels of one group fill in under the matrix-core GEMMs of the other (2.5 %
+    over ONE bulk stream shared by all groups, profiles/r02y; BITSWAP_BULK_PER_GROUP=0 restores that).
     Chains never interact: results are identical to coding each group on its own.
     """
 
@@ -657,9 +660,13 @@ class GroupedCodec:
         self.device = zendpoints.device
         self.X, self.Z, self.K = self.codecs[0].X, self.codecs[0].Z, self.codecs[0].K
         self.bulk = None
-        if groups > 1:
+        self.group_streams = None
+        if groups > 1 and (isinstance(self.codecs[0].backend, Hip64Backend) or os.environ.get("BITSWAP_GROUP_STREAMS") == "1"):
+            # fused coding kernels: nothing serial to split off; ONE stream per group, the groups overlap each other
+            self.group_streams = [torch.cuda.Stream(device=self.device) for _ in self.codecs]
+        elif groups > 1:
             self.bulk = torch.cuda.Stream(device=self.device)
-            own = os.environ.get("BITSWAP_BULK_PER_GROUP", "1") == "1"    # experiment: every group its own bulk stream
+            own = os.environ.get("BITSWAP_BULK_PER_GROUP", "1") == "1"
             for c in self.codecs:
                 c.bulk = torch.cuda.Stream(device=self.device) if own else self.bulk
                 c.serial = torch.cuda.Stream(device=self.device)
@@ -677,6 +684,8 @@ class GroupedCodec:
                 for c, sl in zip(self.codecs, self.split(nchains))]
 
     def _streams(self):
+        if self.group_streams is not None:
+            return self.group_streams
         return [] if self.bulk is None else list({id(t): t for t in [c.bulk for c in self.codecs] + [c.serial for c in self.codecs]}.values())
 
     def _fork(self):
@@ -691,18 +700,19 @@ class GroupedCodec:
         for s in self._streams():
             cur.wait_stream(s)
 
-    @staticmethod
-    def _round_robin(gens, skew=1):
+    def _round_robin(self, gens, skew=1):
         """Advance the generators in turn; group g starts g*skew operations late so that one group's
         serial kernel coincides with another group's conv stack."""
         live = list(range(len(gens)))
         last = [None] * len(gens)
         tick = 0
+        ctx = [torch.cuda.stream(t) for t in self.group_streams] if self.group_streams is not None else None
         while live:
             for g in list(live):
                 if tick >= g * skew:
                     try:
-                        last[g] = next(gens[g])
+                        with (ctx[g] if ctx is not None else contextlib.nullcontext()):
+                            last[g] = next(gens[g])
                     except StopIteration:
                         live.remove(g)
             tick += 1
@@ -741,6 +751,7 @@ class GroupedCodec:
                 if not warm and c._graph_ok(st):
                     c._graphed(st, False)
             return torch.stack(outs[0], dim=1)
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         self._fork()
 
         def chain_of_blocks(g):
@@ -750,7 +761,7 @@ class GroupedCodec:
                 for x in c.decode_steps(st):
                     yield
                 if x is not None and x.is_cuda:
-                    x.record_stream(torch.cuda.current_stream(self.device))
+                    x.record_stream(main)
                 outs[g][xi] = x
         self._round_robin([chain_of_blocks(g) for g in range(len(self.codecs))])
         self._join()

@@ -556,6 +556,18 @@ def wino_out(M, shape, bias=None, res=None, want_sum=False, want_act=True, cfg=(
     return s_out, a_out
 
 
+def conv3_wino_supported(cin, h, w):
+    """Shapes bs_conv3_wino_f32 takes: a wavefront covers whole images (T = (h/4)*(w/4) divides 64) and the Cin planes
+    of those images plus four activation tiles fit the 160 KB of LDS."""
+    if h % 4 or w % 4 or h < 4 or w < 4:
+        return False
+    t = (h // 4) * (w // 4)
+    if t > 64 or 64 % t:
+        return False
+    img, lp = 64 // t, (h + 4) * (w + 4)
+    return (img * cin * lp + 4 + 4 * (img * lp + 4)) * 4 <= 160 * 1024
+
+
 def conv3_wino(x, w, bias, act=3, want_act=True, ts_out=6):
     """Input conv of a stack fused with the first transform: x [N,Cin,H,W], w [C,Cin,3,3] -> (h [N,C,H,W] | None,
     V [ts_out^2, C, N*T]) with h = ELU(conv3x3(x) + bias) (act & 1) and V = B^T ELU(h) B (act & 2); see

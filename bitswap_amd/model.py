@@ -236,7 +236,9 @@ class Model(nn.Module):
         # kernels (profiles/r02g_kernel_stats.txt: 177 vs 177 ms per step), so it is an option, not the default
         self.wino_inputs = os.environ.get("BITSWAP_WINO_INPUTS", "0") == "1"
         # 3x3 input convs (Cin = zchannels) as a direct fp32 convolution fused with bias, ELU and the forward transform of
-        # the block behind them (bs_conv3_wino_f32) instead of an MIOpen launch + a transform pass
+        # the block behind them (bs_conv3_wino_f32) instead of an MIOpen launch + a transform pass.  As fast as the pair it
+        # replaces (155 us against 72 + 93 us alone at 400 blocks, the same bench line: profiles/r02x, r02y); kept on
+        # because it takes a library's algorithm choice out of what sender and receiver have to agree on.
         self.fused_inputs = os.environ.get("BITSWAP_FUSED_INPUTS", "1") == "1"
         # Winograd route: run with the ResNet width padded to the next multiple of 64 when that costs at most 8 dead
         # channels (252, 254, 255 -> 256).  The batched GEMMs of [C x C] x [C x tiles] are 15-20 % faster at C = 256
@@ -426,7 +428,8 @@ class Model(nn.Module):
             return self._unpad(hip.wino_fused(raw.m, shape_out, ts, m.bias_p(), None, True, want_act=True)[1])  # ELU(A^T M A + b)
         if follows and self._wino_ok(list(nxt[0].children()), x):
             nts = int(round(list(nxt[0].children())[0].conv1._wu.shape[0] ** 0.5))
-            if self.fused_inputs and m.kernel_size == 3 and m.in_dim <= 16 and m.stride == 1 and m.padding == 1:
+            if (self.fused_inputs and m.kernel_size == 3 and m.in_dim <= 16 and m.stride == 1 and m.padding == 1
+                    and hip.conv3_wino_supported(m.in_dim, x.shape[2], x.shape[3])):
                 # direct 3x3 conv on the fp32 VALU + bias + ELU + forward transform in one launch (no MIOpen call)
                 wp = m._wp if m._wp is not None else m._w
                 return _ConvDone(*hip.conv3_wino(x.contiguous(), wp, m.bias_p(), 3, True, nts))

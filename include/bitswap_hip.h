@@ -240,6 +240,9 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  * bs_conv3_wino_f32 -- the 3x3 'same' INPUT convolution of a stack (x [N,Cin,H,W], w [C,Cin,3,3], small Cin) fused with
  *   what follows it up to the first GEMM of the next block: h = (act & 1) ? ELU(conv(x) + bias[c]) : conv(x) + bias[c];
  *   act_out [N,C,H,W] = h (nullable); V [ts_out^2, C, N*T] = B^T h' B with h' = (act & 2) ? ELU(h) : h.  ts_out 6 or 8.
+ *   H, W multiples of 4 with T = (H/4)*(W/4) dividing 64 (a wavefront covers whole images) and the Cin planes of 64/T
+ *   images within the LDS (BS_EUNSUPPORTED otherwise; bitswap_amd.hip.conv3_wino_supported).  Per (image, channel) the
+ *   sum runs over ci, then ky, kx in that order: batch-invariant.
  *
  * bs_small_k_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols] for small Cin (<= 64): the batched product
  *   of the INPUT convolutions of the stacks in the Winograd domain (Cin = zchannels or 4 x image channels); a write of M

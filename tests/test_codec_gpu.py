@@ -189,24 +189,30 @@ def test_fused_epilogues_match_torch_modules(name, algo):
         assert torch.allclose(a, torch.nn.functional.elu(x), atol=1e-6)
 
 
+@pytest.mark.parametrize("fmt", ["reference", "wave64"])
 @pytest.mark.parametrize("bitswap", [1, 0])
-def test_grouped_codec_equals_plain_codec(bitswap):
+def test_grouped_codec_equals_plain_codec(bitswap, fmt):
     """GroupedCodec (chain groups on separate HIP streams, enqueue order interleaved) is a scheduling
     device only: every chain's stream equals the one the plain single-stream codec produces for the same
-    group composition, the receiver returns the blocks, and all states unwind."""
-    from bitswap_amd.codec import GroupedCodec
+    group composition, the receiver returns the blocks, and all states unwind.  Reference format: a bulk and a serial
+    stream per group; 64-state format: one stream per group."""
+    from bitswap_amd.codec import GroupedCodec, Hip64Backend, HipBackend
+    from bitswap_amd.hip import split_state
     model, zend, zcen = workload.build("cifar8", DEV, quantbits=10, small=16)
     B, n = 6, 3
     images = workload.synthetic_blocks(B * n, model.xs, seed=21).view(B, n, -1).to(torch.int32).to(DEV)
     init = initial_states(B, 12000)
-    gc = GroupedCodec(model, zend, zcen, groups=2, quantbits=10, bitswap=bool(bitswap))
+    mk = (lambda: Hip64Backend(DEV)) if fmt == "wave64" else (lambda: HipBackend(DEV))
+    gc = GroupedCodec(model, zend, zcen, groups=2, quantbits=10, bitswap=bool(bitswap), backend=mk())
+    assert (gc.group_streams is not None) == (fmt == "wave64")
     states = gc.new_states(B, n, states=init)
     gc.encode_blocks(states, images)
     torch.cuda.synchronize()
     gc.check(states)
     got = gc.to_lists(states)
     # the same two groups through the plain codec, one after the other on the default stream
-    plain = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap))
+    plain = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap), backend=mk())
+    plain.use_graphs = False
     want = []
     for sl in gc.split(B):
         st = plain.new_states(sl.stop - sl.start, n, states=init[sl])
@@ -217,7 +223,8 @@ def test_grouped_codec_equals_plain_codec(bitswap):
     out = gc.decode_blocks(states, n)
     torch.cuda.synchronize()
     gc.check(states)
-    assert torch.equal(out, images) and gc.to_lists(states) == init
+    assert torch.equal(out, images)
+    assert gc.to_lists(states) == ([split_state(s) for s in init] if fmt == "wave64" else init)
 
 
 def test_config3_shape_many_blocks_lossless():
