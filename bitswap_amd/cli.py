@@ -77,7 +77,8 @@ def stream_meta(codec, model, chains_in_call):
             "cdf_spec": {"z": [2 if s is not None else 1 for s in codec.zstep], "x": 2 if codec.xstep is not None else 1},
             "library_abi": hip.ABI_VERSION, "backend": getattr(codec.backend, "name", "?"),
             "conv_route": {"fused": bool(getattr(model, "fused", False)), "conv_algo": model.conv_algo,
-                           "wino_inputs": bool(model.wino_inputs), "gemm_backend": model.gemm_backend,
+                           "wino_inputs": bool(model.wino_inputs), "fused_inputs": bool(getattr(model, "fused_inputs", False)),
+                           "pad_channels": bool(getattr(model, "pad_channels", False)), "gemm_backend": model.gemm_backend,
                            "gemm_min_batch": model.gemm_min_batch, "nn_batch": model.nn_batch,
                            "chains_per_call": int(chains_in_call)}}
 

@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/bitswap_hip.h"
 
 namespace {
@@ -599,12 +601,15 @@ __global__ __launch_bounds__(256) void k_small_k_gemm(const float* __restrict__ 
 template <int TS_OUT>
 int launch_conv3(const float* x, const float* w, const float* bias, int act, float* act_out, float* V, int64_t N, int Cin,
                  int C, int H, int W, int cpb, dim3 grid, size_t shm, hipStream_t st) {
-    static size_t granted = 0;                       // dynamic LDS above 64 KB has to be granted per kernel
-    if (shm > granted) {
+    static std::atomic<size_t> granted[64];          // dynamic LDS above 64 KB has to be granted per kernel and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return BS_ELAUNCH;
+    std::atomic<size_t>& g = granted[dev & 63];
+    if (shm > g.load(std::memory_order_relaxed)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_wino<TS_OUT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return BS_EUNSUPPORTED;
-        granted = shm;
+        g.store(shm, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((k_conv3_wino<TS_OUT>), grid, dim3(256), shm, st, x, w, bias, act_out, V, N, Cin, C, H, W, act, cpb);
     return launch_rc();
