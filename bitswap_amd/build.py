@@ -6,7 +6,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bitswap_hip.hip")
-SRCS = [SRC, os.path.join(HERE, "csrc", "net_epilogue.hip")]
+SRCS = [SRC, os.path.join(HERE, "csrc", "net_epilogue.hip"), os.path.join(HERE, "csrc", "wino_gemm.hip")]
 HDR = os.path.join(HERE, "..", "include", "bitswap_hip.h")
 LIB = os.path.join(HERE, "csrc", "libbitswap_hip.so")
 

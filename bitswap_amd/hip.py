@@ -21,7 +21,7 @@ SYMBOLS = [
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres", "bs_layer_pop64",
     "bs_layer_push64",
     "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
-    "bs_small_k_gemm_f32", "bs_conv3_wino_f32",
+    "bs_small_k_gemm_f32", "bs_conv3_wino_f32", "bs_wino_gemm_f32",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
@@ -71,6 +71,7 @@ def load():
     L.bs_wino_fused_f32.argtypes = [p, i32, p, p, i32, p, p, p, i32, i64, i32, i32, i32, p]
     L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.bs_small_k_gemm_f32.argtypes = [p, p, p, i32, i32, i32, i64, p]
+    L.bs_wino_gemm_f32.argtypes = [p, p, p, i32, i32, i32, i64, p]
     L.bs_conv3_wino_f32.argtypes = [p, p, p, i32, p, p, i32, i64, i32, i32, i32, i32, p]
     L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     for n in SYMBOLS:
@@ -583,6 +584,25 @@ def conv3_wino(x, w, bias, act=3, want_act=True, ts_out=6):
     _check(load().bs_conv3_wino_f32(_ptr(x), _ptr(w), _ptr(bias), int(act), _ptr(h), _ptr(V), ts_out, N, Cin, Cc, H, W,
                                     _stream()), "bs_conv3_wino_f32")
     return h, V
+
+
+def wino_gemm_supported(U, V):
+    """bs_wino_gemm_f32 takes float32, contiguous operands with Cin % 16 == 0 and cols % 4 == 0."""
+    return (U.dtype == V.dtype == torch.float32 and U.dim() == V.dim() == 3 and U.is_contiguous() and V.is_contiguous()
+            and U.shape[0] == V.shape[0] and U.shape[2] == V.shape[1] and U.shape[2] % 16 == 0 and V.shape[2] % 4 == 0)
+
+
+def wino_gemm(U, V, out=None):
+    """M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols] on the matrix cores, float32 with float32 accumulation
+    in one fixed order per output element: bitwise independent of cols (include/bitswap_hip.h, bs_wino_gemm_f32)."""
+    _need_cuda(U, V, out)
+    assert wino_gemm_supported(U, V)
+    T, Cout, Cin = U.shape
+    cols = V.shape[2]
+    M = out if out is not None else torch.empty((T, Cout, cols), dtype=torch.float32, device=V.device)
+    assert M.is_contiguous() and tuple(M.shape) == (T, Cout, cols) and M.dtype == torch.float32
+    _check(load().bs_wino_gemm_f32(_ptr(U), _ptr(V), _ptr(M), T, Cout, Cin, cols, _stream()), "bs_wino_gemm_f32")
+    return M
 
 
 def small_k_gemm(U, V):

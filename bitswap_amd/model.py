@@ -246,6 +246,12 @@ class Model(nn.Module):
         # traffic.  The dead channels carry zero weights and zero biases, so they stay exactly zero through ELU and the
         # residual adds and never reach a result.
         self.pad_channels = os.environ.get("BITSWAP_PAD_CHANNELS", "1") == "1"
+        # the batched GEMMs of the Winograd route on our own fp32 MFMA kernel (bs_wino_gemm_f32) instead of the BLAS
+        # library: results independent of the batch and of library heuristics; as fast at 800 chains (162.97 vs 164.72
+        # ms per step), 8 % faster at the reference's 100 (28.2 vs 30.6 ms: the library drops to a 32x32 macro tile
+        # there), profiles/r02G.  Products with fewer than 64 output channels (the heads) stay with the library.
+        self.own_gemm = os.environ.get("BITSWAP_OWN_GEMM", "1") == "1"
+        self.own_gemm_min_cout = int(os.environ.get("BITSWAP_OWN_GEMM_MIN_COUT", "64"))
         self._cp = reswidth
         self.gemm_min_batch = int(os.environ.get("BITSWAP_GEMM_MIN_BATCH", "1"))
         # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs ("" = torch's default)
@@ -496,21 +502,29 @@ class Model(nn.Module):
             v = hip.wino_fused(h, shape, 0, None, None, True, ts_out=ts)[2]                   # B^T ELU(h) B
         for k, L in enumerate(layers):
             b1, b2 = L.conv1.bias_p(), L.conv2.bias_p()
-            v = hip.wino_fused(torch.bmm(L.conv1._wu, v), shape, ts, b1, None, True, ts_out=ts)[2]
-            m2 = torch.bmm(L.conv2._wu, v)
+            v = hip.wino_fused(self._bmm(L.conv1._wu, v), shape, ts, b1, None, True, ts_out=ts)[2]
+            m2 = self._bmm(L.conv2._wu, v)
             if k == len(layers) - 1:      # the block is followed by act: only ELU(sum) is needed
                 if want_v:                # ... and only as the operand of the 3x3 head convs
                     return _WinoOperand(hip.wino_fused(m2, shape, ts, b2, h, True, ts_out=6)[2], shape)
                 return hip.wino_fused(m2, shape, ts, b2, h, True, want_act=True)[1]
             h, _, v = hip.wino_fused(m2, shape, ts, b2, h, True, want_sum=True, ts_out=ts)
 
+    def _bmm(self, U, V):
+        """The batched product of a Winograd-domain convolution: our MFMA kernel (one fixed summation order per output,
+        whatever the batch) for outputs of at least `own_gemm_min_cout` channels, else the BLAS library."""
+        from . import hip
+        if self.own_gemm and U.shape[1] >= self.own_gemm_min_cout and hip.wino_gemm_supported(U, V):
+            return hip.wino_gemm(U, V)
+        return torch.bmm(U, V)
+
     def _res_wino_unfused(self, layers, h, cfg):
         from . import hip
         shape = tuple(h.shape)
         for k, L in enumerate(layers):
-            m1 = torch.bmm(L.conv1._wu, hip.wino_in(h, None, True, cfg))              # conv1(ELU(h))
+            m1 = self._bmm(L.conv1._wu, hip.wino_in(h, None, True, cfg))              # conv1(ELU(h))
             t = hip.wino_out(m1, shape, L.conv1.bias_p(), None, False, True, cfg)[1]  # ELU(. + b1)
-            m2 = torch.bmm(L.conv2._wu, hip.wino_in(t, None, False, cfg))
+            m2 = self._bmm(L.conv2._wu, hip.wino_in(t, None, False, cfg))
             if k == len(layers) - 1:
                 return hip.wino_out(m2, shape, L.conv2.bias_p(), h, False, True, cfg)[1]
             h = hip.wino_out(m2, shape, L.conv2.bias_p(), h, True, False, cfg)[0]
@@ -544,7 +558,7 @@ class Model(nn.Module):
         from . import hip
         w, b = self._heads[key]
         if isinstance(h, _WinoOperand):     # head convs as one more batched GEMM on the operand the block left
-            x = hip.wino_fused(torch.bmm(self._heads_u[key], h.v), (h.shape[0], w.shape[0]) + h.shape[2:], 6, None,
+            x = hip.wino_fused(self._bmm(self._heads_u[key], h.v), (h.shape[0], w.shape[0]) + h.shape[2:], 6, None,
                                None, False, want_sum=True)[0]
             return hip.head_params(x, b, mode)
         return hip.head_params(F.conv2d(self._unpad(h), w, None, stride=1, padding=(w.shape[-1] - 1) // 2), b, mode)
@@ -565,7 +579,7 @@ class Model(nn.Module):
             h = self._fused_res(self.gen_res0, self._fused_res(self.gen_res1, self._fused_in(self.gen_in, h, self.gen_res1)), hv)
             if isinstance(h, _WinoOperand):
                 g0 = self.gen_mu[0]
-                x = hip.wino_fused(torch.bmm(self._gen_mu_u, h.v), (h.shape[0], g0.out_dim) + h.shape[2:], 6, g0.b,
+                x = hip.wino_fused(self._bmm(self._gen_mu_u, h.v), (h.shape[0], g0.out_dim) + h.shape[2:], 6, g0.b,
                                    None, False, want_sum=True)[0]
                 return self.gen_mu[1](x), self._gen_scale
             h = self._unpad(h)

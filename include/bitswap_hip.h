@@ -244,6 +244,12 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *   images within the LDS (BS_EUNSUPPORTED otherwise; bitswap_amd.hip.conv3_wino_supported).  Per (image, channel) the
  *   sum runs over ci, then ky, kx in that order: batch-invariant.
  *
+ * bs_wino_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols], float32 on the matrix cores
+ *   (v_mfma_f32_32x32x2_f32, float32 accumulate): the batched product in the middle of a Winograd-domain convolution
+ *   (bitswap_amd/csrc/wino_gemm.hip).  Every output element is the sum over ci in one fixed order that depends on
+ *   Cin only: results are bitwise independent of `cols` (how many blocks are coded together), which no BLAS library
+ *   promises.  Cin % 16 == 0, cols % 4 == 0, 16-byte aligned operands (BS_EUNSUPPORTED / BS_EINVAL otherwise).
+ *
  * bs_small_k_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols] for small Cin (<= 64): the batched product
  *   of the INPUT convolutions of the stacks in the Winograd domain (Cin = zchannels or 4 x image channels); a write of M
  *   with a dozen multiply-adds per element.  cols % 4 == 0, 16-byte aligned operands.
@@ -256,6 +262,7 @@ int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scal
                        int HW, int mode, void* stream);
 int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W,
                         int act, void* stream);
+int bs_wino_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream);
 int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act, float* act_out, float* V, int ts_out,
                       int64_t N, int Cin, int C, int H, int W, void* stream);
 int bs_small_k_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream);

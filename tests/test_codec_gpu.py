@@ -688,6 +688,49 @@ def test_small_k_gemm_matches_bmm():
         assert torch.equal(M, hip.small_k_gemm(U, V))
 
 
+@pytest.mark.parametrize("T,Cout,Cin,cols", [(36, 256, 256, 1600), (64, 256, 256, 640), (36, 128, 64, 208), (3, 96, 48, 100),
+                                              (36, 16, 256, 400), (2, 300, 32, 132)])
+def test_wino_gemm_matches_bmm_and_is_batch_invariant(T, Cout, Cin, cols):
+    """bs_wino_gemm_f32 (fp32 MFMA batched product of the Winograd route) against the float64 product: full tiles,
+    partial column tiles, output-channel counts that are no multiple of the workgroup tile, all three workgroup shapes.
+    Every output is summed in one fixed order: a subset of the columns gives the same bits as the full call."""
+    from bitswap_amd import hip
+    g = torch.Generator().manual_seed(T + cols)
+    U = (torch.randn((T, Cout, Cin), generator=g) / Cin ** 0.5).to(DEV)
+    V = torch.randn((T, Cin, cols), generator=g).to(DEV)
+    M = hip.wino_gemm(U, V)
+    want = torch.bmm(U.double(), V.double())
+    assert M.shape == want.shape and float((M.double() - want).abs().max()) < 2e-5
+    lib = torch.bmm(U, V)
+    assert float((M - lib).abs().max()) < 2e-5
+    assert torch.equal(M, hip.wino_gemm(U, V))
+    sub = V[:, :, 4:cols // 2 // 4 * 4].contiguous()
+    assert torch.equal(hip.wino_gemm(U, sub), M[:, :, 4:cols // 2 // 4 * 4])
+    out = torch.full_like(M, float("nan"))
+    assert hip.wino_gemm(U, V, out=out) is out and torch.equal(out, M)
+
+
+def test_own_gemm_route_round_trip():
+    """The conv stacks with their batched products on bs_wino_gemm_f32 (Model.own_gemm): conv outputs within fp32
+    rounding of the library route, lossless round trip, every state unwound."""
+    model, zend, zcen = workload.build("cifar8", DEV, quantbits=8, small=64)
+    model.own_gemm, model.own_gemm_min_cout = True, 16
+    B, n = 6, 2
+    images = workload.synthetic_blocks(B * n, model.xs, seed=33).view(B, n, -1).to(torch.int32).to(DEV)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=8)
+    codec.use_graphs = False
+    state, _ = codec.compress(images)
+    out = codec.decompress(state, n)
+    assert torch.equal(out, images) and state.to_lists() == initial_states(B)
+    # the same stack through the library GEMMs: same numbers up to fp32 summation order
+    z = torch.randn((B,) + tuple(model.zdim), generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        mu1, s1 = model.generate(1)(given=z)
+        model.own_gemm = False
+        mu2, s2 = model.generate(1)(given=z)
+    assert float((mu1 - mu2).abs().max()) < 1e-4 * max(1.0, float(mu2.abs().max())) and float((s1 - s2).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("ts,N,C,hw", [(6, 21, 40, 16), (8, 21, 40, 16), (6, 7, 9, 8), (8, 3, 17, 32), (6, 400, 256, 16)])
 def test_conv3_wino_matches_conv_plus_transform(ts, N, C, hw):
     """bs_conv3_wino_f32 (input conv of a stack, Cin = 8, fused with bias + ELU + the forward transform) against

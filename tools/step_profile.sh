@@ -1,9 +1,9 @@
 #!/bin/bash
 # Per-kernel time of ONE bench step: kernel-trace totals of a 5-step run minus those of a 1-step run, divided by 4
-# (setup, bins sampling and warm-up cancel).   gpurun --timeout 900 -- 'bash tools/step_profile.sh r02t'
+# (setup, bins sampling and warm-up cancel).   gpurun --timeout 900 -- '[BENCH_ARGS="--chains 100 --groups 1"] bash tools/step_profile.sh r02t'
 TAG=${1:-rXX}; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
 for k in 1 5; do
-  ( cd /tmp && rm -rf sp$k && timeout 400 rocprofv3 --kernel-trace -d /tmp/sp$k -o st --output-format csv -- python $R/bench.py --steps $k --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1 )
+  ( cd /tmp && rm -rf sp$k && timeout 400 rocprofv3 --kernel-trace -d /tmp/sp$k -o st --output-format csv -- python $R/bench.py --steps $k --warmup 1 --no-cpu-baseline --no-extra $BENCH_ARGS > /dev/null 2>&1 )
 done
 python - <<PY
 import csv, glob, collections
