@@ -88,12 +88,16 @@ class ImageBins:
     def __init__(self, type, device, shape):
         self.type, self.device, self.shape = type, device, [shape]
 
+    # The arithmetic runs on the HOST and the result is copied to the device: torch divides by a scalar with IEEE
+    # division on the CPU but with a multiplication by the rounded reciprocal on the GPU, which moves a third of these
+    # endpoints by an ulp or two -- enough to flip a table entry once in ~1e8 bins, i.e. to make a GPU sender and a CPU
+    # receiver (or the oracle) disagree on a stream.  Bins are data both ends must share bit for bit.
     def endpoints(self):
-        e = torch.arange(1, 256, dtype=self.type, device=self.device)
-        e = ((e - 127.5) / 127.5) - 1. / 255.
+        e = torch.arange(1, 256, dtype=self.type, device="cpu")
+        e = (((e - 127.5) / 127.5) - 1. / 255.).to(self.device)
         return e[None,].expand(self.shape + [-1])
 
     def centres(self):
-        c = torch.arange(0, 256, dtype=self.type, device=self.device)
-        c = (c - 127.5) / 127.5
+        c = torch.arange(0, 256, dtype=self.type, device="cpu")
+        c = ((c - 127.5) / 127.5).to(self.device)
         return c[None,].expand(self.shape + [-1])

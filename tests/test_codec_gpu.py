@@ -688,6 +688,16 @@ def test_small_k_gemm_matches_bmm():
         assert torch.equal(M, hip.small_k_gemm(U, V))
 
 
+def test_pixel_bins_are_identical_on_host_and_device():
+    """ImageBins built for the GPU must be the host's numbers bit for bit (torch divides by a scalar differently on
+    the two; a GPU sender and a CPU receiver / the oracle would otherwise disagree on a table entry once in ~1e8 bins,
+    which the full-width 64-state test hit)."""
+    from bitswap_amd.rand import ImageBins
+    a, b = ImageBins(torch.float64, DEV, 7), ImageBins(torch.float64, "cpu", 7)
+    assert torch.equal(a.endpoints().cpu(), b.endpoints()) and torch.equal(a.centres().cpu(), b.centres())
+    assert a.endpoints().is_cuda and a.endpoints().shape == (7, 255) and a.endpoints().stride(0) == 0
+
+
 @pytest.mark.parametrize("T,Cout,Cin,cols", [(36, 256, 256, 1600), (64, 256, 256, 640), (36, 128, 64, 208), (3, 96, 48, 100),
                                               (36, 16, 256, 400), (2, 300, 32, 132)])
 def test_wino_gemm_matches_bmm_and_is_batch_invariant(T, Cout, Cin, cols):
