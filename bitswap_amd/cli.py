@@ -79,7 +79,8 @@ def stream_meta(codec, model, chains_in_call):
             "conv_route": {"fused": bool(getattr(model, "fused", False)), "conv_algo": model.conv_algo,
                            "wino_inputs": bool(model.wino_inputs), "fused_inputs": bool(getattr(model, "fused_inputs", False)),
                            "pad_channels": bool(getattr(model, "pad_channels", False)), "own_gemm": bool(getattr(model, "own_gemm", False)),
-                           "own_gemm_min_cout": int(getattr(model, "own_gemm_min_cout", 0)), "gemm_backend": model.gemm_backend,
+                           "own_gemm_min_cout": int(getattr(model, "own_gemm_min_cout", 0)),
+                           "own_gemm_min_cols": int(getattr(model, "own_gemm_min_cols", 0)), "gemm_backend": model.gemm_backend,
                            "gemm_min_batch": model.gemm_min_batch, "nn_batch": model.nn_batch,
                            "chains_per_call": int(chains_in_call)}}
 

@@ -252,6 +252,9 @@ class Model(nn.Module):
         # there), profiles/r02G.  Products with fewer than 64 output channels (the heads) stay with the library.
         self.own_gemm = os.environ.get("BITSWAP_OWN_GEMM", "1") == "1"
         self.own_gemm_min_cout = int(os.environ.get("BITSWAP_OWN_GEMM_MIN_COUT", "64"))
+        # ... and so do products with few columns (13 chains = 208 columns of 16x16 planes: 64 x 128 workgroup tiles
+        # leave most CUs idle, 8.9 vs 7.1 ms per step in the 64-state format, profiles/r02H vs r02I)
+        self.own_gemm_min_cols = int(os.environ.get("BITSWAP_OWN_GEMM_MIN_COLS", "512"))
         self._cp = reswidth
         self.gemm_min_batch = int(os.environ.get("BITSWAP_GEMM_MIN_BATCH", "1"))
         # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs ("" = torch's default)
@@ -512,9 +515,11 @@ class Model(nn.Module):
 
     def _bmm(self, U, V):
         """The batched product of a Winograd-domain convolution: our MFMA kernel (one fixed summation order per output,
-        whatever the batch) for outputs of at least `own_gemm_min_cout` channels, else the BLAS library."""
+        whatever the batch) for outputs of at least `own_gemm_min_cout` channels and `own_gemm_min_cols` columns, else
+        the BLAS library.  Sender and receiver code the same number of chains per call, so they take the same branch."""
         from . import hip
-        if self.own_gemm and U.shape[1] >= self.own_gemm_min_cout and hip.wino_gemm_supported(U, V):
+        if (self.own_gemm and U.shape[1] >= self.own_gemm_min_cout and V.shape[2] >= self.own_gemm_min_cols
+                and hip.wino_gemm_supported(U, V)):
             return hip.wino_gemm(U, V)
         return torch.bmm(U, V)
 

@@ -724,7 +724,7 @@ def test_own_gemm_route_round_trip():
     """The conv stacks with their batched products on bs_wino_gemm_f32 (Model.own_gemm): conv outputs within fp32
     rounding of the library route, lossless round trip, every state unwound."""
     model, zend, zcen = workload.build("cifar8", DEV, quantbits=8, small=64)
-    model.own_gemm, model.own_gemm_min_cout = True, 16
+    model.own_gemm, model.own_gemm_min_cout, model.own_gemm_min_cols = True, 16, 4
     B, n = 6, 2
     images = workload.synthetic_blocks(B * n, model.xs, seed=33).view(B, n, -1).to(torch.int32).to(DEV)
     codec = BitSwapCodec(model, zend, zcen, quantbits=8)
