@@ -306,8 +306,12 @@ def main(args):
     name = args.workload
     r = run_workload(args, name, args.chains, args.groups, args.steps, args.warmup, dev, rank, world, dist, want_gather=True)
     codec, model = r.pop("codec"), r.pop("model")
-    conv_path = (f"{model.conv_algo} (fp32; ResNet/head convs as transform-domain batched GEMMs, BLAS backend "
-                 f"{model.gemm_backend})" if getattr(model, "fused", False) else "torch modules")
+    gemm = (f"bs_wino_gemm_f32 (own fp32 MFMA kernel, from {model.own_gemm_min_cout} channels x {model.own_gemm_min_cols} "
+            f"columns; below: BLAS backend {model.gemm_backend})" if getattr(model, "own_gemm", False)
+            else f"BLAS backend {model.gemm_backend}")
+    conv_path = (f"{model.conv_algo} (fp32; ResNet/head convs as transform-domain batched GEMMs on {gemm}; 3x3 input convs: "
+                 f"{'bs_conv3_wino_f32' if getattr(model, 'fused_inputs', False) else 'MIOpen'})"
+                 if getattr(model, "fused", False) else "torch modules")
     Z, X = codec.Z, codec.X
     del codec, model
 

@@ -470,3 +470,19 @@ def test_container_tiling_and_sharding_properties():
             assert sorted(c for o in owners for c in o) == list(range(nch))
         loads = [sum(wts[c] for c in o) for o in owners]
         assert max(loads) <= (4 / 3) * (sum(wts) / world) + max(wts)
+
+
+def test_kernel_support_predicates():
+    """Host-side shape checks in front of bs_conv3_wino_f32 / bs_wino_gemm_f32 (no GPU involved): the model falls back
+    to MIOpen / the BLAS library exactly where the kernels would answer BS_EUNSUPPORTED."""
+    from bitswap_amd import hip
+    assert hip.conv3_wino_supported(8, 16, 16) and hip.conv3_wino_supported(16, 32, 32) and hip.conv3_wino_supported(8, 8, 8)
+    assert not hip.conv3_wino_supported(8, 64, 64)        # 256 tiles: more than a wavefront
+    assert not hip.conv3_wino_supported(8, 16, 18)        # not a multiple of 4
+    assert not hip.conv3_wino_supported(16, 8, 8)         # 16 images x 16 planes exceed the LDS
+    U, V = torch.zeros(3, 32, 48), torch.zeros(3, 48, 100)
+    assert hip.wino_gemm_supported(U, V)
+    assert not hip.wino_gemm_supported(torch.zeros(3, 32, 40), torch.zeros(3, 40, 100))      # Cin % 16
+    assert not hip.wino_gemm_supported(U, torch.zeros(3, 48, 102))                            # cols % 4
+    assert not hip.wino_gemm_supported(U, V.transpose(1, 2).contiguous().transpose(1, 2))     # not contiguous
+    assert not hip.wino_gemm_supported(U.double(), V.double())
