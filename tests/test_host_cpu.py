@@ -486,3 +486,22 @@ def test_kernel_support_predicates():
     assert not hip.wino_gemm_supported(U, torch.zeros(3, 48, 102))                            # cols % 4
     assert not hip.wino_gemm_supported(U, V.transpose(1, 2).contiguous().transpose(1, 2))     # not contiguous
     assert not hip.wino_gemm_supported(U.double(), V.double())
+
+
+def test_grouped_codec_enqueue_order():
+    """GroupedCodec._round_robin (pure host logic): coding operations of the chain groups are enqueued alternately,
+    group g starting g*skew operations late, every generator run to its end."""
+    from bitswap_amd.codec import GroupedCodec
+    gc = GroupedCodec.__new__(GroupedCodec)
+    gc.group_streams = None
+    log = []
+
+    def ops(g, n):
+        for k in range(n):
+            log.append((g, k))
+            yield k
+    last = gc._round_robin([ops(0, 3), ops(1, 2), ops(2, 1)], skew=1)
+    assert log == [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)] and last == [2, 1, 0]
+    log.clear()
+    gc._round_robin([ops(0, 2), ops(1, 2)], skew=0)
+    assert log == [(0, 0), (1, 0), (0, 1), (1, 1)]
