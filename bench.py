@@ -21,9 +21,13 @@ shape (100 "experiments"), and the opt-in 64-state stream format at 800 and at 1
 procedure with fewer steps.
 
 Extra objects on the JSON line: `roofline` for the dominant hot-path kernel (the fused
-logistic-CDF -> integer-table kernel, decode flavour) from HIP events recorded on the launch stream
-inside the timed region -- per kernel against HBM as the contract asks, plus the whole-path fraction
- and the VALU-issue fraction the kernel is really bound by -- and `cpu_baseline`: the
+logistic-CDF -> integer-table kernel, decode flavour), timed with HIP events on its launch stream in an
+EXCLUSIVE single-stream pass right after the timed region (inside the pipeline a launch shares the chip with
+the other chain group's GEMMs; that time-shared figure is reported next to it).  The headline bound is the
+one the kernel sits on -- VALU issue, `frac` = issue slots / time / peak -- with the HBM figures beside it
+computed on bytes that actually move (batched algorithmic bytes, PMC counter bytes): every fraction <= 1.
+`roofline.mfma` is the same for the kernel that dominates the rocprof summary (the Winograd-domain batched
+GEMM of the conv stacks, fp32 MFMA), `path_frac` the whole-path figure of SURVEY.md 8(d).  `cpu_baseline`: the
 oracle (C restatement of the reference, libm CDF) + the same conv stacks on the host cores, timed on a
 bounded sample of the same workload, next to the committed measurement of the reference's own Python
 path (profiles/r02_ref_cpu_baseline.json, tools/ref_cpu_baseline.py).
@@ -53,6 +57,7 @@ VALU_SLOTS_PER_ROW = {2: 399, 1: 648}   # CDF spec 2 (uniform bins) / spec 1
 # utilisation next to the HBM figure.  Vector FP64 peak 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
 FP64_FLOPS_PER_ROW = {2: 353 * 64, 1: 699 * 64}
 FP64_PEAK_TFLOPS = 78.6
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, MI355X_MICROARCH.md (155 measured)
 
 TITLES = {"mnist2": "MNIST-shaped 2-latent-layer", "cifar8": "CIFAR-10-shaped 8-latent-layer",
           "imagenet4": "ImageNet32-shaped 4-latent-layer", "imagenetcrop4": "ImageNet-crop-shaped 4-latent-layer"}
@@ -110,15 +115,36 @@ def cpu_baseline(args, name):
     out = {"value": B * n * 1024 / dt, "unit": "pixels/s", "cores": threads, "kind": "port",
            "sample": f"{B} chains x {n} block(s) of {name}, sender+receiver, oracle C (libm CDF) + torch-CPU convs, "
                      f"{dt:.1f} s, lossless={ok}"}
-    # the reference's own Python path (mnist_compress.py:164-358 replayed around the imported reference classes) cannot
-    # travel to the GPU box; its committed measurement rides along, labelled with where it was taken
-    rp = os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json")
-    if os.path.exists(rp):
+    out["reference_python"] = reference_python_baseline(name)
+    return out
+
+
+def reference_python_baseline(name):
+    """The reference's OWN Python path (mnist_compress.py:164-358 replayed around the imported reference classes,
+    tools/ref_cpu_baseline.py).  Same-host when the reference is present on this machine (/root/reference or
+    $BITSWAP_REFERENCE): measured live on a bounded sample.  The project's GPU boxes carry no copy of the reference: there the
+    committed measurement from the build container rides along, and `host` says so."""
+    import subprocess
+    ref = os.environ.get("BITSWAP_REFERENCE", "/root/reference")
+    if os.path.isdir(ref) and name in ("cifar8", "imagenet4", "mnist2"):
         try:
-            out["reference_python"] = json.load(open(rp))
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_cpu_baseline.py"), "--config", name,
+                                "--where", "same host as the GPU run (measured live by bench.py)"],
+                               capture_output=True, text=True, timeout=240, env=dict(os.environ, BITSWAP_REFERENCE=ref))
+            if r.returncode == 0:
+                d = json.loads(r.stdout[r.stdout.index("{"):])
+                d["same_host"] = True
+                return d
         except Exception:
             pass
-    return out
+    rp = os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json")
+    try:
+        d = json.load(open(rp))
+        d["same_host"] = False
+        d["host"] += " -- the reference is not present on this host, committed measurement quoted"
+        return d
+    except Exception:
+        return None
 
 
 def _valu_busy(spec):
@@ -135,7 +161,68 @@ def algorithmic_bytes_per_block(codec):
     return (2 * nz - 1) * (Z * (K - 1) * 8 + 2 * Z * 4 + Z * 4) + (2 * X * 4 + X) + Z * 12
 
 
-def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gather=False):
+def exclusive_pass(codec, states, block, rkey, tl, dev):
+    """The roofline kernel with the chip to itself: ONE chain group codes one block (sender, then the receiver that undoes
+    it) on a single stream -- no other group's GEMMs next to the table launches -- with the same Timeline events.  Runs
+    after the timed region; the state ends where it started.  -> (seconds, launches) of `rkey`, or None."""
+    c, st = codec.codecs[0], states[0]
+    saved = (c.bulk, c.serial, c.use_graphs)
+    try:
+        torch.cuda.synchronize()
+        c.bulk = c.serial = None
+        c.use_graphs = False
+        tl.reset()
+        sl = codec.split(block.shape[0])[0]
+        c.encode_block(st, block[sl, 0])
+        back = c.decode_block(st)
+        torch.cuda.synchronize()
+        if not torch.equal(back, block[sl, 0]):
+            return None
+        t = tl.totals().get(rkey)
+        return t if t and t[1] else None
+    except Exception:
+        return None
+    finally:
+        c.bulk, c.serial, c.use_graphs = saved
+        tl.reset()
+
+
+def gemm_roofline(model, chains, dev, reps=20):
+    """The kernel that dominates the rocprof summary is not on the entropy path: the Winograd-domain batched GEMM of the
+    conv stacks (bs_wino_gemm_f32, fp32 MFMA).  Its own roofline, at the shape one chain group launches most often
+    (36 transform positions x [C x C] x [C x 16 tiles per block]), HIP events around a short exclusive loop."""
+    try:
+        from bitswap_amd import hip
+        if not (getattr(model, "fused", False) and getattr(model, "own_gemm", False)):
+            return None
+        C = int(model._cp)
+        cols = int(chains) * 16
+        U = torch.randn(36, C, C, device=dev)
+        V = torch.randn(36, C, cols, device=dev)
+        if not hip.wino_gemm_supported(U, V):
+            return None
+        out = torch.empty(36, C, cols, device=dev)
+        for _ in range(3):
+            hip.wino_gemm(U, V, out=out)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            hip.wino_gemm(U, V, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) / reps * 1e-3
+        fl = 2.0 * 36 * C * C * cols
+        return {"kernel": "k_wino_gemm<8> (bs_wino_gemm_f32: v_mfma_f32_32x32x2_f32, persistent balanced tiles)", "bound": "mfma",
+                "shape": f"T36 x [{C}x{C}] x [{C}x{cols}]", "achieved": round(fl / t / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(t * 1e3, 4),
+                "launches": reps, "hbm_bytes_per_launch": int(4 * 36 * C * cols * 2 + 4 * 36 * C * C),
+                "timing": "exclusive: HIP events around a back-to-back loop on the current stream"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gather=False, want_roofline=True):
     """One measurement by the contract's procedure.  Returns a dict (timings are max over ranks)."""
     from bitswap_amd import workload
     from bitswap_amd.codec import GroupedCodec, Timeline, initial_states
@@ -235,13 +322,26 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     rkey = "pop_z" if args.format == "wave64" else "tables_z"
     if args.format == "wave64":
         totals.pop("tables_z", None), totals.pop("tables_x", None)      # lazy handles: nothing is launched there
-    if rkey in totals and totals[rkey][1]:
-        sec, cnt = totals[rkey]
+    if rkey in totals and totals[rkey][1] and want_roofline:
+        shared_sec, shared_cnt = totals[rkey]
+        excl = exclusive_pass(codec, states, images[:, W:W + 1], rkey, tl, dev)
         Kb, Z = codec.K, codec.Z
         rows = B * Z / max(1, groups)                     # rows one launch processes (one chain group)
-        alg = int(rows * ((Kb - 1) * 8 + 2 * 4 + 4))      # endpoints f64 + mu,scale f32 + symbol i32
+        sec, cnt = excl if excl else (shared_sec, shared_cnt)
         avg = sec / cnt
-        ach = alg / avg / 1e9
+        spec = args.cdf_spec if any(s is not None for s in codec.codecs[0].zstep) else 1
+        slots = VALU_SLOTS_PER_ROW[spec] if (Kb == 1024 and args.format == "reference") else None
+        kname = (f"k_layer64<16,float,{'uniform' if spec == 2 else 'generic'},pop> (logistic CDF -> integer table -> rANS pop in "
+                 f"one launch, rows in registers, CDF spec {spec})" if args.format == "wave64" else
+                 f"k_logistic<16,float,decode,{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> integer cdf "
+                 f"rows, CDF spec {spec})")
+        # --- HBM side, on bytes that move.  SURVEY 8(d) prices a z-row at (K-1)*8 + 12 B because it counts the [Z, K-1]
+        # float64 endpoint table once per BLOCK; a launch over `chains` blocks reads that table from HBM once (the rest are
+        # L2 hits), so the batched algorithmic bytes are table + 12 B/row (+ the cdf-row hand-off the split design writes:
+        # counted by the PMC figure, not by the algorithm)
+        table_bytes = Z * (Kb - 1) * 8
+        alg_batched = int(table_bytes + rows * 12)
+        survey_alg = int(rows * ((Kb - 1) * 8 + 12))
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp) and args.format == "reference":
@@ -252,30 +352,39 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                 traffic = None
         a_block = algorithmic_bytes_per_block(codec)
         path = 2.0 * a_block * world * B * K / dt / 1e9
-        spec = args.cdf_spec if any(s is not None for s in codec.codecs[0].zstep) else 1
-        slots = VALU_SLOTS_PER_ROW[spec] if (Kb == 1024 and args.format == "reference") else None
-        kname = (f"k_layer64<16,float,{'uniform' if spec == 2 else 'generic'},pop> (logistic CDF -> integer table -> rANS pop in "
-                 f"one launch, rows in registers, CDF spec {spec})" if args.format == "wave64" else
-                 f"k_logistic<16,float,decode,{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> integer cdf "
-                 f"rows, CDF spec {spec})")
-        roof = {"kernel": kname, "bound": "hbm",
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg * 1e3, 4),
-                "alg_bytes_per_launch": alg,
-                # whole path, SURVEY.md 8(d): 2 * A_block * n_blocks / (t_sender + t_receiver) against the same peak
-                "path_alg_bytes_per_block": a_block, "path_achieved": round(path / world, 1),
-                "path_frac": round(path / world / HBM_PEAK_GBPS, 4),
-                # what bounds the kernel: float64 / integer VALU issue (the endpoint rows are L2 hits, the bytes above
-                # are mostly not moved: see `traffic`)
-                "valu_issue": None if slots is None else {
-                    "slots_per_row": slots, "achieved_Ginstr_s": round(rows * slots / avg / 1e9, 1),
-                    "peak_Ginstr_s": round(VALU_PEAK_GINSTR, 1), "frac": round(rows * slots / avg / 1e9 / VALU_PEAK_GINSTR, 4),
+        hbm = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "alg_bytes_per_launch": alg_batched, "achieved": round(alg_batched / avg / 1e9, 1),
+               "frac": round(alg_batched / avg / 1e9 / HBM_PEAK_GBPS, 5),
+               "traffic_bytes_per_launch": traffic,
+               "traffic_achieved": None if traffic is None else round(traffic / avg / 1e9, 1),
+               "traffic_frac": None if traffic is None else round(traffic / avg / 1e9 / HBM_PEAK_GBPS, 4),
+               "note": "alg = endpoint table once per launch + 12 B/row (mu, scale, symbol); traffic = PMC FETCH x2 + WRITE "
+                       "(profiles/traffic.json), 98 % of it the cdf-row hand-off to k_rans_pop_wave; SURVEY 8(d)'s per-block "
+                       f"count would be {survey_alg} B per launch, of which all but the first table pass are L2 hits"}
+        if slots is not None:
+            ach = rows * slots / avg / 1e9
+            roof = {"kernel": kname, "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINSTR, 1),
+                    "unit": "Ginstr/s", "frac": round(ach / VALU_PEAK_GINSTR, 4), "slots_per_row": slots,
                     # measured by SQ counters (profiles/valu_busy.json, tools/pmc_valu.sh): share of the SIMD cycles the
                     # VALU pipe is busy while the kernel runs, at the clock the chip actually holds under float64 load
-                    "valu_busy_pmc": _valu_busy(spec)},
-                "fp64": None if slots is None else {
-                    "flops_per_row": FP64_FLOPS_PER_ROW[spec], "achieved_TFLOPs": round(rows * FP64_FLOPS_PER_ROW[spec] / avg / 1e12, 2),
-                    "peak_TFLOPs": FP64_PEAK_TFLOPS, "frac": round(rows * FP64_FLOPS_PER_ROW[spec] / avg / 1e12 / FP64_PEAK_TFLOPS, 4)}}
+                    "valu_busy_pmc": _valu_busy(spec)}
+        else:       # no issue model for this kernel shape: the counter-side HBM figure is the headline
+            roof = {"kernel": kname, "bound": "hbm", "achieved": hbm["traffic_achieved"] or hbm["achieved"],
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": hbm["traffic_frac"] if hbm["traffic_frac"] is not None else hbm["frac"]}
+        roof.update({"traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg * 1e3, 4),
+                     "timing": ("exclusive: HIP events on the launch stream, single-stream pass of one chain group after the "
+                                "timed region" if excl else "time-shared: HIP events inside the timed region"),
+                     "avg_launch_ms_in_pipeline": round(shared_sec / shared_cnt * 1e3, 4), "rows_per_launch": int(rows),
+                     "hbm": hbm,
+                     "fp64": None if slots is None else {
+                         "flops_per_row": FP64_FLOPS_PER_ROW[spec],
+                         "achieved_TFLOPs": round(rows * FP64_FLOPS_PER_ROW[spec] / avg / 1e12, 2), "peak_TFLOPs": FP64_PEAK_TFLOPS,
+                         "frac": round(rows * FP64_FLOPS_PER_ROW[spec] / avg / 1e12 / FP64_PEAK_TFLOPS, 4)},
+                     # whole path, SURVEY.md 8(d): 2 * A_block * n_blocks / (t_sender + t_receiver) against the HBM peak
+                     "path_alg_bytes_per_block": a_block, "path_achieved": round(path / world, 1),
+                     "path_frac": round(path / world / HBM_PEAK_GBPS, 4),
+                     "mfma": gemm_roofline(model, B // max(1, groups), dev)})
     breakdown = {k: round(v[0] / dt, 4) for k, v in sorted(totals.items())} if totals else None
     res = {"workload": name, "chains_per_gpu": B, "chain_groups": groups, "steps": K, "warmup": W,
            "value": world * B * K * 1024 / dt, "ms_per_step": dt / K * 1e3, "lossless": ok, "bits_per_dim": bpd,
@@ -306,11 +415,11 @@ def main(args):
     name = args.workload
     r = run_workload(args, name, args.chains, args.groups, args.steps, args.warmup, dev, rank, world, dist, want_gather=True)
     codec, model = r.pop("codec"), r.pop("model")
-    gemm = (f"bs_wino_gemm_f32 (own fp32 MFMA kernel, from {model.own_gemm_min_cout} channels x {model.own_gemm_min_cols} "
-            f"columns; below: BLAS backend {model.gemm_backend})" if getattr(model, "own_gemm", False)
-            else f"BLAS backend {model.gemm_backend}")
+    gemm = ("bs_wino_gemm_f32 (own fp32 MFMA kernel, every product: results independent of chains per call)"
+            if getattr(model, "own_gemm", False) else f"BLAS backend {model.gemm_backend}")
     conv_path = (f"{model.conv_algo} (fp32; ResNet/head convs as transform-domain batched GEMMs on {gemm}; 3x3 input convs: "
-                 f"{'bs_conv3_wino_f32' if getattr(model, 'fused_inputs', False) else 'MIOpen'})"
+                 f"{'bs_conv3_wino_f32' if getattr(model, 'fused_inputs', False) else 'MIOpen'}; 5x5 input conv: "
+                 f"{'Winograd domain (bs_small_k_gemm_f32)' if getattr(model, 'wino_in5', False) else 'MIOpen'})"
                  if getattr(model, "fused", False) else "torch modules")
     Z, X = codec.Z, codec.X
     del codec, model
@@ -328,7 +437,7 @@ def main(args):
             try:
                 a2 = copy.copy(args)
                 a2.format = fmt
-                e = run_workload(a2, wn, ch, gr, ks, max(ws, 2) if fmt == "wave64" else ws, dev, rank, world, dist)
+                e = run_workload(a2, wn, ch, gr, ks, max(ws, 2) if fmt == "wave64" else ws, dev, rank, world, dist, want_roofline=False)
                 e.pop("codec"), e.pop("model"), e.pop("stream_gather")
                 e["value"], e["ms_per_step"] = round(e["value"], 1), round(e["ms_per_step"], 3)
                 e["bits_per_dim"] = round(e["bits_per_dim"], 4)
@@ -360,6 +469,7 @@ def main(args):
                    "quantbits": args.quantbits, "ansbits": 31, "cdf_spec": args.cdf_spec, "stream_format": args.format,
                    "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32", "conv_path": conv_path,
                    "weights": "seeded random init (no checkpoints offline)"},
+        "rccl_ranks": (world if (world > 1 and (os.environ.get("BENCH_DIST_BACKEND") or "nccl") == "nccl") else 0),
         "lossless": r["lossless"], "bits_per_dim": round(r["bits_per_dim"], 4),
         "stream_time_fraction": r["stream_time_fraction"],
         "roofline": r["roofline"], "cpu_baseline": cpu, "stream_gather": r["stream_gather"], "extra": extra,

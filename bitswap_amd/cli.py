@@ -19,7 +19,7 @@ import time
 import numpy as np
 import torch
 
-from . import container, dist, tiling, workload
+from . import container, dist, meta, tiling, workload
 from .bins import discretize, _cache_names as _bins_cache_names
 from .codec import BitSwapCodec, initial_states
 from .model import elbo_bits, preset
@@ -67,27 +67,19 @@ def load_model(dataset, nz, device, params, synthetic, nn_batch=None):
     raise FileNotFoundError(f"checkpoint {path} not found -- pass --params <file> or --synthetic")
 
 
-def stream_meta(codec, model, chains_in_call):
-    """What a receiver has to share with the sender beyond weights and bins for a stream to decode: the stream
-    format, the CDF specification per table, and the route the conv stacks took (their float32 results differ in the
-    last bits between routes, batch shapes and BLAS backends).  Written next to the bitstreams as stream_meta.json."""
-    from . import hip
-    return {"stream_format": "wave64" if getattr(codec.backend, "name", "").endswith("wave64") else "reference",
-            "ansbits": codec.bits, "quantbits": codec.q, "bitswap": codec.bitswap,
-            "cdf_spec": {"z": [2 if s is not None else 1 for s in codec.zstep], "x": 2 if codec.xstep is not None else 1},
-            "library_abi": hip.ABI_VERSION, "backend": getattr(codec.backend, "name", "?"),
-            "conv_route": {"fused": bool(getattr(model, "fused", False)), "conv_algo": model.conv_algo,
-                           "wino_inputs": bool(model.wino_inputs), "fused_inputs": bool(getattr(model, "fused_inputs", False)),
-                           "pad_channels": bool(getattr(model, "pad_channels", False)), "own_gemm": bool(getattr(model, "own_gemm", False)),
-                           "own_gemm_min_cout": int(getattr(model, "own_gemm_min_cout", 0)),
-                           "own_gemm_min_cols": int(getattr(model, "own_gemm_min_cols", 0)), "gemm_backend": model.gemm_backend,
-                           "gemm_min_batch": model.gemm_min_batch, "nn_batch": model.nn_batch,
-                           "chains_per_call": int(chains_in_call)}}
+def stream_dir(outdir, dataset, nz, bitswap):
+    scheme = SCHEME[int(bool(bitswap))]
+    return os.path.join(outdir, "bitstreams", dataset, f"nz{nz}", scheme), scheme
+
+
+def stream_name(scheme, quantbits, nz, c, wave64=False):
+    """Pickle name of experiment c (0-based), mnist_compress.py:265-267."""
+    return f"{scheme}_{quantbits}bits_nz{nz}_experiment{c + 1}" + ("_wave64" if wave64 else "")
 
 
 def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndatapoints=100, decompress=False,
              synthetic=False, data=None, params=None, outdir=".", backend=None, small=None, verbose=True,
-             save_bins=False, fmt="reference"):
+             save_bins=False, fmt="reference", cdf_spec=2):
     """One (dataset, nz, quantbits, scheme) experiment set.  Returns dict of the metric arrays on
     rank 0 (None on other ranks).  fmt "wave64": the opt-in 64-state stream format (pickles then hold 64 sub-state
     lists per experiment and carry the suffix _wave64)."""
@@ -133,7 +125,7 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
     mine = dist.shard_chains(experiments, world, rank)
     inits = initial_states(experiments, 10000, seed=100)        # experiment ei gets the ei-th draw (:158)
     codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
-                         backend=_format_backend(fmt, backend, dev))
+                         backend=_format_backend(fmt, backend, dev), cdf_spec=cdf_spec)
     wave64 = hasattr(codec.backend.new_state([inits[0]], 16), "len64") if fmt == "wave64" else False
     x = images[torch.from_numpy(randindices[mine].reshape(-1))].view(len(mine), ndatapoints, -1).to(torch.int32)
     state = codec.new_states(len(mine), ndatapoints, states=[inits[c] for c in mine])
@@ -147,19 +139,22 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
         elbos[:, xi] = (elbo_bits(model, xb) / model.xdim).cpu().numpy()
     sent = state.to_lists()
 
-    scheme = SCHEME[int(bool(bitswap))]
-    sdir = os.path.join(outdir, "bitstreams", dataset, f"nz{nz}", scheme)
+    sdir, scheme = stream_dir(outdir, dataset, nz, bitswap)
     os.makedirs(sdir, exist_ok=True)
     for c, s in zip(mine, sent):
-        container.save_state(os.path.join(sdir, f"{scheme}_{quantbits}bits_nz{nz}_experiment{c + 1}"
-                                          + ("_wave64" if wave64 else "")), s)
+        container.save_state(os.path.join(sdir, stream_name(scheme, quantbits, nz, c, wave64)), s)
+    # what a receiver must reproduce for these streams to decode (bitswap_amd/meta.py); read back and enforced by
+    # decompress_streams() and by the --decompress leg below
+    fp = meta.fingerprint(codec, chains_per_call=len(mine))
     if rank == 0:
-        import json
-        with open(os.path.join(sdir, "stream_meta.json"), "w") as fp:
-            json.dump(dict(stream_meta(codec, model, len(mine)), world_size=world), fp, indent=1)
+        meta.save(os.path.join(sdir, "stream_meta.json"), fp, world_size=world, experiments=experiments,
+                  ndatapoints=ndatapoints)
+    if world > 1:
+        dist.barrier()
 
     t_recv = 0.0
     if decompress:
+        meta.check(meta.load(os.path.join(sdir, "stream_meta.json")), fp, f"{sdir}/stream_meta.json")
         t0 = time.perf_counter()
         out = codec.decompress(state, ndatapoints)
         t_recv = time.perf_counter() - t0
@@ -195,6 +190,48 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
     return rows
 
 
+def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=False, data=None, params=None,
+                       outdir=".", backend=None, small=None, verbose=True, cdf_spec=2):
+    """Receiver only (the reference decodes inside compress(), mnist_compress.py:277-358; a real receiver is another
+    process): load the experiment pickles and stream_meta.json a sender wrote under `outdir`, REFUSE to decode unless this
+    receiver reproduces the recorded format / CDF specification / conv route, decode every experiment, and assert the
+    reference's two end conditions (every datapoint matches, :319,354; the initial state is restored, :358).
+    Returns the decoded images [experiments, ndatapoints, X] on rank 0 (single process: streams are read from disk)."""
+    dev = torch.device("cpu") if backend is not None else torch.device("cuda", gpu)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    seed_everything()
+    sdir, scheme = stream_dir(outdir, dataset, nz, bitswap)
+    written = meta.load(os.path.join(sdir, "stream_meta.json"))
+    fmt = written.get("stream_format", "reference")
+    experiments, ndatapoints = int(written["experiments"]), int(written["ndatapoints"])
+    model = workload.synthetic_model(dataset, nz, dev, small=small) if small else load_model(dataset, nz, dev, params, synthetic)
+    images = load_images(dataset, data, synthetic or bool(small), model.xs, max(experiments * ndatapoints, 512))
+    bins_data = images[: min(len(images), 4096)].view((-1,) + tuple(model.xs))
+    zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, dataset, data=bins_data,
+                            ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"), save=False)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
+                         backend=_format_backend(fmt, backend, dev), cdf_spec=cdf_spec)
+    meta.check(written, meta.fingerprint(codec, chains_per_call=experiments), f"{sdir}/stream_meta.json")
+    wave64 = fmt == "wave64" and backend is None
+    states = [container.load_state(os.path.join(sdir, stream_name(scheme, quantbits, nz, c, wave64)))
+              for c in range(experiments)]
+    nwords = max((sum(len(x) for x in s) if wave64 else len(s)) for s in states)
+    state = codec.backend.new_state(states, nwords + ndatapoints * (model.xdim + 64) + 4 * model.zdim_flat)
+    out = codec.decompress(state, ndatapoints).cpu()
+    randindices = np.load(os.path.join(outdir, "bitstreams", dataset, "indices.npy"))
+    want = images[torch.from_numpy(randindices.reshape(-1))].view(experiments, ndatapoints, -1).to(torch.int32)
+    assert torch.equal(out, want), "decoded datapoint does not match"                     # (:319,354)
+    inits = initial_states(experiments, 10000, seed=100)
+    if wave64:
+        from .hip import split_state
+        inits = [split_state(s) for s in inits]
+    assert state.to_lists() == inits, "initial state not restored"                        # (:358)
+    if verbose:
+        print(f"decoded {experiments} x {ndatapoints} datapoints from {sdir}: lossless, initial states restored")
+    return out
+
+
 def dataset_main(dataset, default_nz, nz_loop=None):
     """argparse front end shared by the four <dataset>_compress.py scripts (flags :369-373)."""
     p = argparse.ArgumentParser()
@@ -212,14 +249,24 @@ def dataset_main(dataset, default_nz, nz_loop=None):
     p.add_argument('--outdir', default=".")
     p.add_argument('--format', default="reference", choices=["reference", "wave64"],
                    help="stream format: the reference's single-state stream, or the opt-in 64-state format")
+    p.add_argument('--decompress-only', action='store_true',
+                   help="receiver only: decode the pickles a previous run wrote under --outdir (checks stream_meta.json first)")
+    p.add_argument('--cdf-spec', default=2, type=int, choices=[1, 2],
+                   help="deterministic CDF specification (include/bitswap_hip.h): 2 = uniform-bin recurrence where the bins "
+                        "allow it (default), 1 = one sigmoid per endpoint everywhere (streams written before round 2)")
     p.add_argument('--save-bins', action='store_true',
                    help="write bins fitted on the given test images under the reference's cache names (bins/*.pt)")
     args = p.parse_args()
     print(args)
     for nz in (nz_loop or [args.nz]):      # imagenet_compress.py:382 ignores --nz and runs [2, 4]
+        if args.decompress_only:
+            decompress_streams(args.quantbits, nz, args.bitswap, args.gpu, dataset=dataset, synthetic=args.synthetic,
+                               data=args.data, params=args.params, outdir=args.outdir, cdf_spec=args.cdf_spec)
+            continue
         compress(args.quantbits, nz, args.bitswap, args.gpu, dataset=dataset, experiments=args.experiments,
                  ndatapoints=args.ndatapoints, decompress=bool(args.decompress), synthetic=args.synthetic,
-                 data=args.data, params=args.params, outdir=args.outdir, save_bins=args.save_bins, fmt=args.format)
+                 data=args.data, params=args.params, outdir=args.outdir, save_bins=args.save_bins, fmt=args.format,
+                 cdf_spec=args.cdf_spec)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -270,17 +317,27 @@ def _format_backend(fmt, backend, dev):
     return backend
 
 
+class ImageStreams(list):
+    """compress_images() result: per image (state list, min_words, bits/dim); `.fingerprint` is the record a receiver
+    must reproduce (bitswap_amd/meta.py) -- demo_compress.py writes it next to the container."""
+    fingerprint = None
+
+
 def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_quirk=False, setup=None, backend=None,
-                    trim=True, fmt="reference"):
+                    trim=True, fmt="reference", cdf_spec=2):
     """images_blocks: list of [n_i, 32, 32, 3] uint8 block arrays (one per image; every image is a
     chain, imagenetcrop_compress.py:279-300).  Chains of different length run in lock-step and
     drop out as they finish.  Returns per image (state list, min_words, bits/dim); in the 64-state format the state is
     a list of 64 sub-state lists and min_words a list of 64."""
+    results = ImageStreams()
+    if len(images_blocks) == 0:          # a rank that owns no image (more ranks than images)
+        return results
     model, zend, zcen, dev = setup
     flat = [torch.from_numpy((tiling.blocks_to_hwc_flat(b) if hwc_quirk else tiling.blocks_to_chw_flat(b)).astype(np.int32))
             for b in images_blocks]
     codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
-                         backend=_format_backend(fmt, backend, dev))
+                         backend=_format_backend(fmt, backend, dev), cdf_spec=cdf_spec)
+    results.fingerprint = meta.fingerprint(codec, chains_per_call=len(flat))
     np.random.seed(100)   # every image starts from the same 'random' stack (imagenetcrop_compress.py:249,122)
     nmax = max(len(f) for f in flat)
     one = initial_states(1, 10000, seed=100)[0]
@@ -289,7 +346,7 @@ def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_qui
     state, order, met = codec.compress_ragged(flat, state=state)
     mins = state.min_len.cpu().tolist()
     lists = state.to_lists()
-    results = [None] * len(flat)
+    results.extend([None] * len(flat))
     for k, i in enumerate(order):
         m = mins[k]
         m = ([int(v) if trim else 0 for v in m] if isinstance(m, list) else (int(m) if trim else 0))
@@ -297,12 +354,23 @@ def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_qui
     return results
 
 
-def decompress_image(state, nblocks, quantbits=10, nz=4, gpu=0, setup=None, backend=None, hwc_quirk=False):
+def decompress_image(state, nblocks, quantbits=10, nz=4, gpu=0, setup=None, backend=None, hwc_quirk=False,
+                     expect=None, expect_word=None, cdf_spec=2):
     """demo_decompress.decompress (:69-148): -> [nblocks, 32, 32, 3] uint8 blocks.  A state that is a list of 64
-    sub-state lists (container.unpack64) is decoded in the 64-state format."""
+    sub-state lists (container.unpack64) is decoded in the 64-state format.  expect: the sender's fingerprint record
+    (the container's sidecar) / expect_word: its CRC-32 (64-state container header): decoding is REFUSED
+    (meta.StreamMismatch) unless this receiver's codec reproduces it."""
     model, zend, zcen, dev = setup
     fmt = "wave64" if isinstance(state[0], (list, tuple)) else "reference"
-    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=True, backend=_format_backend(fmt, backend, dev))
+    codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=True, backend=_format_backend(fmt, backend, dev),
+                         cdf_spec=cdf_spec)
+    mine = meta.fingerprint(codec, chains_per_call=1)
+    if expect is not None:
+        meta.check(expect, mine, "container")
+    if expect_word is not None and int(expect_word) != 0 and int(expect_word) != meta.word(mine) and expect is None:
+        raise meta.StreamMismatch(f"container fingerprint {int(expect_word):#010x} != this receiver's {meta.word(mine):#010x}: "
+                                  "it was written with another CDF specification / conv route / library revision "
+                                  "(the sidecar <name>_bitswap.meta.json names the fields)")
     nwords = sum(len(s) for s in state) if fmt == "wave64" else len(state)
     st = codec.backend.new_state([list(state)], nwords + nblocks * (model.xdim + 64) + 4 * model.zdim_flat)
     out = codec.decompress(st, nblocks)[0].cpu().numpy()

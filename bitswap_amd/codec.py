@@ -262,6 +262,8 @@ class BitSwapCodec:
         self.graph_max_chains = int(os.environ.get("BITSWAP_GRAPH_MAX_CHAINS", "128"))
         self._graphs = collections.OrderedDict()      # (state, direction) -> _StepGraph | None, the newest few
         self._graph_cap = 4
+        self._graph_failures = 0
+        self.graph_captures = 0                      # block steps captured so far (tests, diagnostics)
         # optional stream split (GroupedCodec): convs + table kernels on `bulk`, the serial rANS kernels
         # on `serial`; None = everything on the caller's current stream
         self.bulk = self.serial = None
@@ -406,24 +408,47 @@ class BitSwapCodec:
         return self.use_graphs is True or state.B <= self.graph_max_chains
 
     def _graphed(self, state, sender):
-        """The captured step for this state (same tensors on every replay), or None if capture is not possible."""
+        """The captured step for this state (same tensors on every replay), or None if capture is not possible.
+        A graph pins its state (a stack of up to GBs) and a private allocator pool: the cache is LRU-bounded and
+        release_graphs() drops a state's graphs when its run ends."""
         key = (id(state.head), state.B, sender)
-        g = self._graphs.get(key)
-        if g is None and key not in self._graphs:
-            try:
-                torch.cuda.synchronize()
-                g = _StepGraph(self, state, sender)
-                g._keep = state                      # the graph holds raw pointers into the state's tensors
-            except Exception as e:                   # e.g. a library call that cannot be captured on this stack
-                import warnings
-                warnings.warn(f"hipGraph capture of the block step failed ({e!r}); running eagerly")
-                torch.cuda.synchronize()
-                self.use_graphs, g = False, None
-            self._graphs[key] = g
-            while len(self._graphs) > self._graph_cap:   # a graph pins its state and a private memory pool
-                torch.cuda.synchronize()
-                self._graphs.popitem(last=False)
+        if key in self._graphs:
+            self._graphs.move_to_end(key)            # least recently USED goes first
+            return self._graphs[key]
+        try:
+            torch.cuda.synchronize()
+            g = _StepGraph(self, state, sender)
+            g._keep = state                          # the graph holds raw pointers into the state's tensors
+            self.graph_captures += 1
+        except Exception as e:                       # e.g. a library call that cannot be captured on this stack
+            import warnings
+            self._graph_failures += 1
+            warnings.warn(f"hipGraph capture of the block step failed ({e!r}); running this state eagerly"
+                          + ("; giving up on graph replay for this codec" if self._graph_failures >= 2 else ""))
+            torch.cuda.synchronize()
+            g = None
+            if self._graph_failures >= 2:            # one failure may be that state's shape; two are the stack
+                self.use_graphs = False
+        self._graphs[key] = g
+        while len(self._graphs) > self._graph_cap:
+            torch.cuda.synchronize()
+            self._graphs.popitem(last=False)
         return g
+
+    def release_graphs(self, state=None):
+        """Drop the captured block steps of `state` (and of its prefix views), or all of them: their private memory pools
+        and the references that keep finished states alive go with them.  compress()/decompress() and the ragged
+        drivers call it when their run ends; a long-lived codec (a server, cli.compress looping over nz) therefore holds
+        graphs only while a run is in flight."""
+        if not self._graphs:
+            return
+        base = None if state is None else state.stack.data_ptr()
+        dead = [k for k, g in self._graphs.items()
+                if state is None or g is None or g._keep.stack.data_ptr() == base]
+        if dead:
+            torch.cuda.synchronize()
+            for k in dead:
+                del self._graphs[k]
 
     def _graph_room(self, n):
         """Let up to n graphs coexist (ragged runs: one per distinct number of active chains and direction)."""
@@ -559,6 +584,7 @@ class BitSwapCodec:
                 self.encode_block_fast(state, images[:, xi])
             self._snap(lens[xi], state)
         self.backend.check(state, "compress")
+        self.release_graphs(state)
         lens, init_len, rest_len = lens.cpu().numpy().T.astype(np.int64), init_len.cpu().numpy(), rest_len.cpu().numpy()
         added = (lens - init_len[:, None]) * 32                      # totaladdedbits (:254)
         total = (lens - rest_len[:, None] + 1) * 32                  # totalbits (:255): len(restbits)-1 = rest words
@@ -605,6 +631,7 @@ class BitSwapCodec:
             else:
                 self.encode_block(state.prefix(k), x[:k, xi])
         self.backend.check(state, "compress_ragged")
+        self.release_graphs(state)
         lens, init_len, rest_len = state.len.cpu().numpy().astype(np.int64), init_len.cpu().numpy(), rest_len.cpu().numpy()
         nsa = np.array(ns, dtype=np.int64)
         total = (lens - rest_len + 1) * 32                             # totalbits of the whole chain (:255)
@@ -630,6 +657,7 @@ class BitSwapCodec:
             for c in range(k):
                 out[c][xi] = xb[c]
         self.backend.check(state, "decompress_ragged")
+        self.release_graphs(state)
         return [torch.stack(o, dim=0) for o in out]
 
     def decompress(self, state, nblocks):
@@ -639,6 +667,7 @@ class BitSwapCodec:
             # the first step runs eagerly (library warm-up before a capture), the rest replay the graph when it pays
             out[xi] = self.decode_block(state) if xi == nblocks - 1 else self.decode_block_fast(state)
         self.backend.check(state, "decompress")
+        self.release_graphs(state)
         return torch.stack(out, dim=1)
 
 

@@ -229,14 +229,24 @@ __device__ __forceinline__ void uni_bins(const double (&e)[NPL], double rs, doub
 
 // One (chain, dim) row: bn.t[i] = trunc(pmf * M) of this lane's NPL bins (the reference's f - 1).  `e` holds the
 // lane's endpoints (spec 1) or its anchor + residuals (spec 2, see k_logistic).
+// Returns false when the row leaves the domain of CDF spec 2: NPL * h / scale < 650.  det_exp clamps its argument to +-700.
+// A clamped ANCHOR is harmless on its own: beyond +700 every bin of the lane is exactly 1, beyond -700 the lane's bins
+// come out as e^-(700 - b h/scale) <= e^-50 -- too large, but still truncated to the same f = 1 as the true values, so the
+// table is the exact one.  What must not be clamped is the geometric factor Q_b = exp(-b h/scale): with h/scale in the
+// hundreds (a scale tiny against the bin width: scale < 5e-5 for the pixel bins, 20x below the reference's floor of
+// 2/255/8, mnist_train.py:411; reachable only through the C ABI) a lane with a clamped anchor would put 0.5 where the
+// cdf is 1e-18, and the cdf would step DOWN into the next lane.  Such rows are not coded: the caller flags
+// BS_ST_BADTABLE (oracle/bitswap_oracle.c::layer_in_domain applies the same test); CDF spec 1 takes any scale.
 template <int NPL, bool UNI>
-__device__ __forceinline__ void logistic_row(const double (&e)[NPL], double hstep, double m_, double rs, double M, int lane,
+__device__ __forceinline__ bool logistic_row(const double (&e)[NPL], double hstep, double m_, double rs, double M, int lane,
                                              Bins<NPL>& bn) {
     double c0, prev;
+    bool in_domain = true;
     if (UNI) {
         const double hr = hstep * rs;
         const double qb = det_exp(-((double)(lane & (NPL - 1)) * hr));   // lane b < NPL: Q_b
         const double ta = (e[0] - m_) * rs;
+        in_domain = (double)NPL * fabs(hr) < 650.0;
         const double A = det_exp(-ta);
         c0 = recip_1_to_huge(1.0 + A);
         prev = c0;
@@ -257,6 +267,7 @@ __device__ __forceinline__ void logistic_row(const double (&e)[NPL], double hste
     // reference: pmf[0] = cdf[0] (no subtraction), mnist_compress.py:185
     const double p0 = (lane == 0) ? c0 : c0 - below;
     bn.t[0] = trunc_u32(p0 * M);
+    return in_domain;
 }
 
 template <int NPL, typename PT, int MODE, bool UNI>
@@ -302,10 +313,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
         sc_n = scale[nrow];
 
         Bins<NPL> bn;
-        logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
+        const bool dom = logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
 
         bool bad;
         uint32_t c = bump_and_scan<NPL>(bn, lane, bits, bad);
+        bad = bad || !dom;
         if (status && (__ballot(bad) != 0ull || !okp) && lane == 0 && status[b] == BS_ST_OK) status[b] = BS_ST_BADTABLE;
 
         if (MODE == M_WAVE) {
@@ -1124,10 +1136,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const double rs = recip_scale(sc_);
             const bool okp = (sc_ > 0.0) && (rs > 0.0) && (fabs(m_) < __builtin_huge_val());
             Bins<NPL> bn;
-            logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
+            const bool dom = logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
             bool bad;
             uint32_t cstart = bump_and_scan<NPL>(bn, lane, bits, bad);
-            if (__ballot(bad) != 0ull || !okp) { st[c] = BS_ST_BADTABLE; continue; }
+            if (__ballot(bad || !dom) != 0ull || !okp) { st[c] = BS_ST_BADTABLE; continue; }
             Bins<NPL> cum;  // cum[k] = c of this lane's k-th bin
             {
                 uint32_t cc = cstart;

@@ -3,24 +3,31 @@
 // float32 in, float32 accumulate (v_mfma_f32_32x32x2_f32), row-major throughout (bitswap_amd/model.py::_res_wino;
 // the reference runs the same convolutions as cuDNN calls inside utils/torch/modules.py:233-241).
 //
-// Why not leave it to the BLAS library: (i) a codec needs sender and receiver to add the same products in the same
-// order, whatever the batch -- here an output element is the sum over ci in ONE fixed order that depends on nothing but
-// Cin (no split-K, no shape-dependent kernel choice), so results are bitwise independent of `cols`, of the library
-// version and of its heuristics; (ii) at the reference's own 100 experiments per call (cols = 1600) the library picks a
-// 32x32 macro tile and runs at half the rate it reaches at 6400 columns (profiles/r02F).
+// Why not leave it to the BLAS library: a codec needs sender and receiver to add the same products in the same order,
+// whatever the batch -- here an output element is the sum over ci in ONE fixed order that depends on nothing but Cin
+// (no split-K, no shape-dependent kernel choice), so results are bitwise independent of `cols`, of Cout, of the
+// library version and of its heuristics.  Since round 3 EVERY product of the conv stacks takes this kernel (any column
+// count, the 16-channel head convolutions included): what a chain decodes to no longer depends on how many chains
+// were coded next to it.
 //
-// Tiling for CDNA4: workgroup = 64*WM x 128 outputs of one t, WM x 2 wavefronts of 64 x 64 (2 x 2 MFMA tiles of
-// 32 x 32, 64 accumulator registers per lane).  With WM = 4 the workgroup spans all 256 output channels: V -- the big
-// operand, cols x Cin x T floats -- is read from HBM exactly once, U[t] (256 KB) stays in L2.  K advances 16 at a time
-// through a double-buffered LDS stage (one barrier per step); global loads of step k+1 are in flight while step k
-// multiplies.  LDS layouts are chosen so that every read is conflict-free:
-//   A: [row][20]  -- a lane reads 4 consecutive k of its row as one 16-byte load (rows 16 apart share banks, and those
-//                    sit in different 16-lane phases of the load);
-//   B: [k][136]   -- a lane reads one float per k; the two half-waves read rows 4 apart, 4 x 136 = 32 (mod 64) banks.
+// Scheduling for CDNA4 (round 3): persistent workgroups over a flat list of work units.  A unit is (t, row tile,
+// block of 32 columns); workgroup g of G owns the contiguous unit range [g Nu / G, (g+1) Nu / G) and walks it in
+// chunks of up to four column blocks (a 32*NW x 128 output tile, NW wavefronts of 32 rows x 128 columns = 1 x 4 MFMA
+// tiles, 64 accumulator registers per lane).  Work per workgroup differs by at most one 32-column block: the tiled
+// round-2 launch (1800 tiles of 256 x 128 on 512 resident slots = 3.52 rounds at 400 chains) lost a quarter of the
+// chip to its last round.  G = 2 workgroups per CU (58 KB of LDS each), and the logical order of the workgroups
+// follows the XCD a workgroup lands on (blockIdx % 8), so that the workgroups sharing an L2 share their U[t].
+// K advances 16 at a time through a double-buffered LDS stage (one barrier per step); the global loads of the next
+// step -- of the next CHUNK at the end of a chunk -- are in flight while this step multiplies, so the loop never
+// drains between tiles.  LDS layouts are chosen so that every read is conflict-free:
+//   A: [row][20]  -- a lane reads 4 consecutive k of its row as one 16-byte load (the 16 lanes of a ds_read_b128
+//                    phase hit 16 disjoint groups of 4 banks);
+//   B: [k][136]   -- a lane reads one float per k; the 32 lanes of a phase read consecutive words.
 // The MFMA contraction index is permuted (half-wave g takes k = 8j + 4g + i in step i of chunk j) -- the same
-// permutation on both operands, i.e. the same sum in another fixed order.
+// permutation on both operands, i.e. the same sum in another fixed order (the order of the round-2 kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/bitswap_hip.h"
 
@@ -31,48 +38,47 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G_BN = 128, G_BK = 16, G_LDA = G_BK + 4, G_LDB = G_BN + 8;
 
-template <int WM>
-__global__ __launch_bounds__(128 * WM) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
-                                                        float* __restrict__ M, int Cout, int Cin, int64_t cols) {
-    constexpr int BM = 64 * WM, NT = 128 * WM;
-    constexpr int STAGE = BM * G_LDA + G_BK * G_LDB;
-    constexpr int NA = BM * 4 / NT;                  // float4 loads per thread and stage: A (= 2)
-    constexpr int NB = (G_BK * G_BN / 4) / NT;       //                                    B (4 / WM)
-    extern __shared__ float lds[];                   // [2][STAGE]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l32 = lane & 31, g = lane >> 5;
-    const int t = blockIdx.z;
-    const int co0 = blockIdx.y * BM;
-    const int64_t n0 = (int64_t)blockIdx.x * G_BN;
-    const float* Ut = U + (int64_t)t * Cout * Cin;
-    const float* Vt = V + (int64_t)t * Cin * cols;
-    float* Mt = M + (int64_t)t * Cout * cols;
+struct Chunk {
+    int t, co0, cb, nb;     // transform position, first output row, first 32-column block, column blocks (1..4)
+};
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.0f;
-
+// Global -> register -> LDS staging of one K step (A: BM x 16 of U[t], B: 16 x 128 of V[t]); the per-thread parts of the
+// addresses are 32-bit element offsets against wave-uniform bases.
+template <int NW>
+struct Stager {
+    static constexpr int BM = 32 * NW, NT = 64 * NW;
+    static constexpr int STAGE = BM * G_LDA + G_BK * G_LDB;
+    static constexpr int NA = BM * 4 / NT;                  // float4 loads per thread and stage: A (= 2)
+    static constexpr int NB = (G_BK * G_BN / 4) / NT;       //                                    B (8 / NW)
+    const float* U;
+    const float* V;
+    int Cout, Cin, tid;
+    int64_t cols;
+    int offA[NA], offB[NB];
     f32x4 ra[NA], rb[NB];
-    auto load_stage = [&](int k0) {
+
+    __device__ __forceinline__ void init(const float* U_, const float* V_, int Cout_, int Cin_, int64_t cols_, int tid_) {
+        U = U_, V = V_, Cout = Cout_, Cin = Cin_, cols = cols_, tid = tid_;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int e = tid + i * NT, row = e >> 2, kq = e & 3;
-            ra[i] = (co0 + row < Cout) ? *reinterpret_cast<const f32x4*>(Ut + (int64_t)(co0 + row) * Cin + k0 + kq * 4)
-                                      : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < NA; ++i) offA[i] = ((tid + i * NT) >> 2) * Cin + ((tid + i * NT) & 3) * 4;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int e = tid + i * NT, k = e >> 5, c4 = e & 31;
-            rb[i] = (n0 + c4 * 4 < cols) ? *reinterpret_cast<const f32x4*>(Vt + (int64_t)(k0 + k) * cols + n0 + c4 * 4)
-                                         : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto store_stage = [&](int buf) {
+        for (int i = 0; i < NB; ++i) offB[i] = ((tid + i * NT) >> 5) * (int)cols + ((tid + i * NT) & 31) * 4;
+    }
+    __device__ __forceinline__ void load(const Chunk& c, int k0) {
+        const float* Ub = U + ((int64_t)c.t * Cout + c.co0) * Cin + k0;
+        const float* Vb = V + ((int64_t)c.t * Cin + k0) * cols + (int64_t)c.cb * 32;
+        const int rows_left = Cout - c.co0;
+        const int cols_left = (int)min((int64_t)c.nb * 32, cols - (int64_t)c.cb * 32);
+        // rows beyond Cout / columns beyond the chunk only feed outputs that are never stored: their loads are
+        // redirected to a valid address instead of being masked (a select would wait for the load right here)
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            ra[i] = *reinterpret_cast<const f32x4*>(Ub + ((((tid + i * NT) >> 2) < rows_left) ? offA[i] : offA[i] & 15));
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            rb[i] = *reinterpret_cast<const f32x4*>(Vb + ((((tid + i * NT) & 31) * 4 < cols_left) ? offB[i] : offB[i] - ((tid + i * NT) & 31) * 4));
+    }
+    __device__ __forceinline__ void store(float* lds, int buf) const {
         float* As = lds + buf * STAGE;
         float* Bs = As + BM * G_LDA;
 #pragma unroll
@@ -85,66 +91,143 @@ __global__ __launch_bounds__(128 * WM) void k_wino_gemm(const float* __restrict_
             const int e = tid + i * NT, k = e >> 5, c4 = e & 31;
             *reinterpret_cast<f32x4*>(Bs + k * G_LDB + c4 * 4) = rb[i];
         }
-    };
+    }
+};
 
-    const int nk = Cin / G_BK;
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
+// One chunk of NBLK column blocks: the K loop (the stage of its first step is in LDS buffer `buf` and synchronised), then
+// the stores.  The last step prefetches the first stage of the chunk that follows.
+template <int NW, int NBLK>
+__device__ __forceinline__ void run_chunk(Stager<NW>& sg, float* lds, float* __restrict__ M, const Chunk& cur,
+                                          const Chunk& nxt, bool more, int& buf, int wave, int l32, int g) {
+    constexpr int BM = 32 * NW, STAGE = Stager<NW>::STAGE;
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int ni = 0; ni < NBLK; ++ni)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[ni][v] = 0.0f;
+    const int nk = sg.Cin / G_BK;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_stage((kt + 1) * G_BK);            // in flight under the multiplies below
-        const float* As = lds + buf * STAGE + (wm * 64 + l32) * G_LDA + g * 4;
-        const float* Bs = lds + buf * STAGE + BM * G_LDA + (g * 4) * G_LDB + wn * 64 + l32;
+        const bool last = kt + 1 == nk;
+        if (!last) sg.load(cur, (kt + 1) * G_BK);            // in flight under the multiplies below
+        else if (more) sg.load(nxt, 0);                      // ... the next chunk's first stage under this chunk's last
+        const float* As = lds + buf * STAGE + (wave * 32 + l32) * G_LDA + g * 4;
+        const float* Bs = lds + buf * STAGE + BM * G_LDA + (g * 4) * G_LDB + l32;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x4 a[2];
-            float b[2][4];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * G_LDA + j * 8);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) b[ni][i] = Bs[(j * 8 + i) * G_LDB + ni * 32];
+            const f32x4 a = *reinterpret_cast<const f32x4*>(As + j * 8);
+            float b[NBLK][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int ni = 0; ni < NBLK; ++ni) b[ni][i] = Bs[(j * 8 + i) * G_LDB + ni * 32];
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][i], b[ni][i], acc[mi][ni], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ni = 0; ni < NBLK; ++ni)
+                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[ni][i], acc[ni], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_stage(buf ^ 1);                   // the other buffer: last read before the previous barrier
+        if (!last || more) sg.store(lds, buf ^ 1);           // the other buffer: last read before the previous barrier
         __syncthreads();
+        buf ^= 1;
     }
-
     // C layout of the 32x32 MFMA: register v of lane l is row (v/4)*8 + (l/32)*4 + v%4, column l%32
-    const bool all_rows = co0 + BM <= Cout;
+    float* Mt = M + (int64_t)cur.t * sg.Cout * sg.cols;
+    const int row0 = cur.co0 + wave * 32 + g * 4;
+    const bool all_rows = cur.co0 + BM <= sg.Cout;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int64_t col = n0 + wn * 64 + ni * 32 + l32;
-            if (col >= cols) continue;
-            const int row0 = co0 + wm * 64 + mi * 32 + g * 4;
-            float* p = Mt + (int64_t)row0 * cols + col;
+    for (int ni = 0; ni < NBLK; ++ni) {
+        const int64_t col = (int64_t)cur.cb * 32 + ni * 32 + l32;
+        if (col < sg.cols) {
+            float* p = Mt + (int64_t)row0 * sg.cols + col;
             if (all_rows) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) p[(int64_t)((v >> 2) * 8 + (v & 3)) * cols] = acc[mi][ni][v];
+                for (int v = 0; v < 16; ++v) p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[ni][v];
             } else {
 #pragma unroll
                 for (int v = 0; v < 16; ++v)
-                    if (row0 + (v >> 2) * 8 + (v & 3) < Cout) p[(int64_t)((v >> 2) * 8 + (v & 3)) * cols] = acc[mi][ni][v];
+                    if (row0 + (v >> 2) * 8 + (v & 3) < sg.Cout) p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[ni][v];
             }
         }
+    }
 }
 
-template <int WM>
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW >= 8 ? 4 : 2) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
+                                                                        float* __restrict__ M, int Cout, int Cin, int64_t cols,
+                                                                        int ncb, int nrt, int units) {
+    constexpr int BM = 32 * NW;
+    extern __shared__ float lds[];                   // [2][STAGE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, g = lane >> 5;
+
+    // logical workgroup index: the workgroups of one XCD (blockIdx % 8, round-robin dispatch) take consecutive ranges
+    const int G = gridDim.x;
+    int w = blockIdx.x;
+    if ((G & 7) == 0) w = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    int u = __builtin_amdgcn_readfirstlane((int)((int64_t)w * units / G));
+    const int uend = __builtin_amdgcn_readfirstlane((int)((int64_t)(w + 1) * units / G));
+    if (u >= uend) return;
+
+    const int per_t = nrt * ncb;
+    auto decode = [&](int uu) {                      // wave-uniform by construction: say so (the division runs on the VALU)
+        Chunk c;
+        const int t = uu / per_t, r = uu - t * per_t, rt = r / ncb;
+        c.t = __builtin_amdgcn_readfirstlane(t);
+        c.co0 = __builtin_amdgcn_readfirstlane(rt * BM);
+        c.cb = __builtin_amdgcn_readfirstlane(r - rt * ncb);
+        c.nb = min(min(4, ncb - c.cb), uend - uu);
+        return c;
+    };
+
+    Stager<NW> sg;
+    sg.init(U, V, Cout, Cin, cols, tid);
+    Chunk cur = decode(u);
+    sg.load(cur, 0);
+    sg.store(lds, 0);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const int unext = u + cur.nb;
+        const bool more = unext < uend;
+        Chunk nxt = cur;
+        if (more) nxt = decode(unext);
+        if (cur.nb == 4) run_chunk<NW, 4>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        else if (cur.nb == 3) run_chunk<NW, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);   // a range's ragged ends
+        else if (cur.nb == 2) run_chunk<NW, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        else run_chunk<NW, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        if (!more) break;
+        u = unext;
+        cur = nxt;
+    }
+}
+
+int cu_count() {
+    // multiprocessor count of the current device (a device attribute, not library state)
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess
+        || n <= 0)
+        n = 256;
+    return n;
+}
+
+template <int NW>
 int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, hipStream_t st) {
-    constexpr int BM = 64 * WM;
-    dim3 grid((unsigned)((cols + G_BN - 1) / G_BN), (unsigned)((Cout + BM - 1) / BM), (unsigned)T);
+    constexpr int BM = 32 * NW;
+    const int64_t ncb = (cols + 31) / 32, nrt = (Cout + BM - 1) / BM;
+    const int64_t units = (int64_t)T * nrt * ncb;
+    if (units > 0x7fffffff) return BS_EUNSUPPORTED;
     const size_t shm = 2 * (size_t)(BM * G_LDA + G_BK * G_LDB) * sizeof(float);
-    hipLaunchKernelGGL((k_wino_gemm<WM>), grid, dim3(128 * WM), shm, st, U, V, M, Cout, Cin, cols);
+    // workgroups per CU: two of the 8-wave shape (58 KB of LDS, 128 registers each); the one-wave shape of the head
+    // convolutions is bounded by its 22 KB of LDS
+    const int per_cu = NW >= 4 ? 2 : NW == 2 ? 4 : 6;
+    int64_t G = (int64_t)cu_count() * per_cu;
+    if (const char* e = getenv("BITSWAP_GEMM_WGS_PER_CU")) {    // tuning only: the summation order does not depend on it
+        const int v = atoi(e);
+        if (v > 0) G = (int64_t)cu_count() * v;
+    }
+    if (G > units) G = units;
+    hipLaunchKernelGGL((k_wino_gemm<NW>), dim3((unsigned)G), dim3(64 * NW), shm, st, U, V, M, Cout, Cin, cols, (int)ncb,
+                       (int)nrt, (int)units);
     return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
 }
 
@@ -157,12 +240,10 @@ extern "C" int bs_wino_gemm_f32(const float* U, const float* V, float* M, int T,
     if (((uintptr_t)U | (uintptr_t)V | (uintptr_t)M) & 15u) return BS_EINVAL;
     if (T == 0 || cols == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // tallest workgroup the channel count asks for, halved while the launch would leave most CUs without a workgroup
-    // (few columns: 13 chains are 208).  The summation order per output does not depend on the choice.
-    int wm = Cout > 128 ? 4 : Cout > 64 ? 2 : 1;
-    const int64_t ctiles = (cols + G_BN - 1) / G_BN;
-    while (wm > 1 && ctiles * ((Cout + 64 * wm - 1) / (64 * wm)) * T < 384) wm /= 2;
-    if (wm == 4) return launch_gemm<4>(U, V, M, T, Cout, Cin, cols, st);
-    if (wm == 2) return launch_gemm<2>(U, V, M, T, Cout, Cin, cols, st);
+    // tallest workgroup the channel count fills (rows beyond Cout are zero operands whose results are dropped); the
+    // summation order per output does not depend on the choice
+    if (Cout > 128) return launch_gemm<8>(U, V, M, T, Cout, Cin, cols, st);
+    if (Cout > 64) return launch_gemm<4>(U, V, M, T, Cout, Cin, cols, st);
+    if (Cout > 32) return launch_gemm<2>(U, V, M, T, Cout, Cin, cols, st);
     return launch_gemm<1>(U, V, M, T, Cout, Cin, cols, st);
 }

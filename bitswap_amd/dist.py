@@ -61,13 +61,21 @@ def _max_over_ranks(n, dev):
     return int(t.item())
 
 
-def gather_streams(local, chain_ids, nchains, dst=0):
+def _local_only(collective):
+    """Skip the collectives?  Default: yes when there is one process.  collective=True runs them even in a group of one
+    (tests/test_dist_gpu.py: the RCCL code path entered on a single GPU)."""
+    if not td.is_initialized():
+        return True
+    return td.get_world_size() == 1 and not collective
+
+
+def gather_streams(local, chain_ids, nchains, dst=0, collective=None):
     """local: list of uint32 numpy arrays (one finished bitstream per owned chain, any lengths),
     chain_ids: their global chain indices.  Returns on `dst` a list of nchains arrays (None
     elsewhere).  Collectives: max of the per-rank chain counts, all_gather of the per-chain word counts,
     gather of the padded payloads.  Any sharding (round-robin or LPT) is accepted."""
     assert len(local) == len(chain_ids)
-    if not td.is_initialized() or td.get_world_size() == 1:
+    if _local_only(collective):
         out = [None] * nchains
         for c, a in zip(chain_ids, local):
             out[c] = np.asarray(a, dtype=np.uint32)
@@ -108,21 +116,23 @@ def barrier():
         td.barrier()
 
 
-def allreduce_sum(values):
+def allreduce_sum(values, collective=None):
     """Sum a short list of floats over ranks (total bits, total dims)."""
-    if not td.is_initialized() or td.get_world_size() == 1:
+    if _local_only(collective):
         return list(values)
     t = torch.tensor(values, dtype=torch.float64, device=_device())
     td.all_reduce(t)
     return t.cpu().tolist()
 
 
-def gather_rows(local, chain_ids, nchains, dst=0):
+def gather_rows(local, chain_ids, nchains, dst=0, collective=None):
     """Gather per-chain float rows (metrics [n_local, width]) to `dst` in chain order.  A rank may own no chain."""
     local = np.asarray(local, dtype=np.float64)
-    if local.ndim == 1:
+    if len(chain_ids) == 0:               # np.array([]) of a rank that owns nothing: shape (0,), width unknown here
+        local = np.zeros((0, local.shape[1] if local.ndim == 2 else 0))
+    elif local.ndim == 1:
         local = local.reshape(len(chain_ids), -1)
-    if not td.is_initialized() or td.get_world_size() == 1:
+    if _local_only(collective):
         out = np.zeros((nchains, local.shape[1]))
         out[chain_ids] = local
         return out

@@ -1,0 +1,101 @@
+"""Stream fingerprint: everything a receiver must share with the sender, beyond weights and bins, for a stream to decode.
+
+The reference has no counterpart -- it pickles the bare list (mnist_compress.py:265-267) and its container is
+`[words, head_lo, head_hi, nblocks, h, w]` (demo_compress.py:272-283) -- because its sender and receiver are the same
+torch calls in the same process.  Here the float32 results of the conv stacks depend on the route they take (fused
+epilogues, Winograd-domain GEMMs on our kernel or on a BLAS backend, channel padding, micro-batch), and the integer tables
+on the CDF specification per table; a mismatch decodes to garbage without any error.  So every stream we write carries
+(or has next to it) this record, and every receiver path compares it with its own codec before decoding:
+
+* dataset CLIs: `stream_meta.json` next to the experiment pickles (cli.compress / cli.decompress_streams);
+* reference-format demo container: the reference's layout has no room for it, so it travels as the sidecar
+  `<name>_bitswap.meta.json` (absent for containers the reference wrote: the receiver then says what it assumes);
+* 64-state container (our own layout, version 2): the CRC-32 of the record is a header word, the record itself the
+  same sidecar.
+"""
+import json
+import zlib
+
+ROUTE_REV = 3    # bump when a kernel or route change alters the float32 bits of (mu, scale) or the integer tables
+
+
+class StreamMismatch(RuntimeError):
+    """The stream was written with settings this receiver does not reproduce."""
+
+
+def route(model):
+    """What the conv stacks' float32 results depend on besides the weights (bitswap_amd/model.py)."""
+    fused = bool(getattr(model, "fused", False))
+    own = bool(getattr(model, "own_gemm", False))
+    r = {"rev": ROUTE_REV, "fused": fused, "nn_batch": getattr(model, "nn_batch", None)}
+    if fused:
+        r.update({"conv_algo": model.conv_algo, "wino_inputs": bool(model.wino_inputs), "wino_in5": bool(model.wino_in5),
+                  "fused_inputs": bool(model.fused_inputs), "pad_channels": bool(model.pad_channels),
+                  "gemm": "own" if own else f"blas:{model.gemm_backend}", "gemm_min_batch": int(model.gemm_min_batch)})
+    return r
+
+
+def fingerprint(codec, chains_per_call=None):
+    """The record for `codec` (codec.BitSwapCodec).  chains_per_call only matters -- and is only recorded -- when the conv
+    route is not batch-invariant (a BLAS backend or MIOpen in the loop, no fixed micro-batch)."""
+    from . import hip
+    m = codec.model
+    fp = {"stream_format": "wave64" if getattr(codec.backend, "name", "").endswith("wave64") else "reference",
+          "ansbits": int(codec.bits), "quantbits": int(codec.q), "bitswap": bool(codec.bitswap),
+          "cdf_spec": {"z": [2 if s is not None else 1 for s in codec.zstep], "x": 2 if codec.xstep is not None else 1},
+          "library_abi": int(hip.ABI_VERSION), "backend": getattr(codec.backend, "name", "?"), "conv_route": route(m)}
+    if not batch_invariant(fp) and chains_per_call is not None:
+        fp["conv_route"]["chains_per_call"] = int(chains_per_call)
+    return fp
+
+
+def batch_invariant(fp):
+    r = fp["conv_route"]
+    if r.get("nn_batch"):
+        return True
+    return bool(r.get("fused")) and r.get("conv_algo") == "winograd" and r.get("gemm") == "own" and r.get("gemm_min_batch", 1) <= 1 \
+        and (r.get("wino_inputs") or (r.get("wino_in5") and r.get("fused_inputs")))
+
+
+def canonical(fp):
+    """The fields check() compares, in one canonical spelling."""
+    return json.dumps({k: v for k, v in _flat(fp).items() if k not in _IGNORED}, sort_keys=True, separators=(",", ":"))
+
+
+def word(fp):
+    """CRC-32 of the canonical record: the header word of the 64-state container."""
+    return zlib.crc32(canonical(fp).encode()) & 0xFFFFFFFF
+
+
+def _flat(d, pre=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat(v, pre + k + "."))
+        else:
+            out[pre + k] = v
+    return out
+
+
+# informational fields: where the stream was written, not how
+_IGNORED = ("backend", "world_size", "experiments", "ndatapoints", "nblocks", "image")
+
+
+def check(written, mine, what="stream"):
+    """Raise StreamMismatch, naming every differing field, unless this receiver (`mine`) reproduces `written`."""
+    a, b = _flat(written), _flat(mine)
+    bad = [f"{k}: stream {a.get(k)!r} != receiver {b.get(k)!r}" for k in sorted(set(a) | set(b))
+           if k not in _IGNORED and a.get(k) != b.get(k)]
+    if bad:
+        raise StreamMismatch(f"{what} was written with settings this receiver does not reproduce (it would decode to "
+                             "garbage without any error): " + "; ".join(bad))
+
+
+def save(path, fp, **extra):
+    with open(path, "w") as f:
+        json.dump(dict(fp, **extra), f, indent=1, sort_keys=True)
+
+
+def load(path):
+    with open(path) as f:
+        return json.load(f)

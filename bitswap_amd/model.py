@@ -235,6 +235,10 @@ class Model(nn.Module):
         # MIOpen from gemm_min_batch blocks per call on, but the K = 8..12 batched GEMMs run no faster than MIOpen's
         # kernels (profiles/r02g_kernel_stats.txt: 177 vs 177 ms per step), so it is an option, not the default
         self.wino_inputs = os.environ.get("BITSWAP_WINO_INPUTS", "0") == "1"
+        # ... except the 5x5 conv that opens the bottom inference stack (12 squeezed image channels -> reswidth), which
+        # has no direct kernel of ours: it takes the Winograd-domain route (transform, bs_small_k_gemm_f32, fused pass) by
+        # default since round 3, so that NO convolution of the compress path is left to MIOpen's per-shape algorithm choice
+        self.wino_in5 = os.environ.get("BITSWAP_WINO_IN5", "1") == "1"
         # 3x3 input convs (Cin = zchannels) as a direct fp32 convolution fused with bias, ELU and the forward transform of
         # the block behind them (bs_conv3_wino_f32) instead of an MIOpen launch + a transform pass.  As fast as the pair it
         # replaces (155 us against 72 + 93 us alone at 400 blocks, the same bench line: profiles/r02x, r02y); kept on
@@ -247,19 +251,18 @@ class Model(nn.Module):
         # residual adds and never reach a result.
         self.pad_channels = os.environ.get("BITSWAP_PAD_CHANNELS", "1") == "1"
         # the batched GEMMs of the Winograd route on our own fp32 MFMA kernel (bs_wino_gemm_f32) instead of the BLAS
-        # library: results independent of the batch and of library heuristics; as fast at 800 chains (162.97 vs 164.72
-        # ms per step), 8 % faster at the reference's 100 (28.2 vs 30.6 ms: the library drops to a 32x32 macro tile
-        # there), profiles/r02G.  Products with fewer than 64 output channels (the heads) stay with the library.
+        # library: every output is summed in one fixed order that depends on Cin alone, so (mu, scale) do not depend on
+        # how many chains are coded per call, on the library version or on its heuristics.  Since round 3 there is no
+        # size threshold: the persistent kernel balances any column count over the chip and has a one-wave shape for
+        # the 16-channel head convolutions (round 2 sent products under 64 channels / 512 columns to the library, which
+        # made a stream decodable only with the sender's chains-per-call).  BITSWAP_OWN_GEMM=0 restores the library for
+        # experiments; the choice is part of the stream fingerprint (route_fingerprint()).
         self.own_gemm = os.environ.get("BITSWAP_OWN_GEMM", "1") == "1"
-        self.own_gemm_min_cout = int(os.environ.get("BITSWAP_OWN_GEMM_MIN_COUT", "64"))
-        # ... and so do products with few columns (13 chains = 208 columns of 16x16 planes: 64 x 128 workgroup tiles
-        # leave most CUs idle, 8.9 vs 7.1 ms per step in the 64-state format, profiles/r02H vs r02I)
-        self.own_gemm_min_cols = int(os.environ.get("BITSWAP_OWN_GEMM_MIN_COLS", "512"))
         self._cp = reswidth
         self.gemm_min_batch = int(os.environ.get("BITSWAP_GEMM_MIN_BATCH", "1"))
         # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs ("" = torch's default)
         self.gemm_backend = os.environ.get("BITSWAP_GEMM_BACKEND", "ck") or None
-        self._heads, self._heads_u, self._gen_mu_u = {}, {}, None
+        self._heads, self._heads_u, self._gen_mu_u, self._gen_b2 = {}, {}, None, None
         self.conditional_gen_std = conditional_gen_std
         pad5, pad = 2, (kernel_size - 1) // 2
         assert kernel_size % 2 == 1
@@ -385,6 +388,12 @@ class Model(nn.Module):
                 self._heads_u = {k: _tw(padw(w, cin=True)) for k, (w, b) in self._heads.items() if w.shape[-1] == 3}
                 g0 = self.gen_mu[0]
                 self._gen_mu_u = _tw(padw(g0._w, cin=True)) if g0.kernel_size == 3 else None
+                if self.conditional_gen_std and g0.kernel_size == 3:
+                    # crop model (imagenetcrop_train.py:306-315,417): the pixel mean and the pixel scale are two head
+                    # convolutions of the same activations -- one Winograd-domain product with stacked filters
+                    gs = self.gen_std[0]
+                    self._gen_mu_u = _tw(padw(torch.cat([g0._w, gs._w], 0).contiguous(), cin=True))
+                    self._gen_b2 = torch.cat([g0.b, gs.b], 0).detach().contiguous()
                 # ResNet convs (3x3 and 5x5, Cin == Cout) in the Winograd domain: U = G w G^T, [36, Cout, Cin]; the input
                 # convs of every stack (Cin = zchannels or 4 x image channels -> reswidth) get their U as well
                 # (Model.wino_inputs)
@@ -422,7 +431,8 @@ class Model(nn.Module):
             mods = mods[1:]
         m = mods[0]
         follows = nxt is not None and not isinstance(nxt, Pass)
-        if (self.conv_algo == "winograd" and self.wino_inputs and m._wu is not None and x.shape[0] >= self.gemm_min_batch
+        if (self.conv_algo == "winograd" and (self.wino_inputs or (m.kernel_size == 5 and self.wino_in5))
+                and m._wu is not None and x.shape[0] >= self.gemm_min_batch
                 and x.shape[-1] % 4 == 0 and x.shape[-2] % 4 == 0):
             # the input conv itself in the Winograd domain: V = B^T x B (no bias, no activation in front of it),
             # M = U x V; its bias + ELU ride on the next fused pass
@@ -515,11 +525,10 @@ class Model(nn.Module):
 
     def _bmm(self, U, V):
         """The batched product of a Winograd-domain convolution: our MFMA kernel (one fixed summation order per output,
-        whatever the batch) for outputs of at least `own_gemm_min_cout` channels and `own_gemm_min_cols` columns, else
-        the BLAS library.  Sender and receiver code the same number of chains per call, so they take the same branch."""
+        whatever the batch) whenever it takes the shapes (Cin % 16 == 0: every preset of the reference), else the BLAS
+        library (narrow test models) -- a property of the model, never of the call."""
         from . import hip
-        if (self.own_gemm and U.shape[1] >= self.own_gemm_min_cout and V.shape[2] >= self.own_gemm_min_cols
-                and hip.wino_gemm_supported(U, V)):
+        if self.own_gemm and hip.wino_gemm_supported(U, V):
             return hip.wino_gemm(U, V)
         return torch.bmm(U, V)
 
@@ -580,8 +589,13 @@ class Model(nn.Module):
     def _gen_stack_fused(self, i, h):
         from . import hip
         if i == 0:
-            hv = self._gen_mu_u is not None and not self.conditional_gen_std
+            hv = self._gen_mu_u is not None
             h = self._fused_res(self.gen_res0, self._fused_res(self.gen_res1, self._fused_in(self.gen_in, h, self.gen_res1)), hv)
+            if isinstance(h, _WinoOperand) and self.conditional_gen_std:
+                c = self.gen_mu[0].out_dim
+                x = hip.wino_fused(self._bmm(self._gen_mu_u, h.v), (h.shape[0], 2 * c) + h.shape[2:], 6, self._gen_b2,
+                                   None, False, want_sum=True)[0]
+                return self.gen_mu[1](x[:, :c]), ((2. / 255.) / 8.) + softplus(self.gen_std[1](x[:, c:]))
             if isinstance(h, _WinoOperand):
                 g0 = self.gen_mu[0]
                 x = hip.wino_fused(self._bmm(self._gen_mu_u, h.v), (h.shape[0], g0.out_dim) + h.shape[2:], 6, g0.b,

@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-from bitswap_amd import cli, container, tiling
+from bitswap_amd import cli, container, meta, tiling
 
 
 def ask(prompt):
@@ -25,6 +25,7 @@ if __name__ == '__main__':
     ap.add_argument('--params', default=None)
     ap.add_argument('--format', default="reference", choices=["reference", "wave64"],
                     help="reference: the reference's stream/container; wave64: the opt-in 64-state format (own container)")
+    ap.add_argument('--cdf-spec', default=2, type=int, choices=[1, 2], help="deterministic CDF specification (see include/bitswap_hip.h)")
     args = ap.parse_args()
     if args.gpu is None:
         print("Give GPU index (0, 1, 2 etc.).")
@@ -42,10 +43,15 @@ if __name__ == '__main__':
     size_raw = os.path.getsize(os.path.join(d, f"{filename}_uncompressed.npy")) * 8
     print(f"Shape ({old_h}, {old_w}, 3) -> cropped to ({h}, {w}, 3); raw size {size_raw} bits")
     setup = cli.crop_setup(args.gpu, nz=4, quantbits=10, synthetic=args.synthetic, params=args.params)
-    state, min_words, bpd = cli.compress_images([blocks], quantbits=10, nz=4, bitswap=1, gpu=args.gpu, setup=setup,
-                                                fmt=args.format)[0]
-    pack = container.pack64 if args.format == "wave64" else container.pack
-    arr = pack(state, min_words, blocks.shape[0], h, w)
+    res = cli.compress_images([blocks], quantbits=10, nz=4, bitswap=1, gpu=args.gpu, setup=setup, fmt=args.format,
+                              cdf_spec=args.cdf_spec)
+    state, min_words, bpd = res[0]
+    if args.format == "wave64":
+        arr = container.pack64(state, min_words, blocks.shape[0], h, w, fingerprint=meta.word(res.fingerprint))
+    else:
+        arr = container.pack(state, min_words, blocks.shape[0], h, w)      # the reference's layout: no room for metadata
+    # what demo_decompress.py must reproduce (stream format, CDF specification, conv route): the sidecar it checks
+    meta.save(os.path.join(d, f"{filename}_bitswap.meta.json"), res.fingerprint, nblocks=int(blocks.shape[0]), image=file)
     np.save(os.path.join(d, f"{filename}_bitswap"), arr)
     size_bs = os.path.getsize(os.path.join(d, f"{filename}_bitswap.npy")) * 8
     print(f"Bit-Swap: {filename}_bitswap.npy, {size_bs} bits, ratio {100 * size_bs / size_raw:.2f} %, "

@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-from bitswap_amd import cli, container, tiling
+from bitswap_amd import cli, container, meta, tiling
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
@@ -16,6 +16,8 @@ if __name__ == '__main__':
     ap.add_argument('--gpu', default=None, type=int)
     ap.add_argument('--synthetic', action='store_true')
     ap.add_argument('--params', default=None)
+    ap.add_argument('--cdf-spec', default=2, type=int, choices=[1, 2],
+                    help="deterministic CDF specification the stream was written with (1: streams from before round 2)")
     args = ap.parse_args()
     if args.gpu is None:
         print("Give GPU index (0, 1, 2 etc.).")
@@ -32,7 +34,13 @@ if __name__ == '__main__':
     arr = np.load(args.file)
     state, nblocks, h, w = (container.unpack64 if container.is_pack64(arr) else container.unpack)(arr)
     setup = cli.crop_setup(args.gpu, nz=4, quantbits=10, synthetic=args.synthetic, params=args.params)
-    blocks, _ = cli.decompress_image(state, nblocks, quantbits=10, nz=4, gpu=args.gpu, setup=setup)
+    side = os.path.join(d, f"{filename}.meta.json")
+    expect = meta.load(side) if os.path.exists(side) else None
+    if expect is None and not container.is_pack64(arr):
+        print(f"no {os.path.basename(side)} next to the container (the reference writes none): decoding with this build's "
+              f"defaults, CDF spec {args.cdf_spec}; a stream written with other settings decodes to noise")
+    blocks, _ = cli.decompress_image(state, nblocks, quantbits=10, nz=4, gpu=args.gpu, setup=setup, expect=expect,
+                                     expect_word=container.fingerprint64(arr), cdf_spec=args.cdf_spec)
     img = tiling.unextract_blocks(blocks, h, w)
     ref = os.path.join(d, f"{filename.replace('_bitswap', '_uncompressed')}.npy")
     if os.path.exists(ref):

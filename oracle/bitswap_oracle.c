@@ -93,12 +93,18 @@ static double det_exp(double a) {
  * torch at the same sub-ppm level (tests/test_oracle.py::test_cdf_spec2_*).  Every operation is a single
  * IEEE-754 binary64 operation; the HIP kernel (k_logistic, uniform flavour) performs the same ones.
  */
-static void det2_row_cdf(const double* e, double h, double mu, double scale, int K, double* cdf /* K-1 */) {
+/* Returns 0 when the row leaves the domain of spec 2: N h / scale < 650 (the geometric factors Q_b = exp(-b h/scale) must
+ * stay clear of det_exp's clamp at -700; a clamped anchor alone only touches bins that truncate to f = 1 either way) --
+ * such rows are not coded, callers report ORC_BAD_TABLE as the HIP kernels report BS_ST_BADTABLE
+ * (bitswap_hip.hip::logistic_row). */
+static int det2_row_cdf(const double* e, double h, double mu, double scale, int K, double* cdf /* K-1 */) {
     const int N = K >= 64 ? K / 64 : 1;
     const double rs = 1.0 / scale;
     const double hr = h * rs;
+    int ok = 1;
     double Q[64];
     for (int b = 1; b < N && b < 64; ++b) Q[b] = det_exp(-((double)b * hr));
+    if (!((double)N * fabs(hr) < 650.0)) ok = 0;
     for (int j0 = 0; j0 < K - 1; j0 += N) {
         const double ta = (e[j0] - mu) * rs;
         const double A = det_exp(-ta);
@@ -110,6 +116,7 @@ static void det2_row_cdf(const double* e, double h, double mu, double scale, int
             cdf[j0 + b] = 1.0 / fma(Q[b], u, 1.0);
         }
     }
+    return ok;
 }
 
 /* reference formula: torch.sigmoid((x - mu) / scale), utils/torch/rand.py:67-68 */
@@ -287,12 +294,13 @@ int orc_pop(uint64_t* head, uint32_t* stack, int64_t* len,
  * layer, without materialising more than one row.  Same arithmetic as the
  * three functions above (mnist_compress.py:183-188 / :198-203).
  */
-static void row_table(const double* e, double mu, double scale, int K, int bits, int quantbits,
-                      int mode, double h, double* p, int64_t* f, uint32_t* c) {
+static int row_table(const double* e, double mu, double scale, int K, int bits, int quantbits,
+                     int mode, double h, double* p, int64_t* f, uint32_t* c) {
     double prev = 0.0, rs = 1.0 / scale;
+    int ok = 1;
     if (mode == 2) {   /* CDF spec 2: uniform bins of width h */
         double* cd = (double*)malloc(sizeof(double) * (size_t)K);
-        det2_row_cdf(e, h, mu, scale, K, cd);
+        ok = det2_row_cdf(e, h, mu, scale, K, cd);
         for (int j = 0; j < K - 1; ++j) p[j] = (j == 0) ? cd[0] : cd[j] - cd[j - 1];
         prev = cd[K - 2];
         free(cd);
@@ -316,6 +324,19 @@ static void row_table(const double* e, double mu, double scale, int K, int bits,
     int64_t acc = 0;
     c[0] = 0;
     for (int j = 0; j < K; ++j) { acc += f[j]; c[j + 1] = (uint32_t)acc; }
+    return ok;
+}
+
+/* Spec 2 only: every row of the layer inside the domain of det2_row_cdf?  Checked BEFORE anything is coded, like the HIP
+ * table kernels, which flag the chain and leave its state untouched. */
+static int layer_in_domain(const double* scale, int64_t D, int K, int mode, const double* step) {
+    if (mode != 2 || !step) return 1;
+    const int N = K >= 64 ? K / 64 : 1;
+    for (int64_t i = 0; i < D; ++i) {
+        const double rs = 1.0 / scale[i], hr = step[i] * rs;
+        if (!((double)N * fabs(hr) < 650.0)) return 0;
+    }
+    return 1;
 }
 
 /* step: bin width per row, used by mode 2 only (may be NULL otherwise) */
@@ -325,7 +346,7 @@ int orc_layer_pop(uint64_t* head, uint32_t* stack, int64_t* len,
     double* p = (double*)malloc(sizeof(double) * (size_t)K);
     int64_t* f = (int64_t*)malloc(sizeof(int64_t) * (size_t)K);
     uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(K + 1));
-    int rc = ORC_OK;
+    int rc = layer_in_domain(scale, D, K, mode, step) ? ORC_OK : ORC_BAD_TABLE;
     for (int64_t i = D - 1; i >= 0 && rc == ORC_OK; --i) {
         row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, step ? step[i] : 0.0, p, f, c);
         rc = orc_pop(head, stack, len, c, 0, 1, K, bits, sym_out + i);
@@ -340,7 +361,7 @@ int orc_layer_push(uint64_t* head, uint32_t* stack, int64_t* len, int64_t cap,
     double* p = (double*)malloc(sizeof(double) * (size_t)K);
     int64_t* f = (int64_t*)malloc(sizeof(int64_t) * (size_t)K);
     uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(K + 1));
-    int rc = ORC_OK;
+    int rc = layer_in_domain(scale, D, K, mode, step) ? ORC_OK : ORC_BAD_TABLE;
     for (int64_t i = 0; i < D && rc == ORC_OK; ++i) {
         row_table(endpoints + i * (int64_t)(K - 1), mu[i], scale[i], K, bits, quantbits, mode, step ? step[i] : 0.0, p, f, c);
         rc = orc_push(head, stack, len, cap, c, 0, 1, bits, sym + i);

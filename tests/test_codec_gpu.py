@@ -319,26 +319,30 @@ class _Count:
         setattr(self.hip, self.name, self.orig)
 
 
-@pytest.mark.parametrize("name,bitswap", [("cifar8", 1), ("imagenet4", 1), ("imagenet4", 0)])
-def test_full_width_oracle_word_parity(name, bitswap):
-    """BASELINE configs 2, 3 and 5 at FULL model width (reswidth 252 / 254, Z = 2048, X = 3072, K = 1024 / 256) with
-    enough chains per call (26 >= gemm_min_batch) that the conv stacks take the route the bench takes -- Winograd-domain
-    batched GEMMs -- and the production kernel pair (k_logistic wave layout, CDF spec 2 + k_rans_pop_wave +
-    systolic push): the oracle replays the schedule on the CPU with the GPU's conv outputs and must produce the very
-    same words (mnist_compress.py:176-251); then the GPU receiver returns the blocks and unwinds every chain."""
+@pytest.mark.parametrize("name,bitswap,n", [("cifar8", 1, 1), ("imagenet4", 1, 2), ("imagenet4", 0, 1)])
+def test_full_width_oracle_word_parity(name, bitswap, n):
+    """BASELINE configs 2, 3 and 5 at FULL model width (reswidth 252 / 254, Z = 2048, X = 3072, K = 1024 / 256) on the
+    route the bench takes: 32 chains per call, every convolution of the stacks in the Winograd domain on OUR fp32 MFMA
+    GEMM (asserted: bs_wino_gemm_f32 is called, the BLAS library is not), and the production kernel pair (k_logistic wave
+    layout, CDF spec 2 + k_rans_pop_wave + systolic push).  The oracle replays the schedule on the CPU with the GPU's conv
+    outputs and must produce the very same words (mnist_compress.py:176-251); then the GPU receiver returns the blocks
+    and unwinds every chain.  The imagenet4 Bit-Swap case is TWO blocks deep: the second block renormalises into the
+    words the first one pushed above the initial 10,000 (VERDICT r2 weak #2)."""
     model, zend, zcen = workload.build(name, DEV, quantbits=10)
-    B, n = 26, 1
-    assert model.fused and model.conv_algo == "winograd" and B >= model.gemm_min_batch
+    B = 32
+    assert model.fused and model.conv_algo == "winograd" and B >= model.gemm_min_batch and model.own_gemm
     images = workload.synthetic_blocks(B * n, model.xs, seed=17).view(B, n, -1).to(torch.int32)
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap))
     assert codec.cdf_spec == 2 and all(s is not None for s in codec.zstep[:-1]) and codec.zstep[-1] is None
     from bitswap_amd import hip
     assert codec.backend.table_layout(codec.K) == hip.LAYOUT_WAVE
     rec, plain_net = record_nets(codec)
-    with _Count("wino_fused") as wf:
+    with _Count("wino_fused") as wf, _Count("wino_gemm") as wg, _NoBlas() as nb:
         state, met = codec.compress(images.to(DEV))
-    assert wf.n > 0, "the Winograd-domain conv route was not taken"
+    assert wf.n > 0 and wg.n > 0, "the Winograd-domain conv route / the own GEMM was not taken"
+    assert nb.n == 0, f"{nb.n} library GEMM / conv call(s) inside the compress path: the route would depend on the batch"
     sent = state.to_lists()
+    assert min(len(s) for s in sent) > 10000 - 1 or not bitswap      # Bit-Swap chains grow from the first block on
 
     it = iter(rec)
     oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=bool(bitswap),
@@ -354,32 +358,89 @@ def test_full_width_oracle_word_parity(name, bitswap):
     assert state.to_lists() == initial_states(B)
 
 
-@pytest.mark.parametrize("name", ["cifar8", "imagenet4"])
+class _NoBlas:
+    """Count torch.bmm / F.conv2d calls for the duration of a block: the compress path of a full-width model must not
+    leave anything to a library whose kernel choice depends on the batch."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.n, self.F = 0, F
+        self.orig = (torch.bmm, F.conv2d)
+
+        def count(fn):
+            def wrapped(*a, **k):
+                self.n += 1
+                return fn(*a, **k)
+            return wrapped
+        torch.bmm, F.conv2d = count(torch.bmm), count(F.conv2d)
+        return self
+
+    def __exit__(self, *exc):
+        torch.bmm, self.F.conv2d = self.orig
+
+
+def test_full_width_crop_model_oracle_word_parity():
+    """BASELINE config 4's model at FULL width (imagenetcrop_train.py:306-315,417: reswidth 256, the pixel scale a head
+    convolution) with ragged chains and the fixed conv micro-batch of the crop / demo path (nn_batch 32; 33 chains =
+    one full micro-batch + one padded): HIP words == oracle words with the GPU's conv outputs replayed, the receiver
+    returns every block, every chain unwinds to the shared initial state (imagenetcrop_compress.py:249,279-300)."""
+    model, zend, zcen = workload.build("imagenetcrop4", DEV, quantbits=10, nn_batch=32)
+    assert model.conditional_gen_std and model.fused and model.reswidth == 256
+    lens = [2, 1, 2] + [1] * 30
+    chains = [workload.synthetic_blocks(k, model.xs, seed=300 + i).to(torch.int32) for i, k in enumerate(lens)]
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
+    rec, plain_net = record_nets(codec)
+    with _Count("wino_gemm") as wg, _NoBlas() as nb:
+        state, order, met = codec.compress_ragged(chains)
+    assert wg.n > 0 and nb.n == 0
+    sent = state.to_lists()
+
+    it = iter(rec)
+    oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=True, backend=OracleBackend(O.MODE_DET, threads=16))
+    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    ostate, oorder, omet = oc.compress_ragged(chains)
+    assert oorder == order and ostate.to_lists() == sent
+    assert np.array_equal(omet["total"], met["total"]) and np.array_equal(omet["rest_len"], met["rest_len"])
+
+    codec._net = plain_net
+    out = codec.decompress_ragged(state, met["nblocks"])
+    for k, i in enumerate(order):
+        assert torch.equal(out[k].cpu(), chains[i])
+    assert state.to_lists() == [initial_states(1)[0]] * len(lens)
+
+
+@pytest.mark.parametrize("name", ["cifar8", "imagenet4", "imagenetcrop4"])
 def test_full_width_winograd_matches_torch_modules(name):
-    """The conv route of the bench (fused epilogues + Winograd-domain batched GEMMs at full width, 26 blocks per
-    call) against the plain torch modules of the same Model (MIOpen direct convolutions, separate pointwise ops):
-    every infer(i) / generate(i) output within 5e-4 of the output range, bitwise repeatable."""
+    """The conv route of the bench (fused epilogues + Winograd-domain batched GEMMs on bs_wino_gemm_f32 at full width,
+    32 blocks per call = 512 columns) against the plain torch modules of the same Model (MIOpen direct convolutions,
+    separate pointwise ops): every infer(i) / generate(i) output within 5e-4 of the output range, bitwise repeatable, and
+    bitwise independent of the number of blocks per call (a prefix of the batch reproduces its rows)."""
     model, _, _ = workload.build(name, DEV, quantbits=6)
     model.compress(True)
     g = torch.Generator().manual_seed(1)
-    N = 26
+    N = 32
     worst = 0.0
-    with torch.no_grad(), _Count("wino_fused") as wf:
+    with torch.no_grad(), _Count("wino_fused") as wf, _Count("wino_gemm") as wg:
         for i in range(model.nz):
             x = (torch.randint(0, 256, (N, model.xdim), generator=g).float() - 127.5) / 127.5
             zin = torch.randn((N, model.zdim_flat), generator=g)
             for fn, inp in ((model.infer(i), (x if i == 0 else zin).to(DEV)), (model.generate(i), zin.to(DEV))):
                 model.fused = True
-                mu_f, sc_f = fn(inp)
+                with _NoBlas() as nb:
+                    mu_f, sc_f = fn(inp)
+                assert nb.n == 0, "a library GEMM / conv inside the fused compress path"
                 mu_f2, sc_f2 = fn(inp)
+                mu_p, sc_p = fn(inp[:5])                       # 5 blocks per call instead of 32
                 model.fused = False
                 mu_t, sc_t = fn(inp)
                 model.fused = True
                 assert torch.equal(mu_f, mu_f2) and torch.equal(sc_f, sc_f2)
+                assert torch.equal(mu_p, mu_f[:5]) and torch.equal(sc_p.expand_as(mu_p), sc_f.expand_as(mu_f)[:5]), \
+                    "(mu, scale) depend on the number of blocks per call"
                 for a, b in ((mu_f, mu_t), (sc_f, sc_t.expand_as(sc_f))):
                     rng = float(b.abs().max()) + 1e-6
                     worst = max(worst, float((a - b).abs().max()) / rng)
-    assert wf.n > 0
+    assert wf.n > 0 and wg.n > 0
     print(f"full-width {name}: max |fused - torch| / range = {worst:.2e}")
     assert worst < 5e-4, worst
 
@@ -638,10 +699,11 @@ def test_block_step_graph_equals_eager(fmt, bitswap):
     graphed.use_graphs = True
     s1, m1 = eager.compress(images)
     s2, m2 = graphed.compress(images)
-    assert any(g is not None for g in graphed._graphs.values()), "the block step was not captured"
+    assert graphed.graph_captures == 1, "the block step was not captured"
+    assert not graphed._graphs, "a finished run must not leave graphs (and the state they pin) behind"
     assert s1.to_lists() == s2.to_lists() and np.array_equal(m1["cma"], m2["cma"])
     out = graphed.decompress(s2, n)
-    assert sum(g is not None for g in graphed._graphs.values()) == 2
+    assert graphed.graph_captures == 2 and not graphed._graphs
     assert torch.equal(out, images)
     init = initial_states(B)
     if fmt == "wave64":
@@ -668,7 +730,7 @@ def test_ragged_chains_with_graph_replay():
             state, order, met = codec.compress_ragged(chains)
             res[graphs] = (state.to_lists(), met["total"].copy())
             if graphs:
-                assert sum(g is not None for g in codec._graphs.values()) >= 2
+                assert codec.graph_captures >= 2 and not codec._graphs
                 out = codec.decompress_ragged(state, met["nblocks"])
                 for k, i in enumerate(order):
                     assert torch.equal(out[k].cpu(), chains[i])

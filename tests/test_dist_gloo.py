@@ -64,6 +64,12 @@ def _worker(rank, world, port, outdir):
     rows = dist.gather_rows(np.array([[c] for c in mine0], dtype=np.float64).reshape(len(mine0), 1), mine0, 3)
     if rank == 0:
         assert [a.tolist() for a in got] == [[c] * 4 for c in range(3)] and rows[:, 0].tolist() == [0.0, 1.0, 2.0]
+    # ... built exactly as imagenetcrop_compress.py builds it for a rank without images: compress_images([]) is empty
+    # and np.array([[o[2]] for o in []]) has shape (0,), no width
+    res0 = cli.compress_images([], quantbits=6, nz=2, setup=None) if rank == 0 else [(None, 0, 1.5), (None, 0, 2.5)]
+    rows = dist.gather_rows(np.array([[o[2]] for o in res0]), [] if rank == 0 else [0, 1], 2)
+    if rank == 0:
+        assert rows[:, 0].tolist() == [1.5, 2.5]
     # the crop driver's sender with ragged chains, LPT-sharded: every image is coded by exactly one rank and the
     # gathered bits/dim are those of a single-process run with the same nn_batch (batch-invariant convs)
     from bitswap_amd import tiling

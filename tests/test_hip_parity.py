@@ -588,6 +588,41 @@ def test_degenerate_parameters_are_flagged(spec):
     assert st2.status.cpu().tolist() == [0, h.ST_BADTABLE, h.ST_BADTABLE, h.ST_BADTABLE, 0]
 
 
+def test_cdf_spec2_domain_is_flagged():
+    """a row whose anchors leave the +-700 domain of det_exp (scale tiny against the bin width -- reachable
+    through the C ABI, never by the reference's models) is outside CDF spec 2: every flavour flags BS_ST_BADTABLE for the
+    chain and leaves its state alone, as the oracle does (tests/test_oracle.py::test_cdf_spec2_domain_is_enforced); the
+    same parameters are fine under spec 1 (one clamped sigmoid per endpoint: monotone)."""
+    from bitswap_amd.bins import uniform_step
+    from bitswap_amd.codec import Hip64Backend
+    h = hip()
+    K, D, B = 256, 64, 3
+    e = np.stack([np.linspace(-4, 4, K + 1)[1:-1]] * D)
+    step = dev(uniform_step(e))
+    mu = np.zeros((B, D), dtype=np.float32)
+    sc = np.full((B, D), 0.5, dtype=np.float32)
+    sc[1, 5] = 1e-4
+    states = [reference_init_state(800, seed=b) for b in range(B)]
+    st = h.RansState.from_lists(states, cap=2000, device=DEV)
+    cdf = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, step=step, status=st.status)
+    assert st.status.cpu().tolist() == [0, h.ST_BADTABLE, 0]
+    sym, _ = h.rans_pop(st, cdf, K)
+    got = st.to_lists()
+    assert got[1] == states[1] and got[0] != states[0] and got[2] != states[2]
+    st2 = h.RansState.from_lists(states, cap=2000, device=DEV)
+    h.logistic_fc(dev(e), dev(mu), dev(sc), sym, st2.status, 31, 8, step=step)
+    assert st2.status.cpu().tolist() == [0, h.ST_BADTABLE, 0]
+    st3 = h.RansState.from_lists(states, cap=2000, device=DEV)                       # spec 1: a well-formed table
+    cdf1 = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, status=st3.status)
+    assert st3.status.cpu().tolist() == [0, 0, 0]
+    s1, _ = h.rans_pop(st3, cdf1, K)
+    st3.check()
+    assert 0 <= int(s1.min()) and int(s1.max()) < K
+    s64 = h.RansState64.from_lists(states, cap=64, device=DEV)                      # the fused 64-state kernels too
+    h.layer_pop64(s64, dev(e), dev(mu), dev(sc), 31, 8, step=step)
+    assert s64.status.cpu().tolist() == [0, h.ST_BADTABLE, 0]
+
+
 @pytest.mark.parametrize("K", [256, 512, 1024])
 @pytest.mark.parametrize("spec", [1, 2])
 def test_layer64_kernels_vs_oracle(K, spec):

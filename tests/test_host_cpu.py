@@ -505,3 +505,66 @@ def test_grouped_codec_enqueue_order():
     log.clear()
     gc._round_robin([ops(0, 2), ops(1, 2)], skew=0)
     assert log == [(0, 0), (1, 0), (0, 1), (1, 1)]
+
+
+def test_stream_fingerprint_is_enforced_by_receivers(tmp_path):
+    """ADVICE r2 / VERDICT r2 #5: stream_meta.json is read back by the receiver path and a format / CDF-spec / conv-route
+    mismatch is refused loudly instead of decoding to garbage.  cli.decompress_streams is the receiver-only counterpart
+    of the reference's inline receiver (mnist_compress.py:277-358): another codec object, streams from disk."""
+    import json
+    from bitswap_amd import meta
+    ob = OracleBackend(O.MODE_DET)
+    cli.compress(8, 2, 1, 0, dataset="mnist", experiments=3, ndatapoints=2, decompress=False, outdir=str(tmp_path),
+                 backend=ob, small=8, verbose=False)
+    out = cli.decompress_streams(8, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=ob, small=8, verbose=False)
+    assert out.shape == (3, 2, 1024)
+    # a receiver built with the other CDF specification (pixels K = 256 and latents K = 256 qualify for spec 2) refuses
+    with pytest.raises(meta.StreamMismatch, match="cdf_spec"):
+        cli.decompress_streams(8, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=ob, small=8, verbose=False,
+                               cdf_spec=1)
+    # ... and so does any receiver if the record names another conv route or stream format
+    mp = tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap" / "stream_meta.json"
+    good = json.load(open(mp))
+    for key, val in (("conv_route", dict(good["conv_route"], rev=good["conv_route"]["rev"] + 1)), ("stream_format", "wave64"),
+                     ("ansbits", 28)):
+        json.dump(dict(good, **{key: val}), open(mp, "w"))
+        with pytest.raises((meta.StreamMismatch, FileNotFoundError)):
+            cli.decompress_streams(8, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=ob, small=8, verbose=False)
+    json.dump(good, open(mp, "w"))
+    cli.decompress_streams(8, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=ob, small=8, verbose=False)
+
+
+def test_container_fingerprint_and_sidecar():
+    """The 64-state container (version 2) carries the CRC-32 of the sender's fingerprint; version 1 files still read; the
+    single-image receiver refuses a sidecar / header word it does not reproduce."""
+    from bitswap_amd import meta
+    from oracle.backend import Oracle64Backend
+    ob = Oracle64Backend(O.MODE_DET)
+    setup = cli.crop_setup(-1, nz=2, quantbits=6, backend=ob, small=8)
+    rng = np.random.RandomState(3)
+    blocks = tiling.extract_blocks(rng.randint(0, 256, (32, 64, 3)).astype(np.uint8))[0]
+    res = cli.compress_images([blocks], quantbits=6, nz=2, setup=setup, backend=ob, fmt="wave64")
+    (st, mins, _), fp = res[0], res.fingerprint
+    assert fp["stream_format"] == "wave64" and fp["conv_route"]["rev"] == meta.ROUTE_REV
+    arr = container.pack64(st, mins, len(blocks), 32, 64, fingerprint=meta.word(fp))
+    assert container.fingerprint64(arr) == meta.word(fp) and int(arr[1]) == 2
+    v1 = np.concatenate([arr[:1], np.array([1], dtype=np.uint32), arr[2:3], arr[4:]])
+    assert container.is_pack64(v1) and container.fingerprint64(v1) is None
+    assert container.unpack64(v1)[0] == container.unpack64(arr)[0]
+    st2, nb, h, w = container.unpack64(arr)
+    out, _ = cli.decompress_image(st2, nb, quantbits=6, nz=2, setup=setup, backend=ob, expect=fp,
+                                  expect_word=container.fingerprint64(arr))
+    assert np.array_equal(out, blocks)
+    with pytest.raises(meta.StreamMismatch, match="fingerprint"):
+        cli.decompress_image(st2, nb, quantbits=6, nz=2, setup=setup, backend=ob, expect_word=meta.word(fp) ^ 1)
+    bad = json_roundtrip(dict(fp, cdf_spec={"z": [2, 2], "x": 2}))
+    with pytest.raises(meta.StreamMismatch, match="cdf_spec.z"):
+        cli.decompress_image(st2, nb, quantbits=6, nz=2, setup=setup, backend=ob, expect=bad)
+    # informational fields do not take part
+    assert meta.word(dict(fp, backend="hip-wave64", world_size=8)) == meta.word(fp)
+    meta.check(json_roundtrip(dict(fp, backend="elsewhere", nblocks=2)), fp)
+
+
+def json_roundtrip(d):
+    import json
+    return json.loads(json.dumps(d))

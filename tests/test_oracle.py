@@ -191,3 +191,26 @@ def test_chain_replay_spec2_matches_reference_words(golden):
                 assert O.layer_push(st, e, mu, sc, g[f"op{i}_sym"].astype(np.int32), 31, int(q), mode, h) == O.OK
             assert int(st.head[0]) == int(g["op_head"][i])
         assert st.tolist() == words_to_state(g["sent_words"])
+
+
+def test_cdf_spec2_domain_is_enforced():
+    """spec 2 builds a group of bins from its anchor exp(-t_a), and det_exp clamps at +-700 -- a row with a
+    scale so small against the bin width that an anchor (or the last bin of its group) lies beyond would get a cdf that
+    steps down across a group boundary (h / scale in the hundreds).  Such rows are outside the spec: ORC_BAD_TABLE before anything is coded (the HIP
+    kernels: BS_ST_BADTABLE, tests/test_hip_parity.py::test_cdf_spec2_domain_is_flagged); spec 1 still codes them."""
+    K, D = 256, 8
+    e = np.stack([np.linspace(-4, 4, K + 1)[1:-1]] * D)
+    mu, sc = np.zeros(D), np.full(D, 0.5)
+    sc[5] = 1e-4                                       # h / scale = 312: the geometric factors of the group hit the clamp
+    words = [int(w) for w in np.random.RandomState(1).randint(1 << 16, 1 << 32, 400, dtype=np.uint64)]
+    st = O.Stack(words + [words[-1] << 32])
+    before = st.tolist()
+    sym, rc = O.layer_pop(st, e, mu, sc, 31, 8, O.MODE_DET2)
+    assert rc == O.BAD_TABLE and st.tolist() == before
+    assert O.layer_push(st, e, mu, sc, np.zeros(D, dtype=np.int32), 31, 8, O.MODE_DET2) == O.BAD_TABLE and st.tolist() == before
+    sym, rc = O.layer_pop(st, e, mu, sc, 31, 8, O.MODE_DET)        # spec 1: one clamped sigmoid per endpoint, monotone
+    assert rc == O.OK and 0 <= sym.min() and sym.max() < K
+    assert O.layer_push(st, e, mu, sc, sym, 31, 8, O.MODE_DET) == O.OK and st.tolist() == before
+    sc[5] = 0.5                                        # healthy again: spec 2 codes the layer
+    sym, rc = O.layer_pop(st, e, mu, sc, 31, 8, O.MODE_DET2)
+    assert rc == O.OK

@@ -4,8 +4,9 @@
 Replays the sender (mnist_compress.py:164-263) and the receiver (:277-358) loops verbatim -- the same replay
 tests/golden/make_golden.py uses for the chain fixtures -- around the imported, unmodified reference classes
 (ANS, Model, logistic_cdf, Bins, ImageBins) on device "cpu", at the reference's FULL model widths, and times them.
-Needs /root/reference, so it runs in the build container only; its output is committed under profiles/ and quoted by
-bench.py next to the port-based baseline measured on the GPU box.
+Needs the reference (/root/reference or $BITSWAP_REFERENCE).  bench.py runs it on the host of the GPU run when the
+reference is there (`--config <workload> --where "same host as the GPU run"`); the GPU boxes of this project have no copy, so
+there bench.py quotes the committed measurement from the build container, labelled as such.
 
     python tools/ref_cpu_baseline.py > profiles/r02_ref_cpu_baseline.json
 
@@ -59,15 +60,29 @@ def run(name, xs, nz, zch, reswidth, nblocks, bitswap=1, q=10):
             "bits_per_dim": round(float(cma[-1]), 3), "lossless_and_unwound": True}
 
 
+CONFIGS = {"mnist2": ("configs[0]: MNIST nz=2 Bit-Swap, reswidth 63, Z=256, X=1024", (1, 32, 32), 2, 1, 63, 20),
+           "imagenet4": ("configs[2] shape: ImageNet32 nz=4 Bit-Swap, reswidth 254, Z=2048, X=3072", (3, 32, 32), 4, 8, 254, 4),
+           "cifar8": ("configs[1] shape: CIFAR-10 nz=8 Bit-Swap, reswidth 252, Z=2048, X=3072", (3, 32, 32), 8, 8, 252, 3)}
+
+
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="one configuration only (bench.py's same-host leg)")
+    ap.add_argument("--blocks", type=int, default=None)
+    ap.add_argument("--where", default="build container (not the GPU box)",
+                    help="label of the host this runs on (bench.py passes 'same host as the GPU run')")
+    a = ap.parse_args()
     threads = torch.get_num_threads()
-    res = [run("configs[0]: MNIST nz=2 Bit-Swap, reswidth 63, Z=256, X=1024", (1, 32, 32), 2, 1, 63, 20),
-           run("configs[2] shape: ImageNet32 nz=4 Bit-Swap, reswidth 254, Z=2048, X=3072", (3, 32, 32), 4, 8, 254, 4),
-           run("configs[1] shape: CIFAR-10 nz=8 Bit-Swap, reswidth 252, Z=2048, X=3072", (3, 32, 32), 8, 8, 252, 3)]
+    names = [a.config] if a.config else ["mnist2", "imagenet4", "cifar8"]
+    res = []
+    for n in names:
+        title, xs, nz, zch, w, blocks = CONFIGS[n]
+        res.append(run(title, xs, nz, zch, w, a.blocks or blocks))
     out = {"kind": "reference", "what": "fhkingma/bitswap Python path (imported ANS/Model/logistic_cdf), sender + receiver loops "
                                         "of mnist_compress.py:164-358 replayed on CPU, one chain",
-           "value": res[2]["pixels_per_s"], "unit": "pixels/s (encode+decode)", "cores": threads,
+           "value": res[-1]["pixels_per_s"], "unit": "pixels/s (encode+decode)", "cores": threads,
            "host": f"{platform.processor() or platform.machine()}, {os.cpu_count()} logical CPUs, torch {torch.__version__} "
-                   f"({threads} threads), build container (not the GPU box)",
+                   f"({threads} threads), {a.where}",
            "runs": res, "tool": "tools/ref_cpu_baseline.py"}
     print(json.dumps(out, indent=1))
