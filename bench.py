@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # issue slots per (chain, dim) row of the K = 1024 decode-flavour kernel, from `tools/isa_count.py` ("largest loop") on
 # the shipped code object: VALU instructions of the per-row loop + 3 extra slots per quarter-rate v_rcp_f64.  Under
-# sustained float64 load the chip runs at about 4/4.9 of the nominal clock (tools/instr_rate.hip), so 0.82 here is the
+# sustained float64 load the chip runs at about 4/4.9 of the nominal clock (tools/probes/instr_rate.hip), so 0.82 here is the
 # practical ceiling
 VALU_SLOTS_PER_ROW = {2: 399, 1: 648}   # CDF spec 2 (uniform bins) / spec 1
 # float64 flops of one row (64 lanes x [2 per fma + 1 per add/mul/rcp] in that loop): SURVEY 8(d) asks for the FP64
@@ -222,14 +222,17 @@ def gemm_roofline(model, chains, dev, reps=20):
         return {"error": repr(e)}
 
 
-def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gather=False, want_roofline=True):
+def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gather=False, want_roofline=True, regime=None):
     """One measurement by the contract's procedure.  Returns a dict (timings are max over ranks)."""
     from bitswap_amd import workload
     from bitswap_amd.codec import GroupedCodec, Timeline, initial_states
 
-    model, zend, zcen = workload.build(name, dev, quantbits=args.quantbits)
+    model, zend, zcen = workload.build(name, dev, quantbits=args.quantbits, regime=regime)
     n = K + W
-    images = workload.synthetic_blocks(B * n, model.xs, seed=1000 + rank).view(B, n, -1).to(torch.int32).to(dev)
+    if regime == "lowrate":      # blocks from the calibrated model's own generative path (workload.lowrate_blocks)
+        images = workload.lowrate_blocks(model, B * n, seed=1000 + rank, batch=400).view(B, n, -1).to(torch.int32).to(dev)
+    else:
+        images = workload.synthetic_blocks(B * n, model.xs, seed=1000 + rank).view(B, n, -1).to(torch.int32).to(dev)
     tl = Timeline(enabled=not args.no_timeline)
     backend = None
     if args.format == "wave64":
@@ -431,22 +434,27 @@ def main(args):
         extra = []
         ks, ws = min(args.steps, 6), min(args.warmup, 1)
         import copy
-        for (wn, ch, gr, fmt) in (("imagenet4", 800, 2, "reference"), ("cifar8", 100, 1, "reference"),
-                                  ("cifar8", 800, 2, "wave64"), ("cifar8", 13, 1, "wave64")):
+        for (wn, ch, gr, fmt, reg) in (("imagenet4", 800, 2, "reference", None), ("cifar8", 100, 1, "reference", None),
+                                       ("cifar8", 800, 2, "reference", "lowrate"),
+                                       ("cifar8", 800, 2, "wave64", None), ("cifar8", 13, 1, "wave64", None)):
             torch.cuda.empty_cache()
             try:
                 a2 = copy.copy(args)
                 a2.format = fmt
-                e = run_workload(a2, wn, ch, gr, ks, max(ws, 2) if fmt == "wave64" else ws, dev, rank, world, dist, want_roofline=False)
+                e = run_workload(a2, wn, ch, gr, ks, max(ws, 2) if fmt == "wave64" else ws, dev, rank, world, dist, want_roofline=False,
+                                 regime=reg)
                 e.pop("codec"), e.pop("model"), e.pop("stream_gather")
                 e["value"], e["ms_per_step"] = round(e["value"], 1), round(e["ms_per_step"], 3)
                 e["bits_per_dim"] = round(e["bits_per_dim"], 4)
                 e["stream_format"] = fmt
+                e["regime"] = reg or "random-init weights, unrelated synthetic blocks"
                 e["config"] = (f"{TITLES[wn]} {'Bit-Swap' if args.bitswap else 'BB-ANS'}, {ch} chains / {gr} group(s)"
+                               + (", calibrated low-rate regime (workload.calibrate_lowrate: latent scales at the 0.1 clamp, pixel "
+                                  "scale 0.0035, blocks drawn from the model's own generative path)" if reg == "lowrate" else "")
                                + (", opt-in 64-state stream format (not the reference's word stream)" if fmt == "wave64" else ""))
                 extra.append(e)
             except Exception as ex:   # a sub-result never costs the headline
-                extra.append({"workload": wn, "chains_per_gpu": ch, "stream_format": fmt, "error": repr(ex)})
+                extra.append({"workload": wn, "chains_per_gpu": ch, "stream_format": fmt, "regime": reg, "error": repr(ex)})
 
     if rank != 0:
         if dist is not None:

@@ -80,9 +80,9 @@ __device__ __forceinline__ double lane_shift_up_f64(double v) {
 // Correctly rounded 1/x for x in [1, 2^1011): hardware seed (|rel err| <= 2^-24.4 measured), ONE cubic
 // Newton step (-> 2^-73), one residual correction.  The spec demands RN(1/x), whatever the seed: this
 // sequence agrees with IEEE division on 1.7e10 arguments incl. the all-ones-mantissa hard cases
-// (tools/recip_check.hip), and parity with the oracle's `1.0 / x` is asserted bit for bit
+// (tools/probes/recip_check.hip), and parity with the oracle's `1.0 / x` is asserted bit for bit
 // (tests/test_hip_parity.py::test_sigmoid_bit_exact_vs_oracle).  v_rcp_f64 issues at quarter rate
-// (tools/instr_rate.hip): 4 + 5 issue slots here against 4 + 9 for hipcc's generic f64 division.
+// (tools/probes/instr_rate.hip): 4 + 5 issue slots here against 4 + 9 for hipcc's generic f64 division.
 __device__ __forceinline__ double recip_1_to_huge(double x) {
     double y = __builtin_amdgcn_rcp(x);
     const double e = fma(-x, y, 1.0);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
 // ------------------------------------------------------------------------------------------
 // k_rans_pop_wave: BS_LAYOUT_WAVE rows, one wavefront per chain.
 //
-// A lone wavefront issues about one instruction every 3-4 ns whatever it is (tools/instr_latency.hip),
+// A lone wavefront issues about one instruction every 3-4 ns whatever it is (tools/probes/instr_latency.hip),
 // so the step is written for instruction count.  A row is NR = K/64 registers (register r, lane l =
 // c_{64r+l}) plus one pivot register (lane r = c_{64r}, lane NR = 2^bits, other lanes 0xffffffff):
 //   ballot(pivot <= m)      -> which register holds the symbol (scalar-indexed VGPR read)

@@ -568,3 +568,30 @@ def test_container_fingerprint_and_sidecar():
 def json_roundtrip(d):
     import json
     return json.loads(json.dumps(d))
+
+
+def test_lowrate_regime_codes_its_own_samples_at_a_trained_rate():
+    """workload.calibrate_lowrate + lowrate_blocks: the calibrated synthetic model codes blocks drawn
+    from its own generative path at a few bits/dim -- the regime of peaked tables and saturated tails the 26 bits/dim of
+    plain random weights never reaches -- losslessly, through the same schedule code and the oracle."""
+    model, zend, zcen = workload.build("imagenet4", "cpu", quantbits=10, small=16, regime="lowrate")
+    plain, _, _ = workload.build("imagenet4", "cpu", quantbits=10, small=16)
+    B, n = 3, 3
+    imgs = workload.lowrate_blocks(model, B * n, seed=5).view(B, n, -1).to(torch.int32)
+    assert imgs.min() >= 0 and imgs.max() <= 255 and imgs.float().std() > 2.0       # not a constant image
+    with torch.no_grad():
+        model.compress(True)
+        mu, sc = model.infer(0)(given=imgs[:, 0].float())
+        assert float(sc.max()) < 0.1001 and float(sc.min()) >= 0.1                    # the clamp of mnist_train.py:349
+        mu, sc = model.generate(0)(given=torch.zeros(B, model.zdim_flat))
+        assert 0.003 < float(sc.min()) and float(sc.max()) < 0.004
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, backend=OracleBackend(O.MODE_DET, threads=8))
+    st, met = codec.compress(imgs)
+    assert 2.0 < met["nets"].mean() < 7.0, met["nets"].mean()
+    # most of a pixel row is saturated tail: f = 1 (the reference's +1, mnist_compress.py:33) in > 90 % of the 256 bins
+    xe = codec.xend.numpy()[:64]
+    pm = O.logistic_pmf(xe, mu[0, :64].double().numpy(), sc.expand_as(mu)[0, :64].double().numpy(), O.MODE_DET)
+    f, _, rc = O.tables(pm, 31, 8)
+    assert rc == O.OK and (f == 1).mean() > 0.9
+    out = codec.decompress(st, n)
+    assert torch.equal(out, imgs) and st.to_lists() == initial_states(B)

@@ -1,8 +1,19 @@
-"""bs_wino_gemm_f32 against the library (torch.bmm on the backend the model uses) for the batched shapes of the bench:
-sustained loops, TFLOP/s.  usage: python tools/gemm_probe.py"""
+"""bs_wino_gemm_f32 (persistent balanced kernel, round 3) against its round-2 version (tiled launch; built on the spot from
+tools/probes/wino_gemm_r02.hip) and the library (torch.bmm on the backend the model used to use) for the batched shapes of
+the bench: sustained loops, TFLOP/s, fraction of the 157.3 TFLOP/s fp32 MFMA peak.
+usage: python tools/gemm_probe.py [--quick] [--only-own]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
 import torch
 
-from bitswap_amd import hip
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bitswap_amd import build, hip  # noqa: E402
+
+PEAK = 157.3
 
 
 def timeit(fn, reps=30):
@@ -18,16 +29,53 @@ def timeit(fn, reps=30):
     return a.elapsed_time(b) / reps * 1e-3
 
 
+def old_kernel():
+    so = "/tmp/libgemm_r02.so"
+    src = os.path.join(ROOT, "tools", "probes", "wino_gemm_r02.hip")
+    try:
+        subprocess.check_call([build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+        L = C.CDLL(so)
+        L.bs_wino_gemm_f32.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_int64, C.c_void_p]
+        return L
+    except Exception as e:   # noqa
+        print("round-2 kernel unavailable:", e)
+        return None
+
+
+quick, only_own = "--quick" in sys.argv, "--only-own" in sys.argv
 try:
     torch.backends.cuda.preferred_blas_library("ck")
 except Exception as e:   # noqa
     print("ck backend unavailable", e)
-for T, Cout, Cin, cols in ((36, 256, 256, 6400), (36, 256, 256, 1600), (64, 256, 256, 6400), (64, 256, 256, 1600),
-                           (36, 256, 256, 25600), (36, 256, 256, 208), (36, 16, 256, 6400), (36, 16, 256, 1600)):
+old = None if only_own else old_kernel()
+shapes = ((36, 256, 256, 6400), (36, 256, 256, 1600), (64, 256, 256, 6400), (64, 256, 256, 1600), (36, 256, 256, 25600),
+          (36, 256, 256, 7168), (36, 256, 256, 512), (36, 256, 256, 208), (36, 16, 256, 6400), (36, 16, 256, 1600), (36, 24, 256, 512))
+if quick:
+    shapes = shapes[:1]
+for T, Cout, Cin, cols in shapes:
     U = torch.randn(T, Cout, Cin, device="cuda")
     V = torch.randn(T, Cin, cols, device="cuda")
     out = torch.empty(T, Cout, cols, device="cuda")
     fl = 2.0 * T * Cout * Cin * cols
-    t1 = timeit(lambda: hip.wino_gemm(U, V, out=out))
-    t2 = timeit(lambda: torch.bmm(U, V, out=out))
-    print(f"T{T} Cout{Cout} Cin{Cin} cols{cols}: own {t1 * 1e6:8.1f} us {fl / t1 / 1e12:6.1f} TF | library {t2 * 1e6:8.1f} us {fl / t2 / 1e12:6.1f} TF", flush=True)
+    line = f"T{T} Cout{Cout} Cin{Cin} cols{cols}:"
+    for per_cu in ("", "1"):
+        if per_cu:
+            os.environ["BITSWAP_GEMM_WGS_PER_CU"] = per_cu
+        t1 = timeit(lambda: hip.wino_gemm(U, V, out=out))
+        os.environ.pop("BITSWAP_GEMM_WGS_PER_CU", None)
+        line += f" own{'/' + per_cu + 'wg' if per_cu else ''} {t1 * 1e6:8.1f} us {fl / t1 / 1e12:6.1f} TF ({fl / t1 / 1e12 / PEAK:.2f}) |"
+    if old is not None and Cout >= 64:
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ref = torch.empty_like(out)
+
+        def run_old():
+            rc = old.bs_wino_gemm_f32(U.data_ptr(), V.data_ptr(), ref.data_ptr(), T, Cout, Cin, cols, st)
+            assert rc == 0
+        t0 = timeit(run_old)
+        hip.wino_gemm(U, V, out=out)
+        same = bool(torch.equal(out, ref))
+        line += f" r02 {t0 * 1e6:8.1f} us {fl / t0 / 1e12:6.1f} TF (bitwise same: {same}) |"
+    if not only_own:
+        t2 = timeit(lambda: torch.bmm(U, V, out=out))
+        line += f" library {t2 * 1e6:8.1f} us {fl / t2 / 1e12:6.1f} TF"
+    print(line, flush=True)

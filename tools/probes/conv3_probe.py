@@ -1,6 +1,6 @@
 """Time bs_conv3_wino_f32 alone at the bench's shape (400 blocks, Cin 8 -> 256 channels, 16x16 planes) against the
 route it replaces (MIOpen conv + k_wino_fused<0, 6>).  BITSWAP_CONV3_CPB forces the channels per block.
-usage: python tools/conv3_probe.py [N] [C]"""
+usage: python tools/probes/conv3_probe.py [N] [C]"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 // instr_latency.hip -- dependent-issue latency of the instructions the serial rANS kernels chain together.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/instr_latency tools/instr_latency.hip && /tmp/instr_latency
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/instr_latency tools/probes/instr_latency.hip && /tmp/instr_latency
 // ONE wavefront on the whole GPU, each test a chain of N dependent copies of one instruction (or one
 // VALU<->SALU round trip); reported in ns per link and in cycles at the nominal 2.4 GHz.
 #include <hip/hip_runtime.h>

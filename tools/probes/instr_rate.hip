@@ -1,5 +1,5 @@
 // instr_rate.hip -- issue rate of the float64 / conversion instructions the logistic kernel is built from.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/instr_rate tools/instr_rate.hip && /tmp/instr_rate
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/instr_rate tools/probes/instr_rate.hip && /tmp/instr_rate
 // One wave-instruction = 64 lanes.  Reported: cycles per wave-instruction per SIMD with 8 waves/SIMD resident
 // (throughput, not latency), measured with s_memtime-free wall clock: ops / (time * SIMDs * clock).
 #include <hip/hip_runtime.h>

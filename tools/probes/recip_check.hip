@@ -1,5 +1,5 @@
 // recip_check.hip -- is a cheaper Newton schedule still the correctly rounded reciprocal?
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/recip_check tools/recip_check.hip && /tmp/recip_check
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/recip_check tools/probes/recip_check.hip && /tmp/recip_check
 // Compares, over 2^34 arguments x = 1 + e (the only arguments det_sigmoid feeds it: x in [1, 2^1011)),
 //   A: v_rcp_f64 + 2 quadratic Newton steps + residual correction   (the shipped sequence)
 //   B: v_rcp_f64 + 1 cubic step + residual correction               (one fma less)
