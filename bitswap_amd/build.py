@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bitswap_hip.hip")
 SRCS = [SRC, os.path.join(HERE, "csrc", "net_epilogue.hip"), os.path.join(HERE, "csrc", "wino_gemm.hip")]
 HDR = os.path.join(HERE, "..", "include", "bitswap_hip.h")
-LIB = os.path.join(HERE, "csrc", "libbitswap_hip.so")
+LIB = os.environ.get("BITSWAP_HIP_LIB") or os.path.join(HERE, "csrc", "libbitswap_hip.so")
 
 # -ffp-contract=off: the deterministic CDF spec forbids any fusion the source does not spell out
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -29,6 +29,22 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in SRCS + [HDR] if os.path.exists(p))
 
 
+ASAN_LIB = os.path.join(HERE, "csrc", "libbitswap_hip_asan.so")
+
+
+def build_asan(verbose=False):
+    """AddressSanitizer build of the same sources (host AND device code instrumented: ROCm's ASan needs an xnack+ target),
+    written next to the product library as libbitswap_hip_asan.so.  Diagnostic only: run a test with
+    BITSWAP_HIP_LIB=<that file> HSA_XNACK=1 LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so)."""
+    flags = [f if not f.startswith("--offload-arch") else "--offload-arch=gfx950:xnack+" for f in HIPCC_FLAGS]
+    flags = [f for f in flags if f != "-O3"] + ["-O1", "-g", "-fsanitize=address", "-shared-libsan"]
+    cmd = [hipcc_path()] + flags + ["-o", ASAN_LIB] + SRCS
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return ASAN_LIB
+
+
 def build_hip(force=False, verbose=False):
     """Compile the HIP library if missing or older than its sources.  Returns the .so path."""
     if force or is_stale():
@@ -40,4 +56,5 @@ def build_hip(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_hip(force=True, verbose=True))
+    import sys
+    print(build_asan(verbose=True) if "--asan" in sys.argv else build_hip(force=True, verbose=True))

@@ -175,11 +175,21 @@ class Timeline:
         self.spans = {}
 
 
+# BITSWAP_ROCTX=1: every coding operation (tables_z, pop_z, fc_z, push_x, net, ...) is bracketed by a roctx range, so a
+# `rocprofv3 --marker-trace` timeline shows the schedule of SURVEY.md 8a#10 by name (torch.cuda.nvtx IS roctx on ROCm)
+_ROCTX = os.environ.get("BITSWAP_ROCTX", "0") == "1"
+
+
 class _Span:
     def __init__(self, tl, key):
         self.tl, self.key = tl, key
 
     def __enter__(self):
+        if _ROCTX:
+            try:
+                torch.cuda.nvtx.range_push("bitswap:" + self.key)
+            except Exception:
+                pass
         if self.tl.enabled:
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
@@ -189,6 +199,11 @@ class _Span:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             self.tl.spans.setdefault(self.key, []).append((self.a, b))
+        if _ROCTX:
+            try:
+                torch.cuda.nvtx.range_pop()
+            except Exception:
+                pass
 
 
 class _StepGraph:

@@ -44,11 +44,11 @@ struct Chunk {
 
 // Global -> register -> LDS staging of one K step (A: BM x 16 of U[t], B: 16 x 128 of V[t]); the per-thread parts of the
 // addresses are 32-bit element offsets against wave-uniform bases.
-template <int NW>
+template <int NW, int MI>
 struct Stager {
-    static constexpr int BM = 32 * NW, NT = 64 * NW;
+    static constexpr int BM = 32 * MI * NW, NT = 64 * NW;
     static constexpr int STAGE = BM * G_LDA + G_BK * G_LDB;
-    static constexpr int NA = BM * 4 / NT;                  // float4 loads per thread and stage: A (= 2)
+    static constexpr int NA = BM * 4 / NT;                  // float4 loads per thread and stage: A (2 MI)
     static constexpr int NB = (G_BK * G_BN / 4) / NT;       //                                    B (8 / NW)
     const float* U;
     const float* V;
@@ -95,67 +95,81 @@ struct Stager {
 };
 
 // One chunk of NBLK column blocks: the K loop (the stage of its first step is in LDS buffer `buf` and synchronised), then
-// the stores.  The last step prefetches the first stage of the chunk that follows.
-template <int NW, int NBLK>
-__device__ __forceinline__ void run_chunk(Stager<NW>& sg, float* lds, float* __restrict__ M, const Chunk& cur,
+// the stores.  The last step prefetches the first stage of the chunk that follows.  A wavefront owns MI x NBLK MFMA tiles
+// (32 MI rows x 32 NBLK columns); ALL operand fragments of a K step are requested from LDS before its first MFMA, so the
+// wave pays one LDS latency per 32 MI NBLK / 2 MFMAs instead of one per pair (round-3 visit A: the matrix pipe was busy
+// 70 % of the time with the reads interleaved).
+template <int NW, int MI, int NBLK>
+__device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float* __restrict__ M, const Chunk& cur,
                                           const Chunk& nxt, bool more, int& buf, int wave, int l32, int g) {
-    constexpr int BM = 32 * NW, STAGE = Stager<NW>::STAGE;
-    f32x16 acc[NBLK];
+    constexpr int BM = 32 * MI * NW, STAGE = Stager<NW, MI>::STAGE;
+    f32x16 acc[MI][NBLK];
 #pragma unroll
-    for (int ni = 0; ni < NBLK; ++ni)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[ni][v] = 0.0f;
+        for (int ni = 0; ni < NBLK; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.0f;
     const int nk = sg.Cin / G_BK;
     for (int kt = 0; kt < nk; ++kt) {
         const bool last = kt + 1 == nk;
         if (!last) sg.load(cur, (kt + 1) * G_BK);            // in flight under the multiplies below
         else if (more) sg.load(nxt, 0);                      // ... the next chunk's first stage under this chunk's last
-        const float* As = lds + buf * STAGE + (wave * 32 + l32) * G_LDA + g * 4;
+        const float* As = lds + buf * STAGE + (wave * 32 * MI + l32) * G_LDA + g * 4;
         const float* Bs = lds + buf * STAGE + BM * G_LDA + (g * 4) * G_LDB + l32;
+        f32x4 a[2][MI];
+        float b[2][NBLK][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(As + j * 8);
-            float b[NBLK][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[j][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * G_LDA + j * 8);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int ni = 0; ni < NBLK; ++ni) b[ni][i] = Bs[(j * 8 + i) * G_LDB + ni * 32];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int ni = 0; ni < NBLK; ++ni)
-                    acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[ni][i], acc[ni], 0, 0, 0);
+                for (int ni = 0; ni < NBLK; ++ni) b[j][ni][i] = Bs[(j * 8 + i) * G_LDB + ni * 32];
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NBLK; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][i], b[j][ni][i], acc[mi][ni], 0, 0, 0);
         if (!last || more) sg.store(lds, buf ^ 1);           // the other buffer: last read before the previous barrier
         __syncthreads();
         buf ^= 1;
     }
     // C layout of the 32x32 MFMA: register v of lane l is row (v/4)*8 + (l/32)*4 + v%4, column l%32
     float* Mt = M + (int64_t)cur.t * sg.Cout * sg.cols;
-    const int row0 = cur.co0 + wave * 32 + g * 4;
     const bool all_rows = cur.co0 + BM <= sg.Cout;
 #pragma unroll
-    for (int ni = 0; ni < NBLK; ++ni) {
-        const int64_t col = (int64_t)cur.cb * 32 + ni * 32 + l32;
-        if (col < sg.cols) {
-            float* p = Mt + (int64_t)row0 * sg.cols + col;
-            if (all_rows) {
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row0 = cur.co0 + (wave * MI + mi) * 32 + g * 4;
 #pragma unroll
-                for (int v = 0; v < 16; ++v) p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[ni][v];
-            } else {
+        for (int ni = 0; ni < NBLK; ++ni) {
+            const int64_t col = (int64_t)cur.cb * 32 + ni * 32 + l32;
+            if (col < sg.cols) {
+                float* p = Mt + (int64_t)row0 * sg.cols + col;
+                if (all_rows) {
 #pragma unroll
-                for (int v = 0; v < 16; ++v)
-                    if (row0 + (v >> 2) * 8 + (v & 3) < sg.Cout) p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[ni][v];
+                    for (int v = 0; v < 16; ++v) p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[mi][ni][v];
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        if (row0 + (v >> 2) * 8 + (v & 3) < sg.Cout) p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[mi][ni][v];
+                }
             }
         }
     }
 }
 
-template <int NW>
+template <int NW, int MI>
 __global__ __launch_bounds__(64 * NW, NW >= 8 ? 4 : 2) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
-                                                                        float* __restrict__ M, int Cout, int Cin, int64_t cols,
-                                                                        int ncb, int nrt, int units) {
-    constexpr int BM = 32 * NW;
+                                                          float* __restrict__ M, int Cout, int Cin, int64_t cols,
+                                                          int ncb, int nrt, int units) {
+    constexpr int BM = 32 * MI * NW;
     extern __shared__ float lds[];                   // [2][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 4 : 2) void k_wino_gemm(const fl
         return c;
     };
 
-    Stager<NW> sg;
+    Stager<NW, MI> sg;
     sg.init(U, V, Cout, Cin, cols, tid);
     Chunk cur = decode(u);
     sg.load(cur, 0);
@@ -191,10 +205,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 4 : 2) void k_wino_gemm(const fl
         const bool more = unext < uend;
         Chunk nxt = cur;
         if (more) nxt = decode(unext);
-        if (cur.nb == 4) run_chunk<NW, 4>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-        else if (cur.nb == 3) run_chunk<NW, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);   // a range's ragged ends
-        else if (cur.nb == 2) run_chunk<NW, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-        else run_chunk<NW, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        if (cur.nb == 4) run_chunk<NW, MI, 4>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        else if (cur.nb == 3) run_chunk<NW, MI, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);   // a range's ragged ends
+        else if (cur.nb == 2) run_chunk<NW, MI, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        else run_chunk<NW, MI, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
         if (!more) break;
         u = unext;
         cur = nxt;
@@ -210,23 +224,23 @@ int cu_count() {
     return n;
 }
 
-template <int NW>
+template <int NW, int MI>
 int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, hipStream_t st) {
-    constexpr int BM = 32 * NW;
+    constexpr int BM = 32 * MI * NW;
     const int64_t ncb = (cols + 31) / 32, nrt = (Cout + BM - 1) / BM;
     const int64_t units = (int64_t)T * nrt * ncb;
-    if (units > 0x7fffffff) return BS_EUNSUPPORTED;
+    if (units > 0x7fffffff || (int64_t)Cin * cols > 0x7fffffff) return BS_EUNSUPPORTED;
     const size_t shm = 2 * (size_t)(BM * G_LDA + G_BK * G_LDB) * sizeof(float);
-    // workgroups per CU: two of the 8-wave shape (58 KB of LDS, 128 registers each); the one-wave shape of the head
-    // convolutions is bounded by its 22 KB of LDS
-    const int per_cu = NW >= 4 ? 2 : NW == 2 ? 4 : 6;
+    // workgroups per CU: two of the 256-row shape (58 KB of LDS each, one wavefront per SIMD each, 256 registers per lane);
+    // the one-wave shape of the head convolutions is bounded by its 22 KB of LDS
+    const int per_cu = BM >= 128 ? 2 : BM == 64 ? 4 : 6;
     int64_t G = (int64_t)cu_count() * per_cu;
     if (const char* e = getenv("BITSWAP_GEMM_WGS_PER_CU")) {    // tuning only: the summation order does not depend on it
         const int v = atoi(e);
         if (v > 0) G = (int64_t)cu_count() * v;
     }
     if (G > units) G = units;
-    hipLaunchKernelGGL((k_wino_gemm<NW>), dim3((unsigned)G), dim3(64 * NW), shm, st, U, V, M, Cout, Cin, cols, (int)ncb,
+    hipLaunchKernelGGL((k_wino_gemm<NW, MI>), dim3((unsigned)G), dim3(64 * NW), shm, st, U, V, M, Cout, Cin, cols, (int)ncb,
                        (int)nrt, (int)units);
     return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
 }
@@ -240,10 +254,15 @@ extern "C" int bs_wino_gemm_f32(const float* U, const float* V, float* M, int T,
     if (((uintptr_t)U | (uintptr_t)V | (uintptr_t)M) & 15u) return BS_EINVAL;
     if (T == 0 || cols == 0) return BS_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // tallest workgroup the channel count fills (rows beyond Cout are zero operands whose results are dropped); the
+    // tallest workgroup the channel count fills (rows beyond Cout are redirected operands whose results are dropped); the
     // summation order per output does not depend on the choice
-    if (Cout > 128) return launch_gemm<8>(U, V, M, T, Cout, Cin, cols, st);
-    if (Cout > 64) return launch_gemm<4>(U, V, M, T, Cout, Cin, cols, st);
-    if (Cout > 32) return launch_gemm<2>(U, V, M, T, Cout, Cin, cols, st);
-    return launch_gemm<1>(U, V, M, T, Cout, Cin, cols, st);
+    if (Cout > 128) {
+        // tuning only (tools/gemm_probe.py): the round-3 visit-A shape, 8 wavefronts of 32 rows x 128 columns at 128 registers
+        const char* e = getenv("BITSWAP_GEMM_SHAPE");
+        if (e && e[0] == '8') return launch_gemm<8, 1>(U, V, M, T, Cout, Cin, cols, st);
+        return launch_gemm<4, 2>(U, V, M, T, Cout, Cin, cols, st);      // 4 wavefronts of 64 rows x 128 columns
+    }
+    if (Cout > 64) return launch_gemm<4, 1>(U, V, M, T, Cout, Cin, cols, st);
+    if (Cout > 32) return launch_gemm<2, 1>(U, V, M, T, Cout, Cin, cols, st);
+    return launch_gemm<1, 1>(U, V, M, T, Cout, Cin, cols, st);
 }

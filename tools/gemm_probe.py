@@ -58,12 +58,18 @@ for T, Cout, Cin, cols in shapes:
     out = torch.empty(T, Cout, cols, device="cuda")
     fl = 2.0 * T * Cout * Cin * cols
     line = f"T{T} Cout{Cout} Cin{Cin} cols{cols}:"
-    for per_cu in ("", "1"):
+    for per_cu, shape in (("", ""), ("1", ""), ("3", ""), ("", "8")):
+        if shape and Cout <= 128:
+            continue
         if per_cu:
             os.environ["BITSWAP_GEMM_WGS_PER_CU"] = per_cu
+        if shape:
+            os.environ["BITSWAP_GEMM_SHAPE"] = shape
         t1 = timeit(lambda: hip.wino_gemm(U, V, out=out))
         os.environ.pop("BITSWAP_GEMM_WGS_PER_CU", None)
-        line += f" own{'/' + per_cu + 'wg' if per_cu else ''} {t1 * 1e6:8.1f} us {fl / t1 / 1e12:6.1f} TF ({fl / t1 / 1e12 / PEAK:.2f}) |"
+        os.environ.pop("BITSWAP_GEMM_SHAPE", None)
+        tag = "own" + ("/" + per_cu + "wg" if per_cu else "") + ("/8x32rows" if shape else "")
+        line += f" {tag} {t1 * 1e6:8.1f} us {fl / t1 / 1e12:6.1f} TF ({fl / t1 / 1e12 / PEAK:.2f}) |"
     if old is not None and Cout >= 64:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         ref = torch.empty_like(out)

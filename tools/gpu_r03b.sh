@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-3 visit B: GEMM tests + probe (fat-wave kernel vs visit-A shape vs round-2 vs library) + MFMA counters + short bench.
+TAG=${1:-r03b}; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
+timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "wino_gemm or own_gemm or full_width or rccl or spec2_domain or separate_processes or graph" > $OUT/${TAG}_pytest.log 2>&1; echo "pytest exit $?" | tee -a $OUT/${TAG}_pytest.log
+tail -12 $OUT/${TAG}_pytest.log
+timeout 600 python tools/gemm_probe.py > $OUT/${TAG}_gemm_probe.txt 2>&1; echo "probe exit $?"; cat $OUT/${TAG}_gemm_probe.txt | grep -v Warning
+for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
+  n=$(echo $set | tr ' ' '_' | cut -c1-40)
+  ( cd /tmp && rm -rf pv && timeout 300 rocprofv3 --pmc $set -d /tmp/pv -o pv --output-format csv -- python $R/tools/gemm_probe.py --quick --only-own > /dev/null 2>$OUT/${TAG}_pmc_$n.err )
+  python - <<PY
+import csv, glob, json, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for f in glob.glob("/tmp/pv/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:40] + " grid" + r.get("Grid_Size", "?")
+        if "wino_gemm" in k:
+            a = acc[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+out = {k: {c: v[1] / v[0] for c, v in d.items()} for k, d in acc.items()}
+json.dump(out, open("$OUT/${TAG}_gemm_pmc_$n.json", "w"), indent=1)
+for k, d in out.items():
+    print(k[:70], {c: round(v) for c, v in d.items()})
+PY
+done
+timeout 600 python bench.py --no-extra --no-cpu-baseline > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; echo "bench exit $?"; cut -c1-300 $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err
+exit 0
