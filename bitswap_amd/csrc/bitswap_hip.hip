@@ -724,7 +724,9 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
                 soff = (uint32_t)max((int)(soff - ld4), 0);
                 h = (uint64_t)f * (h >> bits) + (uint64_t)(m - cs);
                 uint32_t hhi = (uint32_t)(h >> 32);
+#if !__has_feature(address_sanitizer)   // (the ASan build, bitswap_amd/build.py --asan, keeps the head in vector registers)
                 asm("" : "+s"(hhi));  // keep this a 32-bit scalar compare (hipcc otherwise builds a 64-bit VALU one)
+#endif
                 if (hhi == 0u) {  // h < 2^32, mnist_compress.py:65
                     h = (h << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, o);
                     ++o;

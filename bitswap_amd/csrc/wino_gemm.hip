@@ -35,61 +35,67 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int G_BN = 128, G_BK = 16, G_LDA = G_BK + 4, G_LDB = G_BN + 8;
+constexpr int G_BN = 128, G_BK = 16, G_LDA = G_BK, G_LDB = G_BN;      // LDS rows are unpadded: the tiles arrive by LDS-DMA
 
 struct Chunk {
     int t, co0, cb, nb;     // transform position, first output row, first 32-column block, column blocks (1..4)
 };
 
-// Global -> register -> LDS staging of one K step (A: BM x 16 of U[t], B: 16 x 128 of V[t]); the per-thread parts of the
-// addresses are 32-bit element offsets against wave-uniform bases.
+// Global -> LDS staging of one K step (A: BM x 16 of U[t], B: 16 x 128 of V[t]) by LDS-DMA (global_load_lds_dwordx4): no
+// staging registers, no ds_write pass -- in the round-3 lab (tools/probes/gemm_lab.hip) the register-staged version of this
+// kernel lost 6 % to its LDS stage stores and 7 % to the loads feeding them.  A wave-instruction writes 64 x 16 bytes to
+// consecutive LDS addresses (wave-uniform base + lane x 16), so the LDS image is linear in the thread index and any
+// permutation has to be applied on the SOURCE side:
+//   A: 16-byte granule q = 4 row + slot holds k = 4 (slot ^ ((row >> 2) & 3)) .. + 3 of that row -- rows are 64 bytes apart
+//      (no padding possible), and the XOR spreads the 16 rows a ds_read_b128 phase touches over all 64 banks;
+//   B: [k][128] as it lies in memory; a lane reads one float per k, the 32 lanes of a phase consecutive words.
 template <int NW, int MI>
 struct Stager {
     static constexpr int BM = 32 * MI * NW, NT = 64 * NW;
     static constexpr int STAGE = BM * G_LDA + G_BK * G_LDB;
-    static constexpr int NA = BM * 4 / NT;                  // float4 loads per thread and stage: A (2 MI)
-    static constexpr int NB = (G_BK * G_BN / 4) / NT;       //                                    B (8 / NW)
+    static constexpr int NA = BM * 4 / NT;                  // 16-byte granules per thread and stage: A (2 MI)
+    static constexpr int NB = (G_BK * G_BN / 4) / NT;       //                                         B (8 / NW)
     const float* U;
     const float* V;
-    int Cout, Cin, tid;
+    int Cout, Cin, tid, wbase;
     int64_t cols;
-    int offA[NA], offB[NB];
-    f32x4 ra[NA], rb[NB];
+    uint32_t offA[NA], offB[NB];             // BYTE offsets of this thread's granules against the chunk's operand bases
 
     __device__ __forceinline__ void init(const float* U_, const float* V_, int Cout_, int Cin_, int64_t cols_, int tid_) {
         U = U_, V = V_, Cout = Cout_, Cin = Cin_, cols = cols_, tid = tid_;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) offA[i] = ((tid + i * NT) >> 2) * Cin + ((tid + i * NT) & 3) * 4;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) offB[i] = ((tid + i * NT) >> 5) * (int)cols + ((tid + i * NT) & 31) * 4;
-    }
-    __device__ __forceinline__ void load(const Chunk& c, int k0) {
-        const float* Ub = U + ((int64_t)c.t * Cout + c.co0) * Cin + k0;
-        const float* Vb = V + ((int64_t)c.t * Cin + k0) * cols + (int64_t)c.cb * 32;
-        const int rows_left = Cout - c.co0;
-        const int cols_left = (int)min((int64_t)c.nb * 32, cols - (int64_t)c.cb * 32);
-        // rows beyond Cout / columns beyond the chunk only feed outputs that are never stored: their loads are
-        // redirected to a valid address instead of being masked (a select would wait for the load right here)
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-            ra[i] = *reinterpret_cast<const f32x4*>(Ub + ((((tid + i * NT) >> 2) < rows_left) ? offA[i] : offA[i] & 15));
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            rb[i] = *reinterpret_cast<const f32x4*>(Vb + ((((tid + i * NT) & 31) * 4 < cols_left) ? offB[i] : offB[i] - ((tid + i * NT) & 31) * 4));
-    }
-    __device__ __forceinline__ void store(float* lds, int buf) const {
-        float* As = lds + buf * STAGE;
-        float* Bs = As + BM * G_LDA;
+        wbase = __builtin_amdgcn_readfirstlane(tid & ~63);        // first granule of this wavefront per load instruction
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = tid + i * NT, row = e >> 2, kq = e & 3;
-            *reinterpret_cast<f32x4*>(As + row * G_LDA + kq * 4) = ra[i];
+            const int q = tid + i * NT, row = q >> 2, kq = (q & 3) ^ ((row >> 2) & 3);
+            offA[i] = (uint32_t)(row * Cin + kq * 4) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) offB[i] = (uint32_t)(((tid + i * NT) >> 5) * (int)cols + ((tid + i * NT) & 31) * 4) * 4u;
+    }
+    // issue the DMA of step (c, k0) into LDS stage `buf`
+    __device__ __forceinline__ void load(const Chunk& c, int k0, float* lds, int buf) const {
+        const char* Ub = reinterpret_cast<const char*>(U + ((int64_t)c.t * Cout + c.co0) * Cin + k0);
+        const char* Vb = reinterpret_cast<const char*>(V + ((int64_t)c.t * Cin + k0) * cols + (int64_t)c.cb * 32);
+        const int rows_left = Cout - c.co0;
+        const int cols_left = (int)min((int64_t)c.nb * 32, cols - (int64_t)c.cb * 32);
+        float* As = lds + buf * STAGE;
+        float* Bs = As + BM * G_LDA;
+        // rows beyond Cout / columns beyond the chunk only feed outputs that are never stored: their loads are redirected
+        // to a valid address (row 0 / column 0 of the tile) instead of being masked
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int q = tid + i * NT;
+            const uint32_t off = ((q >> 2) < rows_left) ? offA[i] : (uint32_t)(((q & 3) ^ ((q >> 4) & 3)) * 16);
+            __builtin_amdgcn_global_load_lds(Ub + off, (lds_ptr_t)(As + (wbase + i * NT) * 4),
+                                             16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int e = tid + i * NT, k = e >> 5, c4 = e & 31;
-            *reinterpret_cast<f32x4*>(Bs + k * G_LDB + c4 * 4) = rb[i];
+            const uint32_t off = (((tid + i * NT) & 31) * 4 < cols_left) ? offB[i] : offB[i] - (uint32_t)((tid + i * NT) & 31) * 16u;
+            __builtin_amdgcn_global_load_lds(Vb + off, (lds_ptr_t)(Bs + (wbase + i * NT) * 4),
+                                             16, 0, 0);
         }
     }
 };
@@ -113,16 +119,19 @@ __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float*
     const int nk = sg.Cin / G_BK;
     for (int kt = 0; kt < nk; ++kt) {
         const bool last = kt + 1 == nk;
-        if (!last) sg.load(cur, (kt + 1) * G_BK);            // in flight under the multiplies below
-        else if (more) sg.load(nxt, 0);                      // ... the next chunk's first stage under this chunk's last
-        const float* As = lds + buf * STAGE + (wave * 32 * MI + l32) * G_LDA + g * 4;
+        // DMA of the next step into the other buffer (its last reads completed before the previous barrier): in flight
+        // under the multiplies below, landed by the barrier at the end of this step
+        if (!last) sg.load(cur, (kt + 1) * G_BK, lds, buf ^ 1);
+        else if (more) sg.load(nxt, 0, lds, buf ^ 1);        // ... the next chunk's first stage under this chunk's last
+        const float* As = lds + buf * STAGE + (wave * 32 * MI + l32) * G_LDA;
         const float* Bs = lds + buf * STAGE + BM * G_LDA + (g * 4) * G_LDB + l32;
+        const int sw = (l32 >> 2) & 3;                       // source-side swizzle of the A granules, see Stager
         f32x4 a[2][MI];
         float b[2][NBLK][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[j][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * G_LDA + j * 8);
+            for (int mi = 0; mi < MI; ++mi) a[j][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * G_LDA + (((2 * j + g) ^ sw) << 2));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -137,7 +146,6 @@ __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float*
 #pragma unroll
                     for (int ni = 0; ni < NBLK; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][i], b[j][ni][i], acc[mi][ni], 0, 0, 0);
-        if (!last || more) sg.store(lds, buf ^ 1);           // the other buffer: last read before the previous barrier
         __syncthreads();
         buf ^= 1;
     }
@@ -166,7 +174,7 @@ __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float*
 }
 
 template <int NW, int MI>
-__global__ __launch_bounds__(64 * NW, NW >= 8 ? 4 : 2) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
+__global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
                                                           float* __restrict__ M, int Cout, int Cin, int64_t cols,
                                                           int ncb, int nrt, int units) {
     constexpr int BM = 32 * MI * NW;
@@ -196,8 +204,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 4 : 2) void k_wino_gemm(const fl
     Stager<NW, MI> sg;
     sg.init(U, V, Cout, Cin, cols, tid);
     Chunk cur = decode(u);
-    sg.load(cur, 0);
-    sg.store(lds, 0);
+    sg.load(cur, 0, lds, 0);
     __syncthreads();
     int buf = 0;
     while (true) {
@@ -231,7 +238,7 @@ int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int C
     const int64_t units = (int64_t)T * nrt * ncb;
     if (units > 0x7fffffff || (int64_t)Cin * cols > 0x7fffffff) return BS_EUNSUPPORTED;
     const size_t shm = 2 * (size_t)(BM * G_LDA + G_BK * G_LDB) * sizeof(float);
-    // workgroups per CU: two of the 256-row shape (58 KB of LDS each, one wavefront per SIMD each, 256 registers per lane);
+    // workgroups per CU: two of the 256-row shape (48 KB of LDS each, one wavefront per SIMD each, up to 256 registers per lane);
     // the one-wave shape of the head convolutions is bounded by its 22 KB of LDS
     const int per_cu = BM >= 128 ? 2 : BM == 64 ? 4 : 6;
     int64_t G = (int64_t)cu_count() * per_cu;
@@ -256,12 +263,7 @@ extern "C" int bs_wino_gemm_f32(const float* U, const float* V, float* M, int T,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tallest workgroup the channel count fills (rows beyond Cout are redirected operands whose results are dropped); the
     // summation order per output does not depend on the choice
-    if (Cout > 128) {
-        // tuning only (tools/gemm_probe.py): the round-3 visit-A shape, 8 wavefronts of 32 rows x 128 columns at 128 registers
-        const char* e = getenv("BITSWAP_GEMM_SHAPE");
-        if (e && e[0] == '8') return launch_gemm<8, 1>(U, V, M, T, Cout, Cin, cols, st);
-        return launch_gemm<4, 2>(U, V, M, T, Cout, Cin, cols, st);      // 4 wavefronts of 64 rows x 128 columns
-    }
+    if (Cout > 128) return launch_gemm<4, 2>(U, V, M, T, Cout, Cin, cols, st);      // 4 wavefronts of 64 rows x 128 columns
     if (Cout > 64) return launch_gemm<4, 1>(U, V, M, T, Cout, Cin, cols, st);
     if (Cout > 32) return launch_gemm<2, 1>(U, V, M, T, Cout, Cin, cols, st);
     return launch_gemm<1, 1>(U, V, M, T, Cout, Cin, cols, st);
