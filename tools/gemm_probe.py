@@ -61,7 +61,16 @@ for T, Cout, Cin, cols in shapes:
     out = torch.empty(T, Cout, cols, device="cuda")
     fl = 2.0 * T * Cout * Cin * cols
     line = f"T{T} Cout{Cout} Cin{Cin} cols{cols}:"
+    def own_with(**env):
+        def run():
+            os.environ.update(env)
+            hip.wino_gemm(U, V, out=out)
+            for k in env:
+                os.environ.pop(k, None)
+        return run
     variants = [("own", lambda: hip.wino_gemm(U, V, out=out))]
+    if "--knobs" in sys.argv:
+        variants += [("own/1wg", own_with(BITSWAP_GEMM_WGS_PER_CU="1")), ("own/3wg", own_with(BITSWAP_GEMM_WGS_PER_CU="3"))]
     ref = None
     if old is not None and Cout >= 64:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
