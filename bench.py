@@ -187,10 +187,12 @@ def exclusive_pass(codec, states, block, rkey, tl, dev):
         tl.reset()
 
 
-def gemm_roofline(model, chains, dev, reps=20):
+def gemm_roofline(model, chains, dev, warm=100, reps=100):
     """The kernel that dominates the rocprof summary is not on the entropy path: the Winograd-domain batched GEMM of the
     conv stacks (bs_wino_gemm_f32, fp32 MFMA).  Its own roofline, at the shape one chain group launches most often
-    (36 transform positions x [C x C] x [C x 16 tiles per block]), HIP events around a short exclusive loop."""
+    (36 transform positions x [C x C] x [C x 16 tiles per block]), HIP events around an exclusive back-to-back loop -- 100
+    launches of warm-up first: the clock of an MI355X follows the load of the last tens of milliseconds, a handful of launches
+    measures the clock history of whatever ran before (profiles/r03b vs r03f: 93 vs 117 TFLOP/s for the same cycle count)."""
     try:
         from bitswap_amd import hip
         if not (getattr(model, "fused", False) and getattr(model, "own_gemm", False)):
@@ -202,7 +204,7 @@ def gemm_roofline(model, chains, dev, reps=20):
         if not hip.wino_gemm_supported(U, V):
             return None
         out = torch.empty(36, C, cols, device=dev)
-        for _ in range(3):
+        for _ in range(warm):
             hip.wino_gemm(U, V, out=out)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -213,11 +215,11 @@ def gemm_roofline(model, chains, dev, reps=20):
         torch.cuda.synchronize()
         t = a.elapsed_time(b) / reps * 1e-3
         fl = 2.0 * 36 * C * C * cols
-        return {"kernel": "k_wino_gemm<8> (bs_wino_gemm_f32: v_mfma_f32_32x32x2_f32, persistent balanced tiles)", "bound": "mfma",
+        return {"kernel": "k_wino_gemm<4,2> (bs_wino_gemm_f32: v_mfma_f32_32x32x2_f32, persistent balanced tiles, LDS-DMA staging)", "bound": "mfma",
                 "shape": f"T36 x [{C}x{C}] x [{C}x{cols}]", "achieved": round(fl / t / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(t * 1e3, 4),
                 "launches": reps, "hbm_bytes_per_launch": int(4 * 36 * C * cols * 2 + 4 * 36 * C * C),
-                "timing": "exclusive: HIP events around a back-to-back loop on the current stream"}
+                "timing": f"exclusive: HIP events around {reps} back-to-back launches on the current stream after {warm} of warm-up"}
     except Exception as e:
         return {"error": repr(e)}
 
