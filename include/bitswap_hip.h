@@ -45,7 +45,9 @@ extern "C" {
  * a stream written with one CDF spec can only be decoded with the same one.
  *   spec 1: one float64 sigmoid per bin endpoint (bin_step == NULL); any bins.
  *   spec 2: rows of UNIFORM-width bins (bin_step != NULL, K >= 256): one exponential per group of K/64 bins
- *           and a geometric factor per bin; same endpoints, agrees with spec 1 to a few ulp of the cdf. */
+ *           and a geometric factor per bin; same endpoints, agrees with spec 1 to a few ulp of the cdf.  Defined for
+ *           rows with (K/64) * bin_step / scale < 650 (the geometric factors must stay clear of the exponential's clamp:
+ *           scale > 5e-5 for the pixel bins, 20x under the reference's floor); a row outside flags BS_ST_BADTABLE. */
 #define BS_CDF_SPEC 2
 
 #define BS_OK 0
@@ -246,9 +248,11 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *
  * bs_wino_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols], float32 on the matrix cores
  *   (v_mfma_f32_32x32x2_f32, float32 accumulate): the batched product in the middle of a Winograd-domain convolution
- *   (bitswap_amd/csrc/wino_gemm.hip).  Every output element is the sum over ci in one fixed order that depends on
- *   Cin only: results are bitwise independent of `cols` (how many blocks are coded together), which no BLAS library
- *   promises.  Cin % 16 == 0, cols % 4 == 0, 16-byte aligned operands (BS_EUNSUPPORTED / BS_EINVAL otherwise).
+ *   (bitswap_amd/csrc/wino_gemm.hip: persistent workgroups over (t, row tile, 32-column block) units, operands staged by
+ *   LDS-DMA).  Every output element is the sum over ci in one fixed order that depends on Cin only: results are bitwise
+ *   independent of `cols` (how many blocks are coded together) and of Cout, which no BLAS library promises -- since round 3
+ *   every product of the conv stacks takes it, the 16-channel head convolutions included.  Cin % 16 == 0, cols % 4 == 0,
+ *   Cin * cols < 2^31, 16-byte aligned operands (BS_EUNSUPPORTED / BS_EINVAL otherwise).
  *
  * bs_small_k_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols] for small Cin (<= 64): the batched product
  *   of the INPUT convolutions of the stacks in the Winograd domain (Cin = zchannels or 4 x image channels); a write of M
