@@ -37,14 +37,21 @@ class HipBackend:
     def new_state(self, states, cap):
         return hip.RansState.from_lists(states, cap=cap, device=self.device)
 
-    @staticmethod
-    def table_layout(K):
-        """cdf rows are an internal hand-off between two of our kernels: use the wave-native layout
-        whenever the pop kernel has it (K = 256..2048), the reference's linear rows otherwise."""
+    # cdf rows are an internal hand-off between two of our kernels.  Rows of uniform-width bins (CDF spec 2: every latent
+    # layer below the top one and the pixels) travel as 64 cumulative values per row and the pop kernel rebuilds the one
+    # group of bins it needs (BS_LAYOUT_PIVOT, 512 B per row instead of 4 (K + 64): the row-reading pop kernel ran at the HBM
+    # roof and nothing overlapped with it); other tables use the wave-native rows whenever the pop kernel has them
+    # (K = 256..2048), the reference's linear rows otherwise.  BITSWAP_PIVOT=0 keeps whole rows everywhere.
+    pivot = os.environ.get("BITSWAP_PIVOT", "1") == "1"
+
+    def table_layout(self, K, uniform=False, D=64):
+        if uniform and self.pivot and hip.pivot_supported(K, D):
+            return hip.LAYOUT_PIVOT
         return hip.LAYOUT_WAVE if hip.wave_supported(K) else hip.LAYOUT_LINEAR
 
-    def table_buffer(self, B, D, K):
-        ld = hip.wave_ld(K) if self.table_layout(K) == hip.LAYOUT_WAVE else hip.aligned_ld(K)
+    def table_buffer(self, B, D, K, uniform=False):
+        layout = self.table_layout(K, uniform, D)
+        ld = hip.PIVOT_LD if layout == hip.LAYOUT_PIVOT else hip.wave_ld(K) if layout == hip.LAYOUT_WAVE else hip.aligned_ld(K)
         return torch.empty((B, D, ld), dtype=torch.int32, device=self.device)
 
     def bin_step(self, endpoints):
@@ -57,8 +64,10 @@ class HipBackend:
 
     def tables(self, endpoints, mu, scale, quantbits, bits, out=None, step=None, status=None):
         K = endpoints.shape[1] + 1
-        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=self.table_layout(K),
-                                   step=step, status=status)
+        layout = self.table_layout(K, step is not None, mu.shape[1])
+        if out is not None and layout == hip.LAYOUT_PIVOT and out.shape[-1] != hip.PIVOT_LD:
+            out = None                                   # a caller's whole-row buffer: not what this layout writes
+        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=layout, step=step, status=status)
 
     def shared_table(self, endpoints, mu, scale, quantbits, bits, step=None):
         """One table row set [D, ld] shared by every chain (the prior)."""
@@ -124,7 +133,7 @@ class Hip64Backend(HipBackend):
         cap64 = longest + max(int(cap) - total, 0) // hip.NSTATES + 64
         return hip.RansState64.from_lists(nested, cap=cap64, device=self.device)
 
-    def table_buffer(self, B, D, K):
+    def table_buffer(self, B, D, K, uniform=False):
         return None
 
     def tables(self, endpoints, mu, scale, quantbits, bits, out=None, step=None, status=None):
@@ -302,11 +311,11 @@ class BitSwapCodec:
         cap = max(len(s) for s in states) + nblocks * (self.X + 64) + 4 * self.Z
         return self.backend.new_state(states, cap)
 
-    def _cdf(self, B, D, K):
+    def _cdf(self, B, D, K, uniform=False):
         """Reusable cdf-row buffer per table shape (the largest, [B, Z, K+64] u32, is 1.8 GB at B=200,
         Z=2048, K=1024: resident for the whole run instead of re-allocated per layer).  A smaller chain
         count (ragged runs: chains drop out) takes a prefix of the buffer made for the largest one."""
-        key = (D, K)
+        key = (D, K, bool(uniform))
         buf = self._cdf_bufs.get(key)
         if buf is None or buf.shape[0] < B:
             if buf is not None and self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
@@ -317,15 +326,19 @@ class BitSwapCodec:
             if buf is not None and self._graphs:
                 torch.cuda.synchronize()   # no replay in flight while its graph is destroyed
                 self._graphs.clear()       # captured block steps hold pointers into the buffer that is going away
-            buf = self.backend.table_buffer(B, D, K)
+            try:
+                buf = self.backend.table_buffer(B, D, K, uniform)
+            except TypeError:                        # a backend without the hand-off choice (oracle stand-in)
+                buf = self.backend.table_buffer(B, D, K)
             self._cdf_bufs[key] = buf
         return buf if buf is None or buf.shape[0] == B else buf[:B]
 
     def _reserve_tables(self, B):
         """Size the cdf-row buffers for B chains now, so that no later, larger call replaces them under a captured step
         (ragged receivers start with the longest chain alone and grow)."""
-        self._cdf(B, self.Z, self.K)
-        self._cdf(B, self.X, 256)
+        for zs in {s is not None for s in self.zstep}:
+            self._cdf(B, self.Z, self.K, zs)
+        self._cdf(B, self.X, 256, self.xstep is not None)
 
     # ---- stream split helpers ---------------------------------------------------------------------
     def _on(self, stream):
@@ -363,7 +376,8 @@ class BitSwapCodec:
         ts = self._tables_stream((mu, scale))
         with self._on(ts), self.tl.span("tables_" + key):
             cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
-                                      out=self._cdf(mu.shape[0], mu.shape[1], K), step=step, status=state.status)
+                                      out=self._cdf(mu.shape[0], mu.shape[1], K, step is not None), step=step,
+                                      status=state.status)
         self._serial_waits_bulk()
         with self._on(self.serial):
             with self.tl.span("pop_" + key):

@@ -146,7 +146,8 @@ struct Bins<1> {
 };
 
 template <int NPL>
-__device__ __forceinline__ uint32_t bump_and_scan(Bins<NPL>& bn, int lane, int bits, bool& bad) {
+__device__ __forceinline__ uint32_t bump_and_scan(Bins<NPL>& bn, int lane, int bits, bool& bad, uint32_t* bumped_bin = nullptr,
+                                                  uint32_t* remnant = nullptr) {
     uint32_t tsum = NPL, best = 0;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -170,6 +171,8 @@ __device__ __forceinline__ uint32_t bump_and_scan(Bins<NPL>& bn, int lane, int b
     const bool mine = lane == first;
     bn.t[barg] += mine ? rem : 0u;
     bad = mine && ((int32_t)(mx + 1u + rem) < 1);
+    if (bumped_bin) *bumped_bin = (uint32_t)(first * NPL + barg);   // wave-uniform: which bin took the remnant, and how much
+    if (remnant) *remnant = rem;
     // exclusive prefix of the bumped per-lane sums: lanes after `first` shift by rem
     uint32_t excl = incl0 - tsum;
     if (lane > first) excl += rem;
@@ -182,7 +185,7 @@ __device__ __forceinline__ uint32_t trunc_u32(double x) { return (uint32_t)(int3
 // k_logistic: fused logistic CDF -> integer table, NPL = K/64 bins per lane
 // ------------------------------------------------------------------------------------------
 // output modes of k_logistic
-enum { M_ENCODE = 0, M_LINEAR = 1, M_LINEAR_VEC = 2, M_WAVE = 3 };
+enum { M_ENCODE = 0, M_LINEAR = 1, M_LINEAR_VEC = 2, M_WAVE = 3, M_PIVOT = 4 };
 
 // BS_LAYOUT_WAVE: dword offset of cdf entry j (K = 64*NPL entries) inside a row.  Register r = j/64 of
 // the popping wavefront holds entries 64r..64r+63 across its lanes; uint4 load i of lane l returns
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
                                                   uint32_t* __restrict__ out1, int64_t ld,
                                                   int32_t* __restrict__ status) {
     constexpr int K = NPL * 64;
-    __shared__ uint32_t stage[MODE == M_WAVE ? 4 * 64 * (NPL + 1) : 1];
+    __shared__ uint32_t stage[MODE == M_WAVE ? 4 * 64 * (NPL + 1) : 1];   // (M_PIVOT needs no transpose)
     const int lane = threadIdx.x & 63;
     const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (d >= D) return;
@@ -316,11 +319,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
         const bool dom = logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
 
         bool bad;
-        uint32_t c = bump_and_scan<NPL>(bn, lane, bits, bad);
+        uint32_t bumped = 0, rem = 0;
+        uint32_t c = bump_and_scan<NPL>(bn, lane, bits, bad, MODE == M_PIVOT ? &bumped : nullptr, MODE == M_PIVOT ? &rem : nullptr);
         bad = bad || !dom;
         if (status && (__ballot(bad) != 0ull || !okp) && lane == 0 && status[b] == BS_ST_OK) status[b] = BS_ST_BADTABLE;
 
-        if (MODE == M_WAVE) {
+        if (MODE == M_PIVOT) {
+            // BS_LAYOUT_PIVOT: the hand-off to k_rans_pop_pivot is ONE 8-byte word per lane -- the cumulative value at
+            // the lane's first bin (remnant included for the lanes behind the bumped one) and, in lanes 0 and 1, which bin
+            // took the remnant and how much.  The popping wavefront rebuilds the NPL bins of the one group its symbol falls
+            // into with the arithmetic of logistic_row: 512 B per row cross HBM instead of 4 (K + 64).
+            uint2 v;
+            v.x = c;
+            v.y = lane == 0 ? bumped : lane == 1 ? rem : 0u;
+            *reinterpret_cast<uint2*>(out0 + row * ld + lane * 2) = v;
+        } else if (MODE == M_WAVE) {
             // wave-native rows for k_rans_pop_wave: the K entries permuted as wave_offset(), then 64 pivot
             // words at [K, K+64) (see below).  The permutation is a 64 x NPL transpose:
             // it goes through a wave-private LDS tile (entry j at j + j/NPL: conflict-free writes, reads with
@@ -737,6 +750,160 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
         sh_sym[c64 * 64 + lane] = (int32_t)mysym;
         n -= o;
         if (n < 0) {  // popped below the bottom: garbage from here on (reads stay in bounds), reported below
+            st = BS_ST_UNDERFLOW;
+            n = 0;
+        }
+        wtop = ntop;
+        wa = na;
+        wb = nb;
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+    __syncthreads();
+    for (int dd = lane; dd < D; dd += 64) {
+        const int sy = sh_sym[dd];
+        const int64_t oo = (int64_t)b * D + dd;
+        sym_out[oo] = sy;
+        if (centres) centre_out[oo] = (float)centres[(int64_t)dd * c_stride + sy];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rans_pop_pivot: BS_LAYOUT_PIVOT rows (uniform-width bins, CDF spec 2), one wavefront per chain.
+//
+// The table kernel hands over 64 cumulative values per row (one per group of NPL bins) plus which bin took the remnant
+// and how much.  Per symbol: ballot(pivot <= m) names the group L; lanes 0 .. NPL-1 rebuild the cdf of its NPL bins and
+// lane NPL the last cdf of group L-1, each with exactly the operations logistic_row spends on that bin (own anchor
+// exponential, own geometric factor, residual of the stored endpoint, correctly rounded reciprocal) -- the truncated
+// differences are therefore the table's, and a 6-step scan on top of the pivot gives c_s and f_s.  About 2.5x the
+// instructions of k_rans_pop_wave per symbol, but 512 B of HBM traffic per row instead of 4352 B: at 400 chains the
+// row-reading pop kernel ran at the HBM roof (3.57 GB per launch in 0.57 ms) and nothing overlapped with it
+// (profiles/r03m_overlap2.txt); this one touches the L2-resident endpoint table and little else.
+// Endpoints of the group are fetched AFTER the group is known (data dependent) and consumed after the two exponentials
+// that do not need them; pivots and the 64 anchor endpoints of a row are prefetched PF rows ahead like the rows of
+// k_rans_pop_wave; (mu, scale, bin width) wait in registers per 64-symbol chunk.
+// ------------------------------------------------------------------------------------------
+template <int NPL, typename PT, int PF>
+__global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                       int32_t* __restrict__ len, int64_t cap,
+                                                       const uint32_t* __restrict__ piv, int64_t ld,
+                                                       const double* __restrict__ endpoints, int64_t e_stride,
+                                                       const double* __restrict__ step, const PT* __restrict__ mu,
+                                                       const PT* __restrict__ scale, int D, int bits, int quantbits,
+                                                       int32_t* __restrict__ sym_out, const double* __restrict__ centres,
+                                                       int64_t c_stride, float* __restrict__ centre_out,
+                                                       int32_t* __restrict__ status) {
+    constexpr int K = NPL * 64;
+    extern __shared__ int32_t sh_sym[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) {  // failed chain (a bad table among them): skipped, outputs well-defined
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t mask = (1u << bits) - 1u;
+    const double M = (double)((1ll << bits) - (1ll << quantbits));
+    int st = BS_ST_OK;
+    const uint2* prow = reinterpret_cast<const uint2*>(piv + (int64_t)b * D * ld) + lane;   // + d * ld / 2
+    const int64_t ld2 = ld / 2;
+    // this lane's role in the rebuild: bin `bi` of the symbol's group (lanes 0 .. NPL-1) or the last bin of the group
+    // below it (lane NPL); the other lanes shadow lane NPL and are never looked at
+    const bool is_bin = lane < NPL;
+    const int bi = is_bin ? lane : NPL - 1;
+
+    auto stack_window = [&](int top, int off) -> uint32_t {
+        const int i = top - 1 - off - lane;
+        return stk[max(i, 0)];
+    };
+    int wtop = n;
+    uint32_t wa = stack_window(wtop, 0), wb = stack_window(wtop, 64);
+
+    uint2 pv[PF];
+    double anc[PF];
+    int dl = D - 1;                                  // row the NEXT refill fetches
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        pv[u] = prow[(int64_t)max(dl, 0) * ld2];
+        anc[u] = endpoints[(int64_t)max(dl, 0) * e_stride + lane * NPL];
+        --dl;
+    }
+
+    int d = D - 1;
+    for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
+        const int idx = (wtop - n) + lane;  // 0..127
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wa);
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wb);
+        const uint32_t win = idx < 64 ? pa : pb;
+        const int ntop = n;
+        const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
+        // parameters of this chunk's 64 rows: lane k <- row c64*64 + k
+        const int64_t prm = (int64_t)b * D + c64 * 64 + lane;
+        const double mu_l = (double)mu[prm], sc_l = (double)scale[prm], h_l = step[c64 * 64 + lane];
+        const double rs_l = recip_scale(sc_l);
+        int o = 0;
+        uint32_t mysym = 0;
+        for (int g = 64 / PF - 1; g >= 0; --g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int dk = d & 63;
+                const uint32_t m = (uint32_t)h & mask;
+                const int L = __popcll(__ballot(pv[u].x <= m)) - 1;          // group of the symbol: 0..63 (c_0 = 0 <= m)
+                const int grp = is_bin ? L : max(L - 1, 0);
+                const int j = grp * NPL + bi;                                // this lane's bin
+                // its upper endpoint: data dependent, requested first, used last
+                const double e_j = endpoints[(int64_t)d * e_stride + min(j, K - 2)];
+                const double m_ = readlane_f64(mu_l, dk), rs = readlane_f64(rs_l, dk), hstep = readlane_f64(h_l, dk);
+                const double e_a = is_bin ? readlane_f64(anc[u], L) : readlane_f64(anc[u], max(L - 1, 0));
+                const uint32_t piv_L = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].x, L);
+                const uint32_t bumped = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 0);
+                const uint32_t rem = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 1);
+                // refill: the row PF steps ahead
+                pv[u] = prow[(int64_t)max(dl, 0) * ld2];
+                anc[u] = endpoints[(int64_t)max(dl, 0) * e_stride + lane * NPL];
+                --dl;
+                // logistic_row, one bin per lane
+                const double hr = hstep * rs;
+                const double A = det_exp(-((e_a - m_) * rs));
+                const double Q = det_exp(-((double)bi * hr));
+                const double r = e_j - fma((double)bi, hstep, e_a);
+                const double eps = r * rs;
+                const double uu = fma(-A, eps, A);
+                double c = recip_1_to_huge(fma(Q, uu, 1.0));
+                if (j == K - 1) c = 1.0;                                     // the last bin has no upper endpoint
+                // cdf of the bin below: lane-1 within the group, lane NPL for bin 0, nothing for the very first bin
+                double below = __shfl_up(c, 1, 64);
+                const double c_grp_below = readlane_f64(c, NPL);
+                if (lane == 0) below = L == 0 ? 0.0 : c_grp_below;
+                uint32_t f = trunc_u32((c - below) * M) + 1u;
+                if ((uint32_t)j == bumped) f += rem;
+                if (!is_bin) f = 0u;
+                const uint32_t incl = wave_incl_scan_add(f);                 // lanes >= NPL add nothing
+                const uint32_t cst = piv_L + incl - f;                       // c of this lane's bin
+                const int pos = __popcll(__ballot(is_bin && cst <= m));      // 1..NPL
+                const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)cst, pos - 1);
+                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)f, pos - 1);
+                mysym = (lane == dk) ? (uint32_t)(L * NPL + pos - 1) : mysym;
+                h = (uint64_t)fs * (h >> bits) + (uint64_t)(m - cs);
+                if ((uint32_t)(h >> 32) == 0u) {  // h < 2^32, mnist_compress.py:65
+                    h = (h << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, o);
+                    ++o;
+                }
+                --d;
+            }
+        }
+        sh_sym[c64 * 64 + lane] = (int32_t)mysym;
+        n -= o;
+        if (n < 0) {
             st = BS_ST_UNDERFLOW;
             n = 0;
         }
@@ -1299,7 +1466,8 @@ int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const d
     hipLaunchKernelGGL((k_logistic<NPL, PT, MODE, UNI>), grid, block, 0, st, endpoints, e_stride, step, m, s, sym, B, D, \
                        bits, quantbits, nb, out0, out1, ld, status)
     if (step) {  // CDF spec 2 (uniform bins); host dispatch guarantees NPL >= 4
-        if (mode == M_WAVE) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR), (NPL >= 4));
+        if (mode == M_PIVOT) BS_LAUNCH((NPL >= 4 ? M_PIVOT : M_LINEAR), (NPL >= 4));
+        else if (mode == M_WAVE) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR), (NPL >= 4));
         else if (mode == M_LINEAR_VEC) BS_LAUNCH((NPL >= 4 ? M_LINEAR_VEC : M_LINEAR), (NPL >= 4));
         else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, (NPL >= 4));
         else BS_LAUNCH(M_LINEAR, (NPL >= 4));
@@ -1360,6 +1528,26 @@ int dispatch_layer64(int K, const double* endpoints, int64_t e_stride, const dou
 
 }  // namespace
 
+template <typename PT>
+int dispatch_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* piv, int64_t ld,
+                       const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale, int B,
+                       int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres, int64_t c_stride,
+                       float* centre_out, int32_t* status, hipStream_t st) {
+    dim3 grid(B), block(64);
+    const PT* m = static_cast<const PT*>(mu);
+    const PT* s = static_cast<const PT*>(scale);
+#define BS_POPP(NPL, PF)                                                                                              \
+    hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, endpoints, \
+                       e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status)
+    if (K == 256) BS_POPP(4, 16);
+    else if (K == 512) BS_POPP(8, 16);
+    else if (K == 1024) BS_POPP(16, 16);
+    else if (K == 2048) BS_POPP(32, 16);
+    else return BS_EUNSUPPORTED;
+#undef BS_POPP
+    return launch_rc();
+}
+
 extern "C" {
 
 int bs_abi_version(void) { return BS_ABI_VERSION; }
@@ -1414,6 +1602,9 @@ int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* 
     } else if (layout == BS_LAYOUT_WAVE) {
         if (ld < K + 64 || K < 256) return BS_EINVAL;
         mode = M_WAVE;
+    } else if (layout == BS_LAYOUT_PIVOT) {      // 64 x (cumulative value, aux) per row: uniform bins (spec 2) only
+        if (ld < 128 || ld % 2 || K < 256 || !bin_step || (reinterpret_cast<uintptr_t>(cdf_out) & 7u)) return BS_EINVAL;
+        mode = M_PIVOT;
     } else {
         return BS_EINVAL;
     }
@@ -1502,6 +1693,25 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, cons
                            bits, sym_out, centres, c_stride, centre_out, status);
 #undef BS_POP
     return launch_rc();
+}
+
+int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* pivots, int64_t ld,
+                      const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu, const void* scale,
+                      int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres,
+                      int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
+    if (!head || !stack || !len || !pivots || !endpoints || !bin_step || !mu || !scale || !sym_out || !status || B < 0 ||
+        D < 0 || cap < 0 || bits < 1 || bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || c_stride < 0 ||
+        (centres && !centre_out) || ld < 128 || ld % 2 || (reinterpret_cast<uintptr_t>(pivots) & 7u))
+        return BS_EINVAL;
+    if (D % 64 != 0 || D > 16384) return BS_EUNSUPPORTED;      // whole 64-symbol chunks; a chain's symbols fit in LDS
+    if (B == 0 || D == 0) return BS_OK;
+    if (param_dtype == BS_PARAM_F32)
+        return dispatch_pop_pivot<float>(head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
+                                         bits, quantbits, sym_out, centres, c_stride, centre_out, status, S(stream));
+    if (param_dtype == BS_PARAM_F64)
+        return dispatch_pop_pivot<double>(head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
+                                          bits, quantbits, sym_out, centres, c_stride, centre_out, status, S(stream));
+    return BS_EINVAL;
 }
 
 int bs_layer_pop64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t cap, const double* endpoints,

@@ -10,15 +10,15 @@ import torch
 
 from . import build as _build
 
-ABI_VERSION = 3   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
+ABI_VERSION = 4   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
 PARAM_F32, PARAM_F64 = 0, 1
-LAYOUT_LINEAR, LAYOUT_WAVE = 0, 1
+LAYOUT_LINEAR, LAYOUT_WAVE, LAYOUT_PIVOT = 0, 1, 2
 
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
-    "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_gather_centres", "bs_layer_pop64",
+    "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_rans_pop_pivot", "bs_gather_centres", "bs_layer_pop64",
     "bs_layer_push64",
     "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
     "bs_small_k_gemm_f32", "bs_conv3_wino_f32", "bs_wino_gemm_f32",
@@ -60,6 +60,7 @@ def load():
     L.bs_rans_push.argtypes = [p, p, p, i64, p, p, i32, i32, i32, p, p]
     L.bs_rans_push_table.argtypes = [p, p, p, i64, p, i64, i64, i32, p, i32, i32, i32, i32, p, p]
     L.bs_rans_pop.argtypes = [p, p, p, i64, p, i64, i64, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
+    L.bs_rans_pop_pivot.argtypes = [p, p, p, i64, p, i64, p, i64, p, p, p, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
     L.bs_gather_centres.argtypes = [p, i64, p, i32, i32, i32, p, p]
     L.bs_layer_pop64.argtypes = [p, p, p, i64, p, i64, p, p, p, i64, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
     L.bs_layer_push64.argtypes = [p, p, p, i64, p, i64, p, p, p, i64, i32, p, i32, i32, i32, i32, i32, p, p]
@@ -149,6 +150,14 @@ def wave_supported(K):
     return K in (256, 512, 1024, 2048)
 
 
+PIVOT_LD = 128      # BS_LAYOUT_PIVOT: 64 x (cumulative value, aux) words per row
+
+
+def pivot_supported(K, D):
+    """bs_rans_pop_pivot takes K = 256 .. 2048 and whole 64-symbol chunks (uniform-width bins only: the caller checks)."""
+    return K in (256, 512, 1024, 2048) and D % 64 == 0 and D <= 16384
+
+
 def selftest():
     n = C.c_int64(-1)
     _check(load().bs_selftest(C.byref(n), _stream()), "bs_selftest")
@@ -199,13 +208,15 @@ def logistic_tables(endpoints, mu, scale, bits=31, quantbits=10, ld=None, out=No
     mu, scale = mu.contiguous(), scale.contiguous()
     if out is not None:
         ld = out.shape[-1]
-    ld = ld or (wave_ld(K) if layout == LAYOUT_WAVE else aligned_ld(K))
+    ld = ld or (wave_ld(K) if layout == LAYOUT_WAVE else PIVOT_LD if layout == LAYOUT_PIVOT else aligned_ld(K))
     if out is None:
         out = torch.empty((B, D, ld), dtype=torch.int32, device=mu.device)
     _check(load().bs_logistic_tables(_ptr(endpoints), es, _ptr(step), _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K,
                                      bits, quantbits, _ptr(out), ld, layout, _ptr(status), _stream()),
            "bs_logistic_tables")
     out.bs_layout = layout
+    if layout == LAYOUT_PIVOT:      # the pop kernel rebuilds rows from what the table kernel saw: keep it with the hand-off
+        out.bs_pivot_args = (endpoints, es, step, mu, scale, quantbits)
     return out
 
 
@@ -328,6 +339,8 @@ def rans_pop(state, cdf, K, bits=31, centres=None, B=None, layout=None):
     """Pop D symbols per chain.  Returns (sym [B,D] int32, z [B,D] float32 | None)."""
     _need_cuda(cdf, centres)
     layout = table_layout(cdf, K) if layout is None else layout
+    if layout == LAYOUT_PIVOT:
+        return rans_pop_pivot(state, cdf, K, bits, centres=centres)
     if not cdf.is_contiguous():
         cdf = cdf.contiguous()
     ld = cdf.shape[-1]
@@ -344,6 +357,26 @@ def rans_pop(state, cdf, K, bits=31, centres=None, B=None, layout=None):
     _check(load().bs_rans_pop(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(cdf),
                               chain_stride, ld, layout, B, D, K, bits, _ptr(sym), _ptr(centres), cs, _ptr(z),
                               _ptr(state.status), _stream()), "bs_rans_pop")
+    return sym, z
+
+
+def rans_pop_pivot(state, piv, K, bits=31, centres=None):
+    """Pop D symbols per chain from BS_LAYOUT_PIVOT rows made by logistic_tables(layout=LAYOUT_PIVOT): the kernel rebuilds
+    the symbol's group of bins from the (endpoints, step, mu, scale) the table kernel used (remembered on `piv`).
+    Returns (sym [B,D] int32, z [B,D] float32 | None)."""
+    endpoints, es, step, mu, scale, quantbits = piv.bs_pivot_args
+    _need_cuda(piv, centres, endpoints, step, mu, scale)
+    assert piv.is_contiguous() and piv.dim() == 3
+    B, D, ld = piv.shape
+    sym = torch.empty((B, D), dtype=torch.int32, device=piv.device)
+    z, cs = None, 0
+    if centres is not None:
+        centres, cs = _row_stride(centres, K)
+        z = torch.empty((B, D), dtype=torch.float32, device=piv.device)
+    _check(load().bs_rans_pop_pivot(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(piv), ld,
+                                    _ptr(endpoints), es, _ptr(step), _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K, bits,
+                                    quantbits, _ptr(sym), _ptr(centres), cs, _ptr(z), _ptr(state.status), _stream()),
+           "bs_rans_pop_pivot")
     return sym, z
 
 

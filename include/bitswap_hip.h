@@ -39,8 +39,9 @@ extern "C" {
 #endif
 
 /* 2: layout argument, BS_LAYOUT_WAVE pivot words, conv-stack epilogue entry points
- * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop64 / _push64 */
-#define BS_ABI_VERSION 3
+ * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop64 / _push64
+ * 4: BS_LAYOUT_PIVOT and bs_rans_pop_pivot (64 cumulative values per row instead of the whole row) */
+#define BS_ABI_VERSION 4
 /* highest version of the deterministic logistic-CDF specification this library implements;
  * a stream written with one CDF spec can only be decoded with the same one.
  *   spec 1: one float64 sigmoid per bin endpoint (bin_step == NULL); any bins.
@@ -72,9 +73,16 @@ extern "C" {
  *                     c_0..c_{K-1} permuted so that a 64-lane wavefront's 16-byte loads leave entries
  *                     64r..64r+63 in register r across its lanes (entry j at dword ((j/256)*64 + j%64)*4
  *                     + (j/64)%4), followed at [K, K+64) by the pivot words: word r = c_{64r} for
- *                     r < K/64, word K/64 = c_K = 2^bits, the remaining words 0xffffffff. */
+ *                     r < K/64, word K/64 = c_K = 2^bits, the remaining words 0xffffffff.
+ *   BS_LAYOUT_PIVOT   internal hand-off format between bs_logistic_tables and bs_rans_pop_pivot for rows of
+ *                     uniform-width bins (CDF spec 2, bin_step != NULL, K = 256*n; ld >= 128 even, 8-byte aligned rows):
+ *                     64 pairs of words; pair l = (c_{l K/64}, aux_l) -- the cumulative value at the first bin of group
+ *                     l -- with aux_0 = the bin that took the remnant 2^bits - sum f (mnist_compress.py:36) and aux_1 =
+ *                     that remnant.  512 bytes per row cross HBM instead of 4 (K + 64): the popping wavefront rebuilds
+ *                     the K/64 bins of the one group its symbol falls into from (endpoints, bin_step, mu, scale). */
 #define BS_LAYOUT_LINEAR 0
 #define BS_LAYOUT_WAVE 1
+#define BS_LAYOUT_PIVOT 2
 
 int bs_abi_version(void);
 int bs_cdf_spec(void);
@@ -103,7 +111,7 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
  *              of rows whose endpoints are an arithmetic progression up to rounding (every latent layer but
  *              the top one: discretization.py:81-83,105-118) and selects CDF spec 2 (K >= 256).  The caller
  *              decides from the bins alone, so sender and receiver agree.
- *   cdf_out [B,D,ld] in `layout` (BS_LAYOUT_LINEAR or BS_LAYOUT_WAVE).
+ *   cdf_out [B,D,ld] in `layout` (BS_LAYOUT_LINEAR, BS_LAYOUT_WAVE or BS_LAYOUT_PIVOT).
  *   status [B] (nullable) receives BS_ST_BADTABLE for a chain with a non-finite mu, a scale that is not a
  *              positive finite number, or a row whose remnant drives a frequency below 1 (mnist_compress.py:46-47).
  * The CDF is evaluated in float64 by the deterministic routine of DESIGN.md (BS_CDF_SPEC);
@@ -157,6 +165,19 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
                 const uint32_t* cdf, int64_t chain_stride, int64_t ld, int layout, int B, int D, int K,
                 int bits, int32_t* sym_out, const double* centres, int64_t c_stride, float* centre_out,
                 int32_t* status, void* stream);
+
+/*
+ * bs_rans_pop_pivot -- bs_rans_pop on BS_LAYOUT_PIVOT rows (the production pair of the batched codec for every table
+ * of uniform-width bins): the same ANS.decode (mnist_compress.py:58-68), the same symbols and words; the integer row of
+ * a symbol's group is rebuilt inside the kernel with the operations bs_logistic_tables spent on it (the SAME endpoints,
+ * bin_step, mu, scale, bits, quantbits must be passed), so only 64 cumulative values per row travel through HBM.
+ * pivots [B,D,ld] as written by bs_logistic_tables(layout = BS_LAYOUT_PIVOT); D % 64 == 0, D <= 16384.
+ */
+int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* pivots, int64_t ld,
+                      const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+                      const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits,
+                      int32_t* sym_out, const double* centres, int64_t c_stride, float* centre_out, int32_t* status,
+                      void* stream);
 
 /*
  * BS_FORMAT_WAVE64 -- opt-in 64-state stream format (no reference counterpart).  A chain owns 64 independent rANS

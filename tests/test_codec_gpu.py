@@ -341,7 +341,8 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime):
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap))
     assert codec.cdf_spec == 2 and all(s is not None for s in codec.zstep[:-1]) and codec.zstep[-1] is None
     from bitswap_amd import hip
-    assert codec.backend.table_layout(codec.K) == hip.LAYOUT_WAVE
+    assert codec.backend.table_layout(codec.K, True, codec.Z) == hip.LAYOUT_PIVOT      # the production hand-off (round 3)
+    assert codec.backend.table_layout(codec.K, False, codec.Z) == hip.LAYOUT_WAVE      # top layer / prior: whole rows
     rec, plain_net = record_nets(codec)
     with _Count("wino_fused") as wf, _Count("wino_gemm") as wg, _NoBlas() as nb:
         state, met = codec.compress(images.to(DEV))

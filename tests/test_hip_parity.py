@@ -588,6 +588,62 @@ def test_degenerate_parameters_are_flagged(spec):
     assert st2.status.cpu().tolist() == [0, h.ST_BADTABLE, h.ST_BADTABLE, h.ST_BADTABLE, 0]
 
 
+@pytest.mark.parametrize("K,D,ptype,shared_row", [(1024, 192, np.float32, False), (256, 128, np.float32, True),
+                                                   (512, 64, np.float64, False), (2048, 64, np.float32, False),
+                                                   (1024, 2048, np.float32, False)])
+def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_row):
+    """BS_LAYOUT_PIVOT (64 cumulative values per row; bs_rans_pop_pivot rebuilds the symbol's group of bins with the table
+    kernel's arithmetic) against BS_LAYOUT_WAVE (the whole integer row in HBM) and against the oracle: same symbols, same
+    words, same centres -- peaked and flat rows, remnant bumps inside and outside the popped group, the first and the last
+    bin, float32 and float64 parameters, the pixel form (one endpoint row shared by every dim), and the bench's own row
+    count; a chain flagged by the table kernel is skipped by both."""
+    from bitswap_amd.bins import uniform_step
+    h = hip()
+    q = int(np.log2(K))
+    rng = np.random.RandomState(K + D)
+    B = 6
+    if shared_row:
+        e = np.stack([np.linspace(-1.0, 1.0, K + 1)[1:-1]] * D)
+        cen = np.stack([np.linspace(-1.0, 1.0, K)] * D)
+    else:
+        lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
+        e = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
+        cen = np.stack([np.linspace(a, b, K) for a, b in zip(lo, hi)])
+    step = dev(uniform_step(e))
+    mu = (rng.randn(B, D) * (0.4 if shared_row else 1.5)).astype(ptype)
+    sc = rng.uniform(0.004 if shared_row else 0.05, 1.0, (B, D)).astype(ptype)
+    sc[0, :] = 0.004 if shared_row else 0.02            # a chain of peaked rows: most bins f = 1
+    mu[1, :] = -50.0                                    # all mass in the first bin
+    mu[2, :] = 50.0                                     # ... in the last one
+    e_d = dev(e[:1]).expand(D, -1) if shared_row else dev(e)
+    c_d = dev(cen)
+    states = [reference_init_state(3000 + 12 * D // 10, seed=b) for b in range(B)]
+    res = {}
+    for layout in (h.LAYOUT_WAVE, h.LAYOUT_PIVOT):
+        st = h.RansState.from_lists(states, cap=8000 + 2 * D, device=DEV)
+        tab = h.logistic_tables(e_d, dev(mu), dev(sc), 31, q, layout=layout, step=step, status=st.status)
+        assert tab.shape[-1] == (h.PIVOT_LD if layout == h.LAYOUT_PIVOT else K + 64)
+        sym, z = h.rans_pop(st, tab, K, 31, centres=c_d)
+        st.check()
+        res[layout] = (sym.cpu().numpy(), z.cpu().numpy(), st.to_lists())
+    a, b = res[h.LAYOUT_WAVE], res[h.LAYOUT_PIVOT]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert (a[0][1] == 0).all() and (a[0][2] >= K - 2).mean() > 0.9      # the mass sits where the mean is
+    # ... and the oracle (CDF spec 2) agrees
+    for bb in (0, 2, 3):
+        ost = O.Stack(states[bb], cap=8000 + 2 * D)
+        osym, rc = O.layer_pop(ost, e, mu[bb].astype(np.float64), sc[bb].astype(np.float64), 31, q, O.MODE_DET2)
+        assert rc == O.OK and np.array_equal(osym, b[0][bb]) and ost.tolist() == b[2][bb]
+    # a degenerate chain: flagged by the table kernel, skipped by the pop, the others untouched by it
+    sc2 = sc.copy()
+    sc2[4, 7] = 0.0
+    st = h.RansState.from_lists(states, cap=8000 + 2 * D, device=DEV)
+    tab = h.logistic_tables(e_d, dev(mu), dev(sc2), 31, q, layout=h.LAYOUT_PIVOT, step=step, status=st.status)
+    sym, _ = h.rans_pop(st, tab, K, 31)
+    assert st.status.cpu().tolist() == [0, 0, 0, 0, h.ST_BADTABLE, 0] and st.to_lists()[4] == states[4]
+    assert np.array_equal(sym.cpu().numpy()[[0, 1, 2, 3, 5]], b[0][[0, 1, 2, 3, 5]])
+
+
 def test_cdf_spec2_domain_is_flagged():
     """a row whose anchors leave the +-700 domain of det_exp (scale tiny against the bin width -- reachable
     through the C ABI, never by the reference's models) is outside CDF spec 2: every flavour flags BS_ST_BADTABLE for the

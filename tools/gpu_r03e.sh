@@ -1,7 +1,7 @@
 #!/bin/bash
 TAG=${1:-r03e}; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
 timeout 600 python -m pytest tests -m gpu -q -x --timeout 300 -k "wino_gemm or own_gemm" > $OUT/${TAG}_pytest.log 2>&1; echo "pytest exit $?"; tail -5 $OUT/${TAG}_pytest.log
-timeout 600 python tools/gemm_probe.py --knobs > $OUT/${TAG}_gemm_probe.txt 2>&1; echo "probe exit $?"; grep -v Warning $OUT/${TAG}_gemm_probe.txt
+timeout 600 python tools/gemm_probe.py > $OUT/${TAG}_gemm_probe.txt 2>&1; echo "probe exit $?"; grep -v Warning $OUT/${TAG}_gemm_probe.txt
 ( cd /tmp && rm -rf pv && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES -d /tmp/pv -o pv --output-format csv -- python $R/tools/gemm_probe.py --quick --only-own > /dev/null 2>$OUT/${TAG}_pmc.err )
 python - <<PY
 import csv, glob, collections
