@@ -52,7 +52,7 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # the shipped code object: VALU instructions of the per-row loop + 3 extra slots per quarter-rate v_rcp_f64.  Under
 # sustained float64 load the chip runs at about 4/4.9 of the nominal clock (tools/probes/instr_rate.hip), so 0.82 here is the
 # practical ceiling
-VALU_SLOTS_PER_ROW = {2: 399, 1: 648}   # CDF spec 2 (uniform bins) / spec 1
+VALU_SLOTS_PER_ROW = {2: 381, 1: 648}   # CDF spec 2 (uniform bins, BS_LAYOUT_PIVOT hand-off; 403 with whole rows) / spec 1
 # float64 flops of one row (64 lanes x [2 per fma + 1 per add/mul/rcp] in that loop): SURVEY 8(d) asks for the FP64
 # utilisation next to the HBM figure.  Vector FP64 peak 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
 FP64_FLOPS_PER_ROW = {2: 353 * 64, 1: 699 * 64}
@@ -335,23 +335,26 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
         sec, cnt = excl if excl else (shared_sec, shared_cnt)
         avg = sec / cnt
         spec = args.cdf_spec if any(s is not None for s in codec.codecs[0].zstep) else 1
+        pivot = bool(spec == 2 and getattr(codec.codecs[0].backend, "pivot", False) and args.format == "reference")
         slots = VALU_SLOTS_PER_ROW[spec] if (Kb == 1024 and args.format == "reference") else None
+        if slots is not None and spec == 2 and not pivot:
+            slots = 403                                   # whole-row hand-off (BITSWAP_PIVOT=0)
         kname = (f"k_layer64<16,float,{'uniform' if spec == 2 else 'generic'},pop> (logistic CDF -> integer table -> rANS pop in "
                  f"one launch, rows in registers, CDF spec {spec})" if args.format == "wave64" else
-                 f"k_logistic<16,float,decode,{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> integer cdf "
-                 f"rows, CDF spec {spec})")
+                 f"k_logistic<16,float,{'pivot' if pivot else 'decode'},{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> "
+                 f"integer table -> {'64 cumulative values per row for bs_rans_pop_pivot' if pivot else 'cdf rows'}, CDF spec {spec})")
         # --- HBM side, on bytes that move.  SURVEY 8(d) prices a z-row at (K-1)*8 + 12 B because it counts the [Z, K-1]
         # float64 endpoint table once per BLOCK; a launch over `chains` blocks reads that table from HBM once (the rest are
-        # L2 hits), so the batched algorithmic bytes are table + 12 B/row (+ the cdf-row hand-off the split design writes:
-        # counted by the PMC figure, not by the algorithm)
+        # L2 hits), so the batched algorithmic bytes are table + 12 B/row + the hand-off to the pop kernel (512 B/row of
+        # cumulative values with BS_LAYOUT_PIVOT; a whole 4 (K + 64) B row before: counted by the PMC figure)
         table_bytes = Z * (Kb - 1) * 8
-        alg_batched = int(table_bytes + rows * 12)
+        alg_batched = int(table_bytes + rows * (12 + (512 if pivot else 0)))
         survey_alg = int(rows * ((Kb - 1) * 8 + 12))
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp) and args.format == "reference":
             try:
-                per_row = json.load(open(tp)).get(name, {}).get("k_logistic_decode_bytes_per_row")
+                per_row = json.load(open(tp)).get(name, {}).get("k_logistic_pivot_bytes_per_row" if pivot else "k_logistic_decode_bytes_per_row")
                 traffic = None if per_row is None else int(per_row * rows)   # PMC bytes/row x rows of one launch
             except Exception:
                 traffic = None
@@ -363,9 +366,12 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                "traffic_bytes_per_launch": traffic,
                "traffic_achieved": None if traffic is None else round(traffic / avg / 1e9, 1),
                "traffic_frac": None if traffic is None else round(traffic / avg / 1e9 / HBM_PEAK_GBPS, 4),
-               "note": "alg = endpoint table once per launch + 12 B/row (mu, scale, symbol); traffic = PMC FETCH x2 + WRITE "
-                       "(profiles/traffic.json), 98 % of it the cdf-row hand-off to k_rans_pop_wave; SURVEY 8(d)'s per-block "
-                       f"count would be {survey_alg} B per launch, of which all but the first table pass are L2 hits"}
+               "note": "alg = endpoint table once per launch + 12 B/row (mu, scale, symbol)"
+                       + (" + the 512 B/row hand-off of cumulative values to bs_rans_pop_pivot" if pivot else "")
+                       + "; traffic = PMC FETCH x2 + WRITE (profiles/traffic.json)"
+                       + ("" if pivot else ", 98 % of it the cdf-row hand-off to k_rans_pop_wave")
+                       + f"; SURVEY 8(d)'s per-block count would be {survey_alg} B per launch, of which all but the first table "
+                         "pass are L2 hits"}
         if slots is not None:
             ach = rows * slots / avg / 1e9
             roof = {"kernel": kname, "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINSTR, 1),

@@ -786,6 +786,14 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
 // that do not need them; pivots and the 64 anchor endpoints of a row are prefetched PF rows ahead like the rows of
 // k_rans_pop_wave; (mu, scale, bin width) wait in registers per 64-symbol chunk.
 // ------------------------------------------------------------------------------------------
+// lane i <- lane i-1 of the whole wavefront (DPP wave_shr:1; lane 0 keeps its value)
+__device__ __forceinline__ double wave_shr1_f64(double v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 template <int NPL, typename PT, int PF>
 __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
                                                        int32_t* __restrict__ len, int64_t cap,
@@ -797,6 +805,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                                                        int64_t c_stride, float* __restrict__ centre_out,
                                                        int32_t* __restrict__ status) {
     constexpr int K = NPL * 64;
+    constexpr bool ONE_EXP = NPL <= 16;      // both exponentials of a symbol in ONE instruction stream (lower / upper half-wave)
     extern __shared__ int32_t sh_sym[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -814,12 +823,14 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
     const uint32_t mask = (1u << bits) - 1u;
     const double M = (double)((1ll << bits) - (1ll << quantbits));
     int st = BS_ST_OK;
-    const uint2* prow = reinterpret_cast<const uint2*>(piv + (int64_t)b * D * ld) + lane;   // + d * ld / 2
     const int64_t ld2 = ld / 2;
-    // this lane's role in the rebuild: bin `bi` of the symbol's group (lanes 0 .. NPL-1) or the last bin of the group
-    // below it (lane NPL); the other lanes shadow lane NPL and are never looked at
+    // this lane's role in the rebuild.  Lanes 0 .. NPL-1: bin `bi` of the symbol's group; lane NPL: the last bin of the group
+    // below it.  With ONE_EXP the upper half-wave evaluates the geometric factors Q_b = exp(-b h/scale) in the same
+    // instructions in which the lower half evaluates the anchors exp(-t_a); lane 32 + k serves lane k.
     const bool is_bin = lane < NPL;
-    const int bi = is_bin ? lane : NPL - 1;
+    const int role = ONE_EXP ? (lane & 31) : lane;
+    const int bi = role < NPL ? role : NPL - 1;
+    const bool q_lane = ONE_EXP && lane >= 32;
 
     auto stack_window = [&](int top, int off) -> uint32_t {
         const int i = top - 1 - off - lane;
@@ -830,13 +841,17 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
 
     uint2 pv[PF];
     double anc[PF];
-    int dl = D - 1;                                  // row the NEXT refill fetches
+    const uint2* pp = reinterpret_cast<const uint2*>(piv + (int64_t)b * D * ld) + (int64_t)(D - 1) * ld2 + lane;   // row of the next refill
+    const double* ap = endpoints + (int64_t)(D - 1) * e_stride + lane * NPL;
+    int dl = D - 1;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        pv[u] = prow[(int64_t)max(dl, 0) * ld2];
-        anc[u] = endpoints[(int64_t)max(dl, 0) * e_stride + lane * NPL];
+        pv[u] = *pp;
+        anc[u] = *ap;
+        if (dl > 0) { pp -= ld2; ap -= e_stride; }
         --dl;
     }
+    const double* erow = endpoints + (int64_t)(D - 1) * e_stride;   // endpoint row of the symbol being popped
 
     int d = D - 1;
     for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
@@ -848,8 +863,9 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
         const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
         // parameters of this chunk's 64 rows: lane k <- row c64*64 + k
         const int64_t prm = (int64_t)b * D + c64 * 64 + lane;
-        const double mu_l = (double)mu[prm], sc_l = (double)scale[prm], h_l = step[c64 * 64 + lane];
-        const double rs_l = recip_scale(sc_l);
+        const double mu_l = (double)mu[prm], h_l = step[c64 * 64 + lane];
+        const double rs_l = recip_scale((double)scale[prm]);
+        const double hr_l = h_l * rs_l;
         int o = 0;
         uint32_t mysym = 0;
         for (int g = 64 / PF - 1; g >= 0; --g) {
@@ -858,36 +874,51 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                 const int dk = d & 63;
                 const uint32_t m = (uint32_t)h & mask;
                 const int L = __popcll(__ballot(pv[u].x <= m)) - 1;          // group of the symbol: 0..63 (c_0 = 0 <= m)
-                const int grp = is_bin ? L : max(L - 1, 0);
-                const int j = grp * NPL + bi;                                // this lane's bin
+                const int Lb = max(L - 1, 0);
+                const int j = (is_bin ? L : Lb) * NPL + bi;                  // this lane's bin (lanes 0 .. NPL)
                 // its upper endpoint: data dependent, requested first, used last
-                const double e_j = endpoints[(int64_t)d * e_stride + min(j, K - 2)];
+                const double e_j = erow[min(j, K - 2)];
+                erow -= d > 0 ? e_stride : 0;
                 const double m_ = readlane_f64(mu_l, dk), rs = readlane_f64(rs_l, dk), hstep = readlane_f64(h_l, dk);
-                const double e_a = is_bin ? readlane_f64(anc[u], L) : readlane_f64(anc[u], max(L - 1, 0));
+                const double hr = readlane_f64(hr_l, dk);
+                const double eL = readlane_f64(anc[u], L), eLb = readlane_f64(anc[u], Lb);
+                const double e_a = is_bin ? eL : eLb;
                 const uint32_t piv_L = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].x, L);
                 const uint32_t bumped = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 0);
                 const uint32_t rem = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 1);
                 // refill: the row PF steps ahead
-                pv[u] = prow[(int64_t)max(dl, 0) * ld2];
-                anc[u] = endpoints[(int64_t)max(dl, 0) * e_stride + lane * NPL];
+                pv[u] = *pp;
+                anc[u] = *ap;
+                if (dl > 0) { pp -= ld2; ap -= e_stride; }
                 --dl;
                 // logistic_row, one bin per lane
-                const double hr = hstep * rs;
-                const double A = det_exp(-((e_a - m_) * rs));
-                const double Q = det_exp(-((double)bi * hr));
+                double A, Q;
+                if (ONE_EXP) {
+                    const double x = det_exp(q_lane ? -((double)bi * hr) : -((e_a - m_) * rs));
+                    A = x;
+                    Q = __shfl(x, lane | 32, 64);                            // lane k < 32 <- lane 32 + k
+                } else {
+                    A = det_exp(-((e_a - m_) * rs));
+                    Q = det_exp(-((double)bi * hr));
+                }
                 const double r = e_j - fma((double)bi, hstep, e_a);
                 const double eps = r * rs;
                 const double uu = fma(-A, eps, A);
                 double c = recip_1_to_huge(fma(Q, uu, 1.0));
                 if (j == K - 1) c = 1.0;                                     // the last bin has no upper endpoint
                 // cdf of the bin below: lane-1 within the group, lane NPL for bin 0, nothing for the very first bin
-                double below = __shfl_up(c, 1, 64);
+                double below = wave_shr1_f64(c);
                 const double c_grp_below = readlane_f64(c, NPL);
                 if (lane == 0) below = L == 0 ? 0.0 : c_grp_below;
                 uint32_t f = trunc_u32((c - below) * M) + 1u;
                 if ((uint32_t)j == bumped) f += rem;
                 if (!is_bin) f = 0u;
-                const uint32_t incl = wave_incl_scan_add(f);                 // lanes >= NPL add nothing
+                uint32_t incl = f;                                           // inclusive scan over the NPL bins
+                incl += dpp_or0<0x111, 0xf>(incl);
+                incl += dpp_or0<0x112, 0xf>(incl);
+                if (NPL > 4) incl += dpp_or0<0x114, 0xf>(incl);
+                if (NPL > 8) incl += dpp_or0<0x118, 0xf>(incl);
+                if (NPL > 16) incl += dpp_or0<0x142, 0xa>(incl);
                 const uint32_t cst = piv_L + incl - f;                       // c of this lane's bin
                 const int pos = __popcll(__ballot(is_bin && cst <= m));      // 1..NPL
                 const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)cst, pos - 1);

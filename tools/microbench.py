@@ -76,6 +76,18 @@ def main():
             r[f"spec{spec}"] = dict(tables_wave_s=t_tab, fc_s=t_fc, pop_wave_s=float(np.median(tp)),
                                     push_s=float(np.median(tq)), tables_alg_GBps=alg / t_tab / 1e9,
                                     fc_alg_GBps=alg / t_fc / 1e9, ns_per_row_tables=t_tab / rows * 1e9)
+            if stp is not None:      # the production hand-off for uniform bins: 64 cumulative values per row
+                pcdf = torch.empty((B, D, hip.PIVOT_LD), dtype=torch.int32, device=dev)
+                t_ptab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=pcdf, layout=hip.LAYOUT_PIVOT, step=stp,
+                                                            status=st.status), args.iters)
+                tables = hip.logistic_tables(e, mu, sc, 31, q, out=pcdf, layout=hip.LAYOUT_PIVOT, step=stp, status=st.status)
+                tpp = []
+                for _ in range(args.iters):
+                    tpp.append(timeit(lambda: hip.rans_pop(st, tables, K), 1, 0))
+                    hip.rans_push(st, fo[0], fo[1])
+                st.check()
+                r[f"spec{spec}"].update(tables_pivot_s=t_ptab, pop_pivot_s=float(np.median(tpp)),
+                                        handoff_bytes_per_row={"wave": 4 * (K + 64), "pivot": 4 * hip.PIVOT_LD})
             # 64-state format: table + rANS step fused, one launch per coding operation
             np.random.seed(1)
             words = np.random.randint(1 << 16, (1 << 32) - 1, size=(B, 64, 160), dtype=np.uint32)

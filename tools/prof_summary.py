@@ -59,23 +59,32 @@ def pmc(d, counter, out):
 
 
 def traffic(fetch_json, write_json, workload, out, rows_per_launch):
-    """HBM bytes per launch of the roofline kernel (fused logistic -> cdf rows, decode flavour, K = 1024),
-    corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: counters are in KiB,
-    FETCH_SIZE under-reports wide coalesced reads by exactly 2x (doubled here), WRITE_SIZE taken as is."""
-    def per(path, counter):
+    """HBM bytes per launch of the roofline kernel (fused logistic -> integer table, decode side, K = 1024), corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: counters are in KiB, FETCH_SIZE under-reports wide
+    coalesced reads by exactly 2x (doubled here), WRITE_SIZE taken as is.  Both hand-off flavours when present: whole rows
+    (k_logistic<16, float, 3, ...>: BS_LAYOUT_WAVE) and 64 cumulative values per row (<16, float, 4, ...>: BS_LAYOUT_PIVOT),
+    and the pop kernels that read them back."""
+    def per(path, counter, prefix):
         d = json.load(open(path))
         for k, v in d.items():
-            if k.startswith("void k_logistic<16, float, 3"):   # decode flavour, wave layout (spec 2: "..., 3, true>")
+            if k.startswith(prefix):
                 return v[f"{counter}_per_dispatch"] * 1024.0, v["dispatches"]
         return None, 0
-    f, nf = per(fetch_json, "FETCH_SIZE")
-    w, nw = per(write_json, "WRITE_SIZE")
     res = json.load(open(out)) if os.path.exists(out) else {}
     rows = float(rows_per_launch)
-    res[workload] = {"k_logistic_decode_bytes_per_launch": None if f is None or w is None else int(2 * f + w),
-                     "k_logistic_decode_bytes_per_row": None if f is None or w is None else (2 * f + w) / rows,
-                     "rows_per_launch": int(rows), "fetch_bytes_raw": f, "fetch_correction": 2.0, "write_bytes": w, "dispatches": [nf, nw],
-                     "source": [os.path.basename(fetch_json), os.path.basename(write_json)]}
+    entry = res.get(workload, {})
+    entry.update({"rows_per_launch": int(rows), "fetch_correction": 2.0, "source": [os.path.basename(fetch_json), os.path.basename(write_json)]})
+    for tag, prefix in (("decode", "void k_logistic<16, float, 3, true"), ("pivot", "void k_logistic<16, float, 4, true"),
+                        ("pop_wave", "void k_rans_pop_wave<16"), ("pop_pivot", "void k_rans_pop_pivot<16")):
+        f, nf = per(fetch_json, "FETCH_SIZE", prefix)
+        w, nw = per(write_json, "WRITE_SIZE", prefix)
+        if f is None or w is None:
+            continue
+        name = f"k_logistic_{tag}" if tag in ("decode", "pivot") else f"k_rans_{tag}"
+        entry[f"{name}_bytes_per_launch"] = int(2 * f + w)
+        entry[f"{name}_bytes_per_row"] = (2 * f + w) / rows
+        entry[f"{name}_fetch_bytes_raw"], entry[f"{name}_write_bytes"], entry[f"{name}_dispatches"] = f, w, [nf, nw]
+    res[workload] = entry
     json.dump(res, open(out, "w"), indent=1)
     print(res[workload])
 
