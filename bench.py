@@ -335,7 +335,10 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
         sec, cnt = excl if excl else (shared_sec, shared_cnt)
         avg = sec / cnt
         spec = args.cdf_spec if any(s is not None for s in codec.codecs[0].zstep) else 1
-        pivot = bool(spec == 2 and getattr(codec.codecs[0].backend, "pivot", False) and args.format == "reference")
+        from bitswap_amd import hip as _hip
+        be = codec.codecs[0].backend
+        pivot = bool(spec == 2 and args.format == "reference" and hasattr(be, "table_layout")
+                     and be.table_layout(Kb, True, Z, int(rows // Z)) == _hip.LAYOUT_PIVOT)
         slots = VALU_SLOTS_PER_ROW[spec] if (Kb == 1024 and args.format == "reference") else None
         if slots is not None and spec == 2 and not pivot:
             slots = 403                                   # whole-row hand-off (BITSWAP_PIVOT=0)

@@ -37,22 +37,29 @@ class HipBackend:
     def new_state(self, states, cap):
         return hip.RansState.from_lists(states, cap=cap, device=self.device)
 
-    # cdf rows are an internal hand-off between two of our kernels.  Rows of uniform-width bins (CDF spec 2: every latent
-    # layer below the top one and the pixels) travel as 64 cumulative values per row and the pop kernel rebuilds the one
-    # group of bins it needs (BS_LAYOUT_PIVOT, 512 B per row instead of 4 (K + 64): the row-reading pop kernel ran at the HBM
-    # roof and nothing overlapped with it); other tables use the wave-native rows whenever the pop kernel has them
-    # (K = 256..2048), the reference's linear rows otherwise.  BITSWAP_PIVOT=0 keeps whole rows everywhere.
+    # cdf rows are an internal hand-off between two of our kernels (never part of a stream: both forms pop the same
+    # symbols).  Whole integer rows in the wave-native layout whenever the pop kernel has it (K = 256..2048; the reference's
+    # linear rows otherwise) -- until a launch's rows add up to gigabytes: from `pivot_min_bytes` on, rows of uniform-width
+    # bins (CDF spec 2) travel as 64 cumulative values and the pop kernel rebuilds the one group of bins it needs
+    # (BS_LAYOUT_PIVOT, 512 B per row instead of 4 (K + 64)).  At 400 chains x 2048 dims the row-reading pop kernel sits at
+    # the HBM roof (3.57 GB in 0.57 ms) and nothing overlaps with it; the rebuilding one takes 1.0 ms of instruction issue on
+    # 400 SIMDs and leaves HBM to the other chain group's kernels.  With few chains the rows are no HBM problem and the
+    # shorter pop wins (100 chains: 27.9 vs 36.7 ms per step, profiles/r03p).  BITSWAP_PIVOT=0: whole rows always.
     pivot = os.environ.get("BITSWAP_PIVOT", "1") == "1"
+    pivot_min_bytes = int(float(os.environ.get("BITSWAP_PIVOT_MIN_BYTES", "2e9")))
 
-    def table_layout(self, K, uniform=False, D=64):
-        if uniform and self.pivot and hip.pivot_supported(K, D):
+    def table_layout(self, K, uniform=False, D=64, B=1):
+        if (uniform and self.pivot and hip.pivot_supported(K, D)
+                and int(B) * int(D) * 4 * (K + 64) >= self.pivot_min_bytes):
             return hip.LAYOUT_PIVOT
         return hip.LAYOUT_WAVE if hip.wave_supported(K) else hip.LAYOUT_LINEAR
 
     def table_buffer(self, B, D, K, uniform=False):
-        layout = self.table_layout(K, uniform, D)
+        layout = self.table_layout(K, uniform, D, B)
         ld = hip.PIVOT_LD if layout == hip.LAYOUT_PIVOT else hip.wave_ld(K) if layout == hip.LAYOUT_WAVE else hip.aligned_ld(K)
-        return torch.empty((B, D, ld), dtype=torch.int32, device=self.device)
+        t = torch.empty((B, D, ld), dtype=torch.int32, device=self.device)
+        t.bs_layout = layout
+        return t
 
     def bin_step(self, endpoints):
         """Per-row bin width on the device if the rows are uniform-width bins the CDF spec 2 kernels take
@@ -64,9 +71,16 @@ class HipBackend:
 
     def tables(self, endpoints, mu, scale, quantbits, bits, out=None, step=None, status=None):
         K = endpoints.shape[1] + 1
-        layout = self.table_layout(K, step is not None, mu.shape[1])
-        if out is not None and layout == hip.LAYOUT_PIVOT and out.shape[-1] != hip.PIVOT_LD:
-            out = None                                   # a caller's whole-row buffer: not what this layout writes
+        layout = self.table_layout(K, step is not None, mu.shape[1], mu.shape[0])
+        if out is not None:                              # a reusable buffer decides (a prefix of a larger batch keeps its layout)
+            want = hip.PIVOT_LD if layout == hip.LAYOUT_PIVOT else hip.wave_ld(K) if layout == hip.LAYOUT_WAVE else hip.aligned_ld(K)
+            if out.shape[-1] != want:
+                if step is not None and out.shape[-1] == hip.PIVOT_LD:
+                    layout = hip.LAYOUT_PIVOT
+                elif out.shape[-1] == hip.wave_ld(K) and hip.wave_supported(K):
+                    layout = hip.LAYOUT_WAVE
+                else:
+                    out = None
         return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=layout, step=step, status=status)
 
     def shared_table(self, endpoints, mu, scale, quantbits, bits, step=None):

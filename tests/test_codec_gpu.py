@@ -6,7 +6,7 @@ import torch
 import oracle as O
 from oracle.backend import OracleBackend
 from bitswap_amd import cli, container, tiling, workload
-from bitswap_amd.codec import BitSwapCodec, initial_states
+from bitswap_amd.codec import BitSwapCodec, HipBackend, initial_states
 from conftest import chain_tables, load_golden_model, reference_init_state, words_to_state
 
 pytestmark = pytest.mark.gpu
@@ -341,8 +341,13 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime):
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap))
     assert codec.cdf_spec == 2 and all(s is not None for s in codec.zstep[:-1]) and codec.zstep[-1] is None
     from bitswap_amd import hip
-    assert codec.backend.table_layout(codec.K, True, codec.Z) == hip.LAYOUT_PIVOT      # the production hand-off (round 3)
-    assert codec.backend.table_layout(codec.K, False, codec.Z) == hip.LAYOUT_WAVE      # top layer / prior: whole rows
+    # the hand-off of the bench's batch size (>= 2 GB of rows per launch: 64 cumulative values per row, the pop kernel
+    # rebuilds its group of bins) forced on at 32 chains; the top layer / prior (CDF spec 1) keeps whole rows
+    codec.backend.pivot_min_bytes = 0
+    assert codec.backend.table_layout(codec.K, True, codec.Z, B) == hip.LAYOUT_PIVOT
+    assert codec.backend.table_layout(codec.K, False, codec.Z, B) == hip.LAYOUT_WAVE
+    assert HipBackend(DEV).table_layout(codec.K, True, codec.Z, 400) == hip.LAYOUT_PIVOT       # ... as the default picks it
+    assert HipBackend(DEV).table_layout(codec.K, True, codec.Z, B) == hip.LAYOUT_WAVE
     rec, plain_net = record_nets(codec)
     with _Count("wino_fused") as wf, _Count("wino_gemm") as wg, _NoBlas() as nb:
         state, met = codec.compress(images.to(DEV))
@@ -398,6 +403,7 @@ def test_full_width_crop_model_oracle_word_parity():
     lens = [2, 1, 2] + [1] * 30
     chains = [workload.synthetic_blocks(k, model.xs, seed=300 + i).to(torch.int32) for i, k in enumerate(lens)]
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
+    codec.backend.pivot_min_bytes = 0           # the big-batch hand-off (BS_LAYOUT_PIVOT) on ragged prefixes too
     rec, plain_net = record_nets(codec)
     with _Count("wino_gemm") as wg, _NoBlas() as nb:
         state, order, met = codec.compress_ragged(chains)
