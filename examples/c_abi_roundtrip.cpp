@@ -2,7 +2,7 @@
 // C ABI of include/bitswap_hip.h.  Builds the integer tables of B chains x D latent dims from (mu, scale), pops D symbols
 // per chain (bits back, ANS.decode, mnist_compress.py:58-68), pushes them again under the same model (ANS.encode, :49-56)
 // and checks that every rANS state is exactly what it was -- first in the reference's single-state stream format
-// (bs_logistic_tables + bs_rans_pop, bs_logistic_fc + bs_rans_push), then in the 64-state format (bs_layer_pop64 /
+// (bs_logistic_tables + bs_rans_pop, bs_logistic_fc + bs_rans_push; whole rows and the pivot hand-off), then in the 64-state format (bs_layer_pop64 /
 // bs_layer_push64).
 //
 //   hipcc --offload-arch=gfx950 -O2 -I include examples/c_abi_roundtrip.cpp -L bitswap_amd/csrc -lbitswap_hip \
@@ -104,6 +104,31 @@ int main() {
     }
     std::printf("reference format: popped %d symbols per chain (first: %d %d %d), %d words taken, state %s\n", D, sym[0], sym[1],
                 sym[2], len[0] - len_after_pop[0], bad ? "NOT restored" : "restored exactly");
+
+    // ---- the same pop through the big-batch hand-off: 64 cumulative values per row, bs_rans_pop_pivot rebuilds the
+    //      symbol's group of bins (BS_LAYOUT_PIVOT) -- same symbols, and the same push restores the state
+    {
+        const int64_t ldp = 128;
+        uint32_t* d_piv;
+        int32_t* d_sym2;
+        HIP_OK(hipMalloc(&d_piv, (size_t)B * D * ldp * 4));
+        HIP_OK(hipMalloc(&d_sym2, (size_t)B * D * 4));
+        BS_OKAY(bs_logistic_tables(d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, B, D, K, bits, q, d_piv, ldp, BS_LAYOUT_PIVOT,
+                                   d_status, stream));
+        BS_OKAY(bs_rans_pop_pivot(d_head, d_stack, d_len, cap, d_piv, ldp, d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, B, D, K,
+                                  bits, q, d_sym2, d_cen, K, d_z, d_status, stream));
+        BS_OKAY(bs_logistic_fc(d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, d_sym2, B, D, K, bits, q, d_f, d_c, d_status, stream));
+        BS_OKAY(bs_rans_push(d_head, d_stack, d_len, cap, d_f, d_c, B, D, bits, d_status, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        auto sym2 = to_host(d_sym2, (size_t)B * D);
+        auto head3 = to_host(d_head, B);
+        auto len3 = to_host(d_len, B);
+        int badp = 0;
+        for (size_t i = 0; i < sym2.size(); ++i) badp += sym2[i] != sym[i];
+        for (int b = 0; b < B; ++b) badp += head3[b] != head[b] || len3[b] != len[b];
+        std::printf("pivot hand-off: %s\n", badp ? "symbols or state DIFFER" : "same symbols as whole rows, state restored exactly");
+        bad += badp;
+    }
 
     // ---- 64-state format: table + rANS step in one launch --------------------------------------------------
     const int64_t cap64 = 256;
