@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cifar8", choices=["mnist2", "cifar8", "imagenet4", "imagenetcrop4"])
-    ap.add_argument("--chains", type=int, default=800,
+    ap.add_argument("--chains", type=int, default=1000,
                     help="independent chains (rANS streams) per GPU; the reference runs 100 'experiments' one block at a time, "
                          "an MI355X wants a few hundred in lock-step (conv efficiency grows with the batch, DESIGN.md 6)")
     ap.add_argument("--quantbits", type=int, default=10)
@@ -445,8 +445,8 @@ def main(args):
         extra = []
         ks, ws = min(args.steps, 6), min(args.warmup, 1)
         import copy
-        for (wn, ch, gr, fmt, reg) in (("imagenet4", 800, 2, "reference", None), ("cifar8", 100, 1, "reference", None),
-                                       ("cifar8", 800, 2, "reference", "lowrate"),
+        for (wn, ch, gr, fmt, reg) in (("imagenet4", 1000, 2, "reference", None), ("cifar8", 100, 1, "reference", None),
+                                       ("cifar8", 1000, 2, "reference", "lowrate"),
                                        ("cifar8", 800, 2, "wave64", None), ("cifar8", 13, 1, "wave64", None)):
             torch.cuda.empty_cache()
             try:

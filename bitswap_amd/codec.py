@@ -719,11 +719,10 @@ class GroupedCodec:
 
     The serial rANS kernels keep one wavefront busy per chain -- a few percent of an MI355X at 100
     chains -- while the conv stacks and the table kernels want the whole chip.  The chains are split
-    into G groups.  Each group has a bulk stream (convs, fused logistic/table kernels) and a serial stream
-    (pop/push).  The enqueue order is interleaved at coding-operation granularity, so while group A's pop
-    runs on its serial stream group B's convs are already executing, and the HBM-bound transform passes
-    and the float64 table kernels of one group fill in under the matrix-core GEMMs of the other (2.5 %
-    over ONE bulk stream shared by all groups, profiles/r02y; BITSWAP_BULK_PER_GROUP=0 restores that).
+    into G groups, each on its own HIP stream (default since round 3; BITSWAP_GROUP_STREAMS=0 gives every group a bulk
+    stream for convs and table kernels plus a serial stream for pop/push, the round-2 arrangement).  The enqueue order is
+    interleaved at coding-operation granularity, so while group A pops, group B's convs are already executing, and the
+    HBM-bound transform passes and the float64 table kernels of one group fill in under the matrix-core GEMMs of the other.
     Chains never interact: results are identical to coding each group on its own.
     """
 
@@ -733,8 +732,14 @@ class GroupedCodec:
         self.X, self.Z, self.K = self.codecs[0].X, self.codecs[0].Z, self.codecs[0].K
         self.bulk = None
         self.group_streams = None
-        if groups > 1 and (isinstance(self.codecs[0].backend, Hip64Backend) or os.environ.get("BITSWAP_GROUP_STREAMS") == "1"):
-            # fused coding kernels: nothing serial to split off; ONE stream per group, the groups overlap each other
+        gs = os.environ.get("BITSWAP_GROUP_STREAMS", "auto")
+        be = self.codecs[0].backend
+        one_stream = gs == "1" or (gs == "auto" and (isinstance(be, Hip64Backend) or getattr(be, "pivot", False)))
+        if groups > 1 and one_stream:
+            # ONE stream per group, the groups overlap each other.  64-state format: the coding kernels are fused, there is
+            # nothing serial to split off.  Reference format: since the pop kernel of big batches no longer streams whole
+            # rows from HBM (BS_LAYOUT_PIVOT) it is cheap to keep in line, and two in-order streams beat the bulk + serial
+            # split (800 chains: 152.5 vs 157.9 ms per step, profiles/r03r; round 2, with the row-reading pop: 164.8 vs 164.2)
             self.group_streams = [torch.cuda.Stream(device=self.device) for _ in self.codecs]
         elif groups > 1:
             self.bulk = torch.cuda.Stream(device=self.device)
