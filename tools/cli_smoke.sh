@@ -17,6 +17,9 @@ for fmt in reference wave64; do
 done
 python cifar_compress.py --synthetic --experiments 6 --ndatapoints 3 --decompress 1 --outdir $T/out | tail -2
 cat $T/out/bitstreams/cifar/nz8/Bit-Swap/stream_meta.json | tr -d '\n' | cut -c1-400; echo
+# a receiver in another process: reads the pickles + stream_meta.json, refuses a CDF-spec mismatch, then decodes
+python cifar_compress.py --synthetic --decompress-only --outdir $T/out | tail -1
+if python cifar_compress.py --synthetic --decompress-only --cdf-spec 1 --outdir $T/out > $T/mismatch.log 2>&1; then echo "MISMATCH NOT REFUSED"; exit 1; else grep -o "StreamMismatch.*" $T/mismatch.log | cut -c1-160; fi
 python cifar_compress.py --synthetic --experiments 6 --ndatapoints 3 --decompress 1 --format wave64 --outdir $T/out64 | tail -1
 python mnist_compress.py --synthetic --nz 2 --bitswap 0 --experiments 4 --ndatapoints 2 --decompress 1 --outdir $T/out | tail -1
 python imagenetcrop_compress.py --synthetic --nimages 12 | tail -4
