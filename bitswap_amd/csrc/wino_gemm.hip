@@ -37,6 +37,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// M is written once and read once, by the transform pass that follows: streaming stores keep it from evicting the U[t]
+// tiles the XCD's other workgroups are about to re-read from L2 (+1.3 % at the bench's shape, profiles/r03v)
+constexpr bool NT_STORE = true;
 constexpr int G_BN = 128, G_BK = 16, G_LDA = G_BK, G_LDB = G_BN;      // LDS rows are unpadded: the tiles arrive by LDS-DMA
 
 struct Chunk {
@@ -162,7 +165,10 @@ __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float*
                 float* p = Mt + (int64_t)row0 * sg.cols + col;
                 if (all_rows) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[mi][ni][v];
+                    for (int v = 0; v < 16; ++v) {
+                        if (NT_STORE) __builtin_nontemporal_store(acc[mi][ni][v], p + (int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols);
+                        else p[(int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols] = acc[mi][ni][v];
+                    }
                 } else {
 #pragma unroll
                     for (int v = 0; v < 16; ++v)
