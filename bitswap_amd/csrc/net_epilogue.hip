@@ -281,6 +281,10 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, c
 // forward transform are cut out with 16-byte reads.  Nothing pointwise is left outside: a layer
 // x + conv2(ELU(conv1(ELU(x)) + b1)) + b2 is  GEMM, fused, GEMM, fused.
 // ------------------------------------------------------------------------------------------
+// M is read once (written by the GEMM in front) and V written once (read by the GEMM behind): streaming loads / stores.
+// Alone at 400 blocks x 256 channels: <6,6> 114 -> 105 us (5.6 TB/s), with the residual sum 137 -> 113, <8,8> 179 -> 158
+// (6.0 TB/s), tools/probes/fused_probe.py, round 3
+constexpr bool FUSED_NT = true;
 template <int TS_IN, int TS_OUT>
 __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ src, const float* __restrict__ bias,
                                                     const float* __restrict__ res, float* __restrict__ sum_out,
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
             for (int q = 0; q < TI; ++q) {
                 float colv[TI], y[4];
 #pragma unroll
-                for (int r = 0; r < TI; ++r) colv[r] = m[(int64_t)(r * TI + q) * tstride];
+                for (int r = 0; r < TI; ++r) colv[r] = FUSED_NT ? __builtin_nontemporal_load(m + (int64_t)(r * TI + q) * tstride) : m[(int64_t)(r * TI + q) * tstride];
                 wino_at<TI, 4>(colv, y);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t1[r][q] = y[r];
@@ -375,7 +379,10 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
             float o[TO];
             wino_bt<TO>(t1[r], o);
 #pragma unroll
-            for (int q = 0; q < TO; ++q) out[(int64_t)(r * TO + q) * tstride] = o[q];
+            for (int q = 0; q < TO; ++q) {
+                if (FUSED_NT) __builtin_nontemporal_store(o[q], out + (int64_t)(r * TO + q) * tstride);
+                else out[(int64_t)(r * TO + q) * tstride] = o[q];
+            }
         }
     }
 }
