@@ -34,8 +34,11 @@ ASAN_LIB = os.path.join(HERE, "csrc", "libbitswap_hip_asan.so")
 
 def build_asan(verbose=False):
     """AddressSanitizer build of the same sources (host AND device code instrumented: ROCm's ASan needs an xnack+ target),
-    written next to the product library as libbitswap_hip_asan.so.  Diagnostic only: run a test with
-    BITSWAP_HIP_LIB=<that file> HSA_XNACK=1 LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so)."""
+    written next to the product library as libbitswap_hip_asan.so.  Diagnostic only: needs an
+    ASan-instrumented HIP runtime (/opt/rocm/lib/asan) and HSA_XNACK=1 to RUN -- this image ships none (the ASan runtime's
+    hsa_amd_memory_pool_allocate interceptor aborts inside torch's bundled libamdhip64, profiles/r03x_asan.log), so round 3
+    only establishes that the sources build instrumented; drive it from a plain HIP program (examples/c_abi_roundtrip.cpp),
+    not from torch."""
     flags = [f if not f.startswith("--offload-arch") else "--offload-arch=gfx950:xnack+" for f in HIPCC_FLAGS]
     flags = [f for f in flags if f != "-O3"] + ["-O1", "-g", "-fsanitize=address", "-shared-libsan"]
     cmd = [hipcc_path()] + flags + ["-o", ASAN_LIB] + SRCS
