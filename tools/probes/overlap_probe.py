@@ -30,8 +30,15 @@ x = torch.randn(400, 256, 16, 16, device=dev)
 bias = torch.randn(256, device=dev)
 
 
+pcdf = torch.empty((B, D, hip.PIVOT_LD), dtype=torch.int32, device=dev)
+PIVOT = "--pivot" in sys.argv      # the big-batch hand-off: 64 cumulative values per row, no 3.57 GB row write
+
+
 def tables():
-    hip.logistic_tables(e, mu, sc, 31, 10, out=wcdf, layout=hip.LAYOUT_WAVE, step=step, status=status)
+    if PIVOT:
+        hip.logistic_tables(e, mu, sc, 31, 10, out=pcdf, layout=hip.LAYOUT_PIVOT, step=step, status=status)
+    else:
+        hip.logistic_tables(e, mu, sc, 31, 10, out=wcdf, layout=hip.LAYOUT_WAVE, step=step, status=status)
 
 
 def gemm():
