@@ -393,6 +393,7 @@ class BitSwapCodec:
                                       out=self._cdf(mu.shape[0], mu.shape[1], K, step is not None), step=step,
                                       status=state.status)
         self._serial_waits_bulk()
+        self._share((mu, scale), self.serial)    # the pivot hand-off's pop kernel reads them again, on the serial stream
         with self._on(self.serial):
             with self.tl.span("pop_" + key):
                 out = self.backend.pop(state, cdf, K, self.bits, centres=centres)

@@ -78,7 +78,8 @@ def _flat(d, pre=""):
 
 
 # informational fields: where the stream was written, not how
-_IGNORED = ("backend", "world_size", "experiments", "ndatapoints", "nblocks", "image")
+# (library_abi: the C interface version -- recorded; what decides decodability is conv_route.rev and the CDF specs)
+_IGNORED = ("backend", "world_size", "experiments", "ndatapoints", "nblocks", "image", "library_abi")
 
 
 def check(written, mine, what="stream"):
