@@ -11,20 +11,24 @@
 // were coded next to it.
 //
 // Scheduling for CDNA4 (round 3): persistent workgroups over a flat list of work units.  A unit is (t, row tile,
-// block of 32 columns); workgroup g of G owns the contiguous unit range [g Nu / G, (g+1) Nu / G) and walks it in
-// chunks of up to four column blocks (a 32*NW x 128 output tile, NW wavefronts of 32 rows x 128 columns = 1 x 4 MFMA
-// tiles, 64 accumulator registers per lane).  Work per workgroup differs by at most one 32-column block: the tiled
-// round-2 launch (1800 tiles of 256 x 128 on 512 resident slots = 3.52 rounds at 400 chains) lost a quarter of the
-// chip to its last round.  G = 2 workgroups per CU (58 KB of LDS each), and the logical order of the workgroups
-// follows the XCD a workgroup lands on (blockIdx % 8), so that the workgroups sharing an L2 share their U[t].
-// K advances 16 at a time through a double-buffered LDS stage (one barrier per step); the global loads of the next
-// step -- of the next CHUNK at the end of a chunk -- are in flight while this step multiplies, so the loop never
-// drains between tiles.  LDS layouts are chosen so that every read is conflict-free:
-//   A: [row][20]  -- a lane reads 4 consecutive k of its row as one 16-byte load (the 16 lanes of a ds_read_b128
-//                    phase hit 16 disjoint groups of 4 banks);
-//   B: [k][136]   -- a lane reads one float per k; the 32 lanes of a phase read consecutive words.
+// block of 32 columns); a workgroup owns a contiguous unit range and walks it in chunks of up to four column blocks
+// (a 64 NW x 128 output tile at the conv stacks' width: NW wavefronts of 64 rows x 128 columns = 2 x 4 MFMA tiles, 128
+// accumulator registers per lane).  Work per workgroup differs by at most one 32-column block: the tiled round-2 launch
+// (1800 tiles of 256 x 128 on 512 resident slots = 3.52 rounds at 400 chains) lost a quarter of the chip to its last
+// round.  G = 2 workgroups per CU (48 KB of LDS each); the workgroups of one XCD (blockIdx % 8) take consecutive ranges,
+// so that the workgroups sharing an L2 share their U[t], and an XCD's longer ranges go to its first workgroups.
+// K advances 16 at a time through a double-buffered LDS stage filled by LDS-DMA (one barrier per step); the DMA of the
+// next step -- of the next CHUNK at the end of a chunk -- is in flight while this step multiplies, so the loop never
+// drains between tiles.  LDS tiles are unpadded (the DMA writes lane-linear):
+//   A: [row][16], 16-byte granules XOR-swizzled on the source side -- a lane reads 4 consecutive k of its row as one
+//                 ds_read_b128, conflict-free over the 16 lanes of a phase;
+//   B: [k][128]   as in memory; MFMA tile ni of a full chunk takes the columns 4 n + ni (n = lane % 32), so a lane's four
+//                 B operands of one k are ONE ds_read_b128 and its four results of one row one dwordx4 store.
+// Inside a wavefront the K step is software-pipelined by hand: the operands of the next k pair are requested before the
+// eight MFMAs of this one are issued (run_chunk_p; what the compiler's own placement cost is in its comment).
 // The MFMA contraction index is permuted (half-wave g takes k = 8j + 4g + i in step i of chunk j) -- the same
-// permutation on both operands, i.e. the same sum in another fixed order (the order of the round-2 kernel).
+// permutation on both operands, i.e. the same sum in another fixed order (the order of the round-2 kernel: which lane
+// computes an output, and which workgroup, never changes its bits; tools/gemm_probe.py checks own == r02 bitwise).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -78,6 +82,7 @@ struct Stager {
         for (int i = 0; i < NB; ++i) offB[i] = (uint32_t)(((tid + i * NT) >> 5) * (int)cols + ((tid + i * NT) & 31) * 4) * 4u;
     }
     // issue the DMA of step (c, k0) into LDS stage `buf`
+    template <int SKIP = 0>                 // (SKIP: lab only -- 1 leaves the A tile out, 2 the B tile)
     __device__ __forceinline__ void load(const Chunk& c, int k0, float* lds, int buf) const {
         const char* Ub = reinterpret_cast<const char*>(U + ((int64_t)c.t * Cout + c.co0) * Cin + k0);
         const char* Vb = reinterpret_cast<const char*>(V + ((int64_t)c.t * Cin + k0) * cols + (int64_t)c.cb * 32);
@@ -88,14 +93,14 @@ struct Stager {
         // rows beyond Cout / columns beyond the chunk only feed outputs that are never stored: their loads are redirected
         // to a valid address (row 0 / column 0 of the tile) instead of being masked
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
+        for (int i = 0; i < ((SKIP & 1) ? 0 : NA); ++i) {
             const int q = tid + i * NT;
             const uint32_t off = ((q >> 2) < rows_left) ? offA[i] : (uint32_t)(((q & 3) ^ ((q >> 4) & 3)) * 16);
             __builtin_amdgcn_global_load_lds(Ub + off, (lds_ptr_t)(As + (wbase + i * NT) * 4),
                                              16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < ((SKIP & 2) ? 0 : NB); ++i) {
             const uint32_t off = (((tid + i * NT) & 31) * 4 < cols_left) ? offB[i] : offB[i] - (uint32_t)((tid + i * NT) & 31) * 16u;
             __builtin_amdgcn_global_load_lds(Vb + off, (lds_ptr_t)(Bs + (wbase + i * NT) * 4),
                                              16, 0, 0);
@@ -179,21 +184,182 @@ __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float*
     }
 }
 
-template <int NW, int MI>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// NBLK consecutive floats of one B row (the lane's columns NBLK l32 .. + NBLK - 1): one ds_read_b128 / b64 where it can be
+template <int NBLK>
+__device__ __forceinline__ void read_b(float (&b)[NBLK], const float* p) {
+    if constexpr (NBLK == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        b[0] = v[0], b[1] = v[1], b[2] = v[2], b[3] = v[3];
+    } else if constexpr (NBLK == 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+        b[0] = v[0], b[1] = v[1];
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NBLK; ++ni) b[ni] = p[ni];
+    }
+}
+
+// The same chunk, software-pipelined inside the wave (round 3, visit C).  In the ISA of run_chunk the compiler sinks every
+// operand read to just before its first use: a K step has eight `ds_read ; s_waitcnt lgkmcnt(0)` pairs with nothing
+// between them -- eight exposed LDS latencies per 64 MFMAs, which only the co-resident workgroup's wave can fill.  Here
+// (+5 % at the bench's shape, profiles/r03C_gemm_probe.txt; one workgroup per CU is now as fast as two were):
+//  * the MFMA tile ni of a wave takes the columns NBLK n + ni (n = lane % 32) instead of 32 ni + n: a lane's NBLK B operands
+//    of one k are adjacent in LDS (ONE ds_read_b128 instead of four ds_read_b32: 12 LDS instructions per K step instead of
+//    36), and its NBLK results of one row are adjacent in memory (dwordx4 stores: 32 per wave and chunk instead of 128).
+//    Which lane computes an output does not change its sum;
+//  * the operands of sub-step s + 1 (one k pair: MI x NBLK MFMAs) are requested before the MFMAs of sub-step s are issued
+//    and held in a second register set (sched_barrier keeps the order), across the barrier too: the barrier sits before the
+//    LAST sub-step's MFMAs, whose operands are in registers, and the first reads of the next stage follow it immediately.
+template <int NW, int MI, int NBLK, int DMA_AT, int LAB = 0>
+__device__ __forceinline__ void run_chunk_p(Stager<NW, MI>& sg, float* lds, float* __restrict__ M, const Chunk& cur,
+                                            const Chunk& nxt, bool more, int& buf, int wave, int l32, int g) {
+    constexpr int BM = 32 * MI * NW, STAGE = Stager<NW, MI>::STAGE;
+    f32x16 acc[MI][NBLK];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NBLK; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.0f;
+    const int nk = sg.Cin / G_BK;
+    const int sw = (l32 >> 2) & 3;                           // source-side swizzle of the A granules, see Stager
+    const int offA = (wave * 32 * MI + l32) * G_LDA, offB = BM * G_LDA + (g * 4) * G_LDB + NBLK * l32;
+    f32x4 a[2][MI];
+    float b[2][NBLK];
+    const float* As = lds + buf * STAGE + offA;
+    const float* Bs = lds + buf * STAGE + offB;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * G_LDA + ((g ^ sw) << 2));
+    read_b<NBLK>(b[0], Bs);
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool last = kt + 1 == nk;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int j = s >> 2, i = s & 3;
+            // a use of this sub-step's operands BEFORE the next ones are requested: the compiler's s_waitcnt lands here, where
+            // they are the only reads outstanding (requested one sub-step = MI NBLK MFMAs ago), instead of after the new request
+            // -- it emits lgkmcnt(0), not lgkmcnt(n), in front of the first consuming MFMA
+#pragma unroll
+            for (int ni = 0; ni < NBLK; ++ni) asm volatile("" ::"v"(b[s & 1][ni]));
+            if (i == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a[j][mi]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s < 7) {
+                if (s == 3) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        a[1][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * G_LDA + (((2 + g) ^ sw) << 2));
+                }
+                read_b<NBLK>(b[(s + 1) & 1], Bs + (((s + 1) >> 2) * 8 + ((s + 1) & 3)) * G_LDB);
+            } else {
+                if (LAB & 3) {               // LAB: timing experiments with WRONG results (tools/gemm_probe.py --lab)
+                    if (!(LAB & 2)) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
+                } else
+                __syncthreads();             // the next stage has landed (vmcnt) and nobody reads this one any more
+                buf ^= 1;
+                As = lds + buf * STAGE + offA;
+                Bs = lds + buf * STAGE + offB;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const f32x4*>(As + mi * 32 * G_LDA + ((g ^ sw) << 2));
+                read_b<NBLK>(b[0], Bs);      // (after the chunk's last step: unused, the next chunk reads its own shape)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == DMA_AT) {
+                // the DMA of the next step, branch-free so that its address arithmetic can sit between this sub-step's MFMAs
+                // (after the very last step of the workgroup's range: a harmless reload of this chunk's first stage)
+                Chunk c = cur;
+                if (last & more) c = nxt;
+                if (!(LAB & 8)) sg.template load<(LAB >> 4) & 3>(c, last ? 0 : (kt + 1) * G_BK, lds, buf ^ 1);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NBLK; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][i], b[s & 1][ni], acc[mi][ni], 0, 0, 0);
+            if (s == DMA_AT) {               // one MFMA, a slice of the address arithmetic, one DMA instruction, ...
+#pragma unroll
+                for (int r = 0; r < MI * NBLK; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // register v of lane l: row (v/4)*8 + (l/32)*4 + v%4 of the 32x32 tile; tile ni's column l%32 is column NBLK (l%32) + ni
+    // of the chunk, so the lane's NBLK tiles hold NBLK adjacent outputs of that row
+    float* Mt = M + (int64_t)cur.t * sg.Cout * sg.cols;
+    const int64_t col = (int64_t)cur.cb * 32 + NBLK * l32;
+    const bool all_rows = cur.co0 + BM <= sg.Cout;
+    auto store = [&](float* q, int mi, int v) {
+        if constexpr (NBLK == 4) {
+            f32x4 o = {acc[mi][0][v], acc[mi][1][v], acc[mi][2][v], acc[mi][3][v]};
+            if (LAB & 64) *reinterpret_cast<f32x4*>(q) = o;
+            else __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(q));
+        } else if constexpr (NBLK == 2) {
+            f32x2 o = {acc[mi][0][v], acc[mi][1][v]};
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x2*>(q));
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NBLK; ++ni)
+                if (NBLK == 1 || col + ni < sg.cols) __builtin_nontemporal_store(acc[mi][ni][v], q + ni);
+        }
+    };
+    // cols % 4 == 0 and col % NBLK == 0: for NBLK = 4 / 2 / 1 the lane's outputs are all inside or all outside (3: per element)
+    if (col < sg.cols && (!(LAB & 4) || acc[0][0][0] == 12345.0f)) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row0 = cur.co0 + (wave * MI + mi) * 32 + g * 4;
+            float* p = Mt + (int64_t)row0 * sg.cols + col;
+            if (all_rows) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) store(p + (int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols, mi, v);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (row0 + (v >> 2) * 8 + (v & 3) < sg.Cout) store(p + (int64_t)((v >> 2) * 8 + (v & 3)) * sg.cols, mi, v);
+            }
+        }
+    }
+}
+
+template <int NW, int MI, int PIPE>
 __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
                                                           float* __restrict__ M, int Cout, int Cin, int64_t cols,
-                                                          int ncb, int nrt, int units) {
+                                                          int ncb, int nrt, int units, int even_ranges) {
     constexpr int BM = 32 * MI * NW;
-    extern __shared__ float lds[];                   // [2][STAGE]
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;
 
-    // logical workgroup index: the workgroups of one XCD (blockIdx % 8, round-robin dispatch) take consecutive ranges
+    // Which units: the workgroups of one XCD (blockIdx % 8, round-robin dispatch) take consecutive ranges of one eighth of the
+    // list, so that they share their U[t] in that XCD's L2.  The ranges of an XCD differ by one unit; the longer ones go to its
+    // FIRST workgroups (blockIdx / 8 = 0, 1, ...): those start first, and consecutive workgroups land on different CUs, so no
+    // CU gets two long ranges (evenly spaced long ranges -- every 16th workgroup at the bench's shape -- met on one CU:
+    // 30 units there against a mean of 28.1).
     const int G = gridDim.x;
-    int w = blockIdx.x;
-    if ((G & 7) == 0) w = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    int u = __builtin_amdgcn_readfirstlane((int)((int64_t)w * units / G));
-    const int uend = __builtin_amdgcn_readfirstlane((int)((int64_t)(w + 1) * units / G));
+    int u, uend;
+    if ((G & 7) == 0 && even_ranges) {          // (probe only: the visit-A/B assignment)
+        const int w = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        u = (int)((int64_t)w * units / G);
+        uend = (int)((int64_t)(w + 1) * units / G);
+    } else if ((G & 7) == 0) {
+        const int S = G >> 3, x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+        const int ux0 = (int)((int64_t)x * units / 8), nx = (int)((int64_t)(x + 1) * units / 8) - ux0;
+        const int base = nx / S, rem = nx - base * S;
+        u = ux0 + sl * base + min(sl, rem);
+        uend = u + base + (sl < rem ? 1 : 0);
+    } else {
+        u = (int)((int64_t)blockIdx.x * units / G);
+        uend = (int)((int64_t)(blockIdx.x + 1) * units / G);
+    }
+    u = __builtin_amdgcn_readfirstlane(u);
+    uend = __builtin_amdgcn_readfirstlane(uend);
     if (u >= uend) return;
 
     const int per_t = nrt * ncb;
@@ -218,10 +384,20 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restric
         const bool more = unext < uend;
         Chunk nxt = cur;
         if (more) nxt = decode(unext);
-        if (cur.nb == 4) run_chunk<NW, MI, 4>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-        else if (cur.nb == 3) run_chunk<NW, MI, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);   // a range's ragged ends
-        else if (cur.nb == 2) run_chunk<NW, MI, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-        else run_chunk<NW, MI, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        if constexpr (PIPE != 0) {
+            constexpr int AT = 1;                 // the sub-step whose MFMAs the DMA issue of the next stage is spread over
+            constexpr int LAB = PIPE >= 16 ? PIPE - 16 : 0;
+            // full chunks pipelined; a range's ragged ends (1-3 column blocks: too few MFMAs per sub-step to cover a read) as before
+            if (cur.nb == 4) run_chunk_p<NW, MI, 4, AT, LAB>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 3) run_chunk<NW, MI, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 2) run_chunk<NW, MI, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else run_chunk<NW, MI, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        } else {
+            if (cur.nb == 4) run_chunk<NW, MI, 4>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 3) run_chunk<NW, MI, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 2) run_chunk<NW, MI, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else run_chunk<NW, MI, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+        }
         if (!more) break;
         u = unext;
         cur = nxt;
@@ -253,8 +429,24 @@ int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int C
         if (v > 0) G = (int64_t)cu_count() * v;
     }
     if (G > units) G = units;
-    hipLaunchKernelGGL((k_wino_gemm<NW, MI>), dim3((unsigned)G), dim3(64 * NW), shm, st, U, V, M, Cout, Cin, cols, (int)ncb,
-                       (int)nrt, (int)units);
+    const char* ev = getenv("BITSWAP_GEMM_VARIANT");           // tuning only: the summation order does not depend on it
+    const int variant = ev ? atoi(ev) : 2;
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), shm, st, U, V, M, Cout, Cin, cols, (int)ncb, (int)nrt, (int)units,
+                           getenv("BITSWAP_GEMM_EVEN_RANGES") ? 1 : 0);
+    };
+    if (variant == 0) go(k_wino_gemm<NW, MI, 0>);     // the visit-A/B kernel (operand reads where the compiler puts them), for the probe
+#ifdef BS_GEMM_LAB    // timing experiments with WRONG results (tools/gemm_probe.py --lab builds its own library with this)
+    else if (NW == 4 && MI == 2 && variant == 17) go(k_wino_gemm<4, 2, 17>);      // no vmcnt wait at the barrier
+    else if (NW == 4 && MI == 2 && variant == 19) go(k_wino_gemm<4, 2, 19>);      // no barrier at all
+    else if (NW == 4 && MI == 2 && variant == 20) go(k_wino_gemm<4, 2, 20>);      // no stores
+    else if (NW == 4 && MI == 2 && variant == 24) go(k_wino_gemm<4, 2, 24>);      // no DMA
+    else if (NW == 4 && MI == 2 && variant == 31) go(k_wino_gemm<4, 2, 31>);      // MFMAs and LDS reads only
+    else if (NW == 4 && MI == 2 && variant == 32) go(k_wino_gemm<4, 2, 32>);      // no DMA of the A tile (U)
+    else if (NW == 4 && MI == 2 && variant == 48) go(k_wino_gemm<4, 2, 48>);      // no DMA of the B tile (V)
+    else if (NW == 4 && MI == 2 && variant == 80) go(k_wino_gemm<4, 2, 80>);      // (right results) plain stores instead of nt
+#endif
+    else go(k_wino_gemm<NW, MI, 2>);
     return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
 }
 

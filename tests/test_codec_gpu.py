@@ -777,12 +777,12 @@ def test_pixel_bins_are_identical_on_host_and_device():
 
 @pytest.mark.parametrize("T,Cout,Cin,cols", [(36, 256, 256, 1600), (64, 256, 256, 640), (36, 128, 64, 208), (3, 96, 48, 100),
                                               (36, 16, 256, 400), (2, 300, 32, 132), (36, 24, 256, 512), (5, 64, 16, 36),
-                                              (1, 40, 32, 16), (36, 256, 256, 6400)])
+                                              (1, 40, 32, 16), (36, 256, 256, 6400), (3, 300, 32, 12004)])
 def test_wino_gemm_matches_bmm_and_is_batch_invariant(T, Cout, Cin, cols):
     """bs_wino_gemm_f32 (fp32 MFMA batched product of the Winograd route, persistent balanced kernel) against the float64
     product: full chunks, ragged range ends (1-3 column blocks), partial column blocks, output-channel counts that are no
-    multiple of the workgroup tile, all four workgroup shapes (8 / 4 / 2 / 1 wavefronts), a single K step, fewer units than
-    workgroups, and the bench's own shape.  Every output is summed in one fixed order: a subset of the columns -- other
+    multiple of the workgroup tile, all four workgroup shapes (4 x 64 rows, 4 / 2 / 1 x 32 rows), a single K step, fewer units than
+    workgroups, the bench's own shape, and full (hand-pipelined) chunks with a partial row tile and a 4-column last block.  Every output is summed in one fixed order: a subset of the columns -- other
     chunk boundaries, another split over the workgroups -- gives the same bits as the full call."""
     from bitswap_amd import hip
     g = torch.Generator().manual_seed(T + cols)

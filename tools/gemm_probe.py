@@ -1,7 +1,7 @@
 """bs_wino_gemm_f32 (persistent balanced kernel, round 3) against its round-2 version (tiled launch; built on the spot from
 tools/probes/wino_gemm_r02.hip) and the library (torch.bmm on the backend the model used to use) for the batched shapes of
 the bench: sustained loops, TFLOP/s, fraction of the 157.3 TFLOP/s fp32 MFMA peak.
-usage: python tools/gemm_probe.py [--quick] [--only-own]"""
+usage: python tools/gemm_probe.py [--quick] [--only-own] [--knobs] [--lab]"""
 import ctypes as C
 import os
 import subprocess
@@ -11,7 +11,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if "--lab" in sys.argv:      # the timing-only variants live behind -DBS_GEMM_LAB: a library of their own, outside the tree
+    os.environ["BITSWAP_HIP_LIB"] = "/tmp/libbitswap_hip_lab.so"
 from bitswap_amd import build, hip  # noqa: E402
+if "--lab" in sys.argv:
+    build.HIPCC_FLAGS.append("-DBS_GEMM_LAB")
+    build.build_hip(force=True)
 
 PEAK = 157.3
 
@@ -55,6 +60,8 @@ shapes = ((36, 256, 256, 6400), (36, 256, 256, 1600), (64, 256, 256, 6400), (64,
           (36, 256, 256, 7168), (36, 256, 256, 512), (36, 256, 256, 208), (36, 16, 256, 6400), (36, 16, 256, 1600), (36, 24, 256, 512))
 if quick:
     shapes = shapes[:1]
+if "--lab" in sys.argv:
+    shapes = (shapes[0], shapes[4])
 for T, Cout, Cin, cols in shapes:
     U = torch.randn(T, Cout, Cin, device="cuda")
     V = torch.randn(T, Cin, cols, device="cuda")
@@ -70,7 +77,12 @@ for T, Cout, Cin, cols in shapes:
         return run
     variants = [("own", lambda: hip.wino_gemm(U, V, out=out))]
     if "--knobs" in sys.argv:
-        variants += [("own/1wg", own_with(BITSWAP_GEMM_WGS_PER_CU="1")), ("own/3wg", own_with(BITSWAP_GEMM_WGS_PER_CU="3"))]
+        variants += [("v0", own_with(BITSWAP_GEMM_VARIANT="0")), ("even-ranges", own_with(BITSWAP_GEMM_EVEN_RANGES="1")), ("v3", own_with(BITSWAP_GEMM_VARIANT="3")),
+                     ("1wg", own_with(BITSWAP_GEMM_WGS_PER_CU="1"))]
+    if "--lab" in sys.argv and Cout == 256:      # timing-only variants (results wrong): what each piece of the K step costs
+        variants += [(n, own_with(BITSWAP_GEMM_VARIANT=str(v))) for n, v in
+                     (("no-vmcnt", 17), ("no-barrier", 19), ("no-stores", 20), ("no-dma", 24), ("mfma+lds", 31), ("no-A-dma", 32),
+                      ("no-B-dma", 48), ("plain-stores", 80))]
     ref = None
     if old is not None and Cout >= 64:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
