@@ -22,6 +22,11 @@
 //
 // Reference lines are cited in include/bitswap_hip.h next to each entry point.
 #include <hip/hip_runtime.h>
+
+// issue priority of the serial coder kernels' wavefronts (one per chain) against co-resident bulk kernels (0 .. 3)
+#ifndef BS_SERIAL_PRIO
+#define BS_SERIAL_PRIO 3
+#endif
 #include <stdint.h>
 
 #include "../../include/bitswap_hip.h"
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, ui
     }
     // latency-critical serial wave: win instruction-issue arbitration against co-resident bulk
     // kernels (the convs of another chain group run concurrently on other streams)
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
     uint64_t h = head[b];
     int n = len[b];
     const uint32_t* stk = stack + (int64_t)b * cap;
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
         return;
     }
     // latency-critical serial wave: win instruction-issue arbitration against co-resident bulk kernels
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
     uint64_t h = head[b];
     int n = len[b];
     const uint32_t* stk = stack + (int64_t)b * cap;
@@ -816,7 +821,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
         }
         return;
     }
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
     uint64_t h = head[b];
     int n = len[b];
     const uint32_t* stk = stack + (int64_t)b * cap;
@@ -1067,7 +1072,7 @@ __device__ __forceinline__ void push_chain(uint64_t* __restrict__ head, uint32_t
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     if (status[b] != BS_ST_OK) return;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
     uint64_t h = head[b];
     int n = len[b];
     uint32_t* stk = stack + (int64_t)b * cap;
@@ -1164,7 +1169,7 @@ __device__ __forceinline__ void push_chain_fast(uint64_t* __restrict__ head, uin
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     if (status[b] != BS_ST_OK) return;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
     const uint64_t h0 = head[b];
     uint32_t in_lo = (uint32_t)h0, in_hi = (uint32_t)(h0 >> 32);  // this lane's input head (lane 0: the chunk's)
     int n = len[b];
@@ -1570,10 +1575,10 @@ int dispatch_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t ca
 #define BS_POPP(NPL, PF)                                                                                              \
     hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, endpoints, \
                        e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status)
-    if (K == 256) BS_POPP(4, 16);
-    else if (K == 512) BS_POPP(8, 16);
-    else if (K == 1024) BS_POPP(16, 16);
-    else if (K == 2048) BS_POPP(32, 16);
+    if (K == 256) BS_POPP(4, 8);
+    else if (K == 512) BS_POPP(8, 8);
+    else if (K == 1024) BS_POPP(16, 8);
+    else if (K == 2048) BS_POPP(32, 8);
     else return BS_EUNSUPPORTED;
 #undef BS_POPP
     return launch_rc();
