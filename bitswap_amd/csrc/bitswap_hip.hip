@@ -27,6 +27,11 @@
 #ifndef BS_SERIAL_PRIO
 #define BS_SERIAL_PRIO 3
 #endif
+// rows of pivots + anchors k_rans_pop_pivot keeps in flight (8: 92 registers; 16: 125, which cost the GEMM beside it more than
+// the deeper prefetch gave -- DESIGN 3.7)
+#ifndef BS_POP_PF
+#define BS_POP_PF 8
+#endif
 #include <stdint.h>
 
 #include "../../include/bitswap_hip.h"
@@ -1575,10 +1580,10 @@ int dispatch_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t ca
 #define BS_POPP(NPL, PF)                                                                                              \
     hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, endpoints, \
                        e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status)
-    if (K == 256) BS_POPP(4, 8);
-    else if (K == 512) BS_POPP(8, 8);
-    else if (K == 1024) BS_POPP(16, 8);
-    else if (K == 2048) BS_POPP(32, 8);
+    if (K == 256) BS_POPP(4, BS_POP_PF);
+    else if (K == 512) BS_POPP(8, BS_POP_PF);
+    else if (K == 1024) BS_POPP(16, BS_POP_PF);
+    else if (K == 2048) BS_POPP(32, BS_POP_PF);
     else return BS_EUNSUPPORTED;
 #undef BS_POPP
     return launch_rc();
