@@ -472,7 +472,7 @@ def main(args):
         ks, ws = min(args.steps, 6), min(args.warmup, 1)
         import copy
         import gc
-        for (wn, ch, gr, fmt, reg) in (("imagenet4", 1000, 2, "reference", None), ("cifar8", 100, 1, "reference", None),
+        for (wn, ch, gr, fmt, reg) in (("imagenet4", 1000, 2, "reference", None), ("cifar8", 100, 2, "reference", None),
                                        ("cifar8", 1000, 2, "reference", "lowrate"),
                                        ("cifar8", 800, 2, "wave64", None), ("cifar8", 13, 1, "wave64", None)):
             gc.collect()                       # the previous workload's model, bins and states go before the next is built

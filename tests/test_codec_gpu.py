@@ -189,17 +189,19 @@ def test_fused_epilogues_match_torch_modules(name, algo):
         assert torch.allclose(a, torch.nn.functional.elu(x), atol=1e-6)
 
 
-@pytest.mark.parametrize("fmt", ["reference", "wave64"])
+@pytest.mark.parametrize("fmt,graphs", [("reference", "1"), ("reference", "0"), ("wave64", "1")])
 @pytest.mark.parametrize("bitswap", [1, 0])
-def test_grouped_codec_equals_plain_codec(bitswap, fmt):
-    """GroupedCodec (chain groups on separate HIP streams, enqueue order interleaved) is a scheduling
-    device only: every chain's stream equals the one the plain single-stream codec produces for the same
-    group composition, the receiver returns the blocks, and all states unwind.  Reference format: a bulk and a serial
-    stream per group; 64-state format: one stream per group."""
+def test_grouped_codec_equals_plain_codec(bitswap, fmt, graphs, monkeypatch):
+    """GroupedCodec (chain groups on separate HIP streams) is a scheduling device only: every chain's stream equals the
+    one the plain single-stream codec produces for the same group composition, the receiver returns the blocks, and all
+    states unwind.  One in-order stream per group in both formats; with few chains per group (reference format) every
+    group's block step is replayed from its own hipGraph on its own stream (graphs = 1), else the enqueue order of the
+    groups is interleaved operation by operation."""
     from bitswap_amd.codec import GroupedCodec, Hip64Backend, HipBackend
     from bitswap_amd.hip import split_state
+    monkeypatch.setenv("BITSWAP_GROUP_GRAPHS", graphs)
     model, zend, zcen = workload.build("cifar8", DEV, quantbits=10, small=16)
-    B, n = 6, 3
+    B, n = 6, 4
     images = workload.synthetic_blocks(B * n, model.xs, seed=21).view(B, n, -1).to(torch.int32).to(DEV)
     init = initial_states(B, 12000)
     mk = (lambda: Hip64Backend(DEV)) if fmt == "wave64" else (lambda: HipBackend(DEV))
@@ -225,6 +227,8 @@ def test_grouped_codec_equals_plain_codec(bitswap, fmt):
     gc.check(states)
     assert torch.equal(out, images)
     assert gc.to_lists(states) == ([split_state(s) for s in init] if fmt == "wave64" else init)
+    if fmt == "reference":
+        assert (sum(c.graph_captures for c in gc.codecs) > 0) == (graphs == "1")
 
 
 def test_config3_shape_many_blocks_lossless():
