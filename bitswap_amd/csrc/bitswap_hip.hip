@@ -314,6 +314,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
     // (mu, scale) of the next chain are fetched while the current one is computed: the row is
     // wave-uniform, so these are scalar loads whose latency would otherwise sit in front of every row
     PT mu_n = mu[(int64_t)b0 * D + d], sc_n = scale[(int64_t)b0 * D + d];
+    int sym_n = 0;
+    if (MODE == M_ENCODE) sym_n = sym[(int64_t)b0 * D + d];
     for (int b = b0; b < b1; ++b) {
         const int64_t row = (int64_t)b * D + d;
         const double m_ = (double)mu_n;
@@ -324,6 +326,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
         const int64_t nrow = (int64_t)min(b + 1, b1 - 1) * D + d;
         mu_n = mu[nrow];
         sc_n = scale[nrow];
+        const int sym_c = sym_n;
+        if (MODE == M_ENCODE) sym_n = sym[nrow];
 
         Bins<NPL> bn;
         const bool dom = logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
@@ -398,17 +402,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
         } else {
             // the symbol is wave-uniform (one row per wave): its lane and bin are scalars, so (f_s, c_s)
             // come out of the registers by scalar index instead of a per-bin select
-            const int s = __builtin_amdgcn_readfirstlane(sym[row]);
+            // (fetched a row ahead, like mu and scale: a scalar load whose latency would otherwise sit at the end of every row)
+            const int s = __builtin_amdgcn_readfirstlane(sym_c);
             const bool ok = (s >= 0) && (s < K);
             if (!ok && lane == 0 && status[b] == BS_ST_OK) status[b] = BS_ST_BADSYMBOL;  // first error sticks
             const int ss = ok ? s : 0;
             const int idx = ss % NPL;
-            Bins<NPL> cum;  // cum[i] = c_i of this lane's bins
+            // c_s = the lane's first cumulative value + the idx bins in front of the symbol: idx is a scalar, so this is a
+            // scalar branch to the one prefix that is needed (idx adds) instead of all NPL prefixes and two selects
+            uint32_t fs = 0, cs = c;
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) { cum.t[i] = c; c += bn.t[i] + 1u; }
+            for (int k = 0; k < NPL; ++k) {
+                if (idx == k) {
+                    uint32_t a = c;
+#pragma unroll
+                    for (int i = 0; i < k; ++i) a += bn.t[i] + 1u;
+                    cs = a;
+                    fs = bn.t[k] + 1u;
+                }
+            }
             if (lane == ss / NPL) {
-                out0[row] = bn.t[idx] + 1u;
-                out1[row] = cum.t[idx];
+                out0[row] = fs;
+                out1[row] = cs;
             }
         }
     }
