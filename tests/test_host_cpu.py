@@ -595,3 +595,40 @@ def test_lowrate_regime_codes_its_own_samples_at_a_trained_rate():
     assert rc == O.OK and (f == 1).mean() > 0.9
     out = codec.decompress(st, n)
     assert torch.equal(out, imgs) and st.to_lists() == initial_states(B)
+
+
+def test_timeline_tool_classifies_wall_time(tmp_path):
+    """tools/prof_summary.py timeline (the evidence behind DESIGN 3.7): a synthetic kernel trace with known overlaps comes
+    out as the right split of wall time into idle / serial-only / one bulk kernel (+ serial) / two bulk kernels, and bulk
+    calls are classified by their company; the 36- and 64-position GEMMs are told apart by the transform in front of them."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    ms = 1_000_000
+    rows = [("void k_wino_fused<6, 6>(float)", 0, 1 * ms, 1), ("void k_wino_gemm<4, 2, 2>(float)", 1 * ms, 3 * ms, 1),
+            ("void k_rans_pop_pivot<16, float, 8>(x)", 1 * ms, 3 * ms, 2),            # beside the first GEMM, all of it
+            ("void k_wino_fused<8, 8>(float)", 3 * ms, 4 * ms, 1), ("void k_wino_gemm<4, 2, 2>(float)", 4 * ms, 6 * ms, 1),
+            ("void k_logistic<16, float, 4, true>(y)", 5 * ms, 7 * ms, 2),            # shares 1 ms with the second GEMM
+            ("k_rans_push(z)", 8 * ms, 9 * ms, 2)]                                     # serial only, after 1 ms of nothing
+    d = tmp_path / "trace"
+    d.mkdir()
+    with open(d / "x_kernel_trace.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Queue_Id"])
+        for r in rows:
+            w.writerow(r)
+    out = tmp_path / "tl.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "prof_summary.py"), "timeline", str(d), str(out), "9", "0"],
+                          stdout=subprocess.DEVNULL)
+    res = json.load(open(out))
+    wall = res["wall_ms"]
+    assert abs(res["span_ms"] - 9.0) < 1e-9
+    assert abs(wall["bulk_1"] - 4.0) < 1e-9 and abs(wall["bulk_1+serial"] - 2.0) < 1e-9 and abs(wall["bulk_2+"] - 1.0) < 1e-9
+    assert abs(wall["idle"] - 1.0) < 1e-9 and abs(wall["serial_only"] - 1.0) < 1e-9
+    calls = res["bulk_call_us"]
+    g36 = [v for k, v in calls.items() if "[T=36]" in k][0]
+    g64 = [v for k, v in calls.items() if "[T=64]" in k][0]
+    assert g36["beside_serial"] == {"calls": 1, "mean_us": 2000.0} and g36["shared"]["calls"] == 0
+    assert g64["shared"] == {"calls": 1, "mean_us": 2000.0} and g64["beside_serial"]["calls"] == 0
