@@ -825,12 +825,13 @@ def test_own_gemm_route_round_trip():
     assert float((mu1 - mu2).abs().max()) < 1e-4 * max(1.0, float(mu2.abs().max())) and float((s1 - s2).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("ts,N,C,hw", [(6, 21, 40, 16), (8, 21, 40, 16), (6, 7, 9, 8), (8, 3, 17, 32), (6, 400, 256, 16)])
+@pytest.mark.parametrize("ts,N,C,hw", [(6, 21, 40, 16), (8, 21, 40, 16), (6, 7, 9, 8), (8, 3, 17, 32), (6, 400, 256, 16),
+                                       (6, 21, 96, 16), (6, 3, 32, 16), (6, 600, 128, 16)])
 def test_conv3_wino_matches_conv_plus_transform(ts, N, C, hw):
     """bs_conv3_wino_f32 (input conv of a stack, Cin = 8, fused with bias + ELU + the forward transform) against
     F.conv2d in float64 followed by the separate transform pass; partial image groups (N not a multiple of the images
     per wavefront), odd channel counts (a wavefront walks channels in pairs), 8x8 / 16x16 / 32x32 planes, and the
-    bench's own shape (400 blocks x 256 channels)."""
+    bench's own shape (400 blocks x 256 channels), multiples of 32 channels with a partial last group of images."""
     from bitswap_amd import hip
     g = torch.Generator().manual_seed(ts)
     Cin = 8
