@@ -145,7 +145,11 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
         container.save_state(os.path.join(sdir, stream_name(scheme, quantbits, nz, c, wave64)), s)
     # what a receiver must reproduce for these streams to decode (bitswap_amd/meta.py); read back and enforced by
     # decompress_streams() and by the --decompress leg below
-    fp = meta.fingerprint(codec, chains_per_call=len(mine))
+    cpc = len(mine)
+    if world > 1:       # every rank's shard size (they differ when the experiments do not divide): one record for all ranks
+        per_rank = [int(round(v)) for v in dist.allreduce_sum([float(len(mine)) if r == rank else 0.0 for r in range(world)])]
+        cpc = per_rank[0] if len(set(per_rank)) == 1 else per_rank
+    fp = meta.fingerprint(codec, chains_per_call=cpc)
     if rank == 0:
         meta.save(os.path.join(sdir, "stream_meta.json"), fp, world_size=world, experiments=experiments,
                   ndatapoints=ndatapoints)

@@ -45,7 +45,10 @@ def fingerprint(codec, chains_per_call=None):
           "cdf_spec": {"z": [2 if s is not None else 1 for s in codec.zstep], "x": 2 if codec.xstep is not None else 1},
           "library_abi": int(hip.ABI_VERSION), "backend": getattr(codec.backend, "name", "?"), "conv_route": route(m)}
     if not batch_invariant(fp) and chains_per_call is not None:
-        fp["conv_route"]["chains_per_call"] = int(chains_per_call)
+        # (a list: chains per call of every rank of an unevenly sharded multi-process run -- 5 experiments on 3 ranks code 2, 2
+        # and 1 chains together; a receiver has to be sharded the same way to reproduce them)
+        fp["conv_route"]["chains_per_call"] = ([int(c) for c in chains_per_call] if isinstance(chains_per_call, (list, tuple))
+                                               else int(chains_per_call))
     return fp
 
 
