@@ -27,10 +27,11 @@
 #ifndef BS_SERIAL_PRIO
 #define BS_SERIAL_PRIO 3
 #endif
-// rows of pivots + anchors k_rans_pop_pivot keeps in flight (8: 92 registers; 16: 125, which cost the GEMM beside it more than
-// the deeper prefetch gave -- DESIGN 3.7)
+// rows of pivots + anchors k_rans_pop_pivot keeps in flight: the fewer registers the coder wavefronts hold, the less they
+// cost the bulk kernels they sit beside -- 16 rows: 125 registers, step 188.4 ms; 8: 92, 181.5; 4: 76,
+// 180.0 (A/B on one box each; 4 rows are still ~3 us ahead of their use)
 #ifndef BS_POP_PF
-#define BS_POP_PF 8
+#define BS_POP_PF 4
 #endif
 #include <stdint.h>
 
