@@ -216,21 +216,34 @@ def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=F
                             ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"), save=False)
     codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
                          backend=_format_backend(fmt, backend, dev), cdf_spec=cdf_spec)
-    meta.check(written, meta.fingerprint(codec, chains_per_call=experiments), f"{sdir}/stream_meta.json")
+    # Which chains were coded together.  A batch-invariant conv route (the GPU's) does not care: everything in one call.
+    # Otherwise the streams of a multi-process sender decode only in the sender's own shards (dist.shard_chains is a pure
+    # function of the counts the record holds): this single process then plays the ranks one after the other.
+    mine = meta.fingerprint(codec, chains_per_call=experiments)
+    shards = [list(range(experiments))]
+    sender_world = int(written.get("world_size", 1))
+    if not meta.batch_invariant(mine) and sender_world > 1:
+        shards = [dist.shard_chains(experiments, sender_world, r) for r in range(sender_world)]
+        sizes = [len(sh) for sh in shards]
+        mine = meta.fingerprint(codec, chains_per_call=sizes[0] if len(set(sizes)) == 1 else sizes)
+        shards = [sh for sh in shards if sh]
+    meta.check(written, mine, f"{sdir}/stream_meta.json")
     wave64 = fmt == "wave64" and backend is None
     states = [container.load_state(os.path.join(sdir, stream_name(scheme, quantbits, nz, c, wave64)))
               for c in range(experiments)]
     nwords = max((sum(len(x) for x in s) if wave64 else len(s)) for s in states)
-    state = codec.backend.new_state(states, nwords + ndatapoints * (model.xdim + 64) + 4 * model.zdim_flat)
-    out = codec.decompress(state, ndatapoints).cpu()
-    randindices = np.load(os.path.join(outdir, "bitstreams", dataset, "indices.npy"))
-    want = images[torch.from_numpy(randindices.reshape(-1))].view(experiments, ndatapoints, -1).to(torch.int32)
-    assert torch.equal(out, want), "decoded datapoint does not match"                     # (:319,354)
     inits = initial_states(experiments, 10000, seed=100)
     if wave64:
         from .hip import split_state
         inits = [split_state(s) for s in inits]
-    assert state.to_lists() == inits, "initial state not restored"                        # (:358)
+    out = torch.zeros((experiments, ndatapoints, model.xdim), dtype=torch.int32)
+    for sh in shards:
+        state = codec.backend.new_state([states[c] for c in sh], nwords + ndatapoints * (model.xdim + 64) + 4 * model.zdim_flat)
+        out[sh] = codec.decompress(state, ndatapoints).cpu().to(torch.int32)
+        assert state.to_lists() == [inits[c] for c in sh], "initial state not restored"   # (:358)
+    randindices = np.load(os.path.join(outdir, "bitstreams", dataset, "indices.npy"))
+    want = images[torch.from_numpy(randindices.reshape(-1))].view(experiments, ndatapoints, -1).to(torch.int32)
+    assert torch.equal(out, want), "decoded datapoint does not match"                     # (:319,354)
     if verbose:
         print(f"decoded {experiments} x {ndatapoints} datapoints from {sdir}: lossless, initial states restored")
     return out

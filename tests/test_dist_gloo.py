@@ -181,3 +181,20 @@ def test_three_rank_shards_and_gathers(tmp_path):
     import json
     meta_file = glob.glob(str(tmp_path / "bitstreams" / "**" / "stream_meta.json"), recursive=True)[0]
     assert json.load(open(meta_file))["conv_route"]["chains_per_call"] == [2, 2, 1]
+    # a receiver in ONE process: the record tells it how the sender was sharded, it decodes the shards one after the other
+    # (a route that is not batch-invariant reproduces the streams only in the sender's batches) -- and refuses a record it
+    # cannot reproduce
+    import oracle as O
+    from oracle.backend import OracleBackend
+    from bitswap_amd import cli, meta
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    out = cli.decompress_streams(6, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=OracleBackend(O.MODE_DET), small=8,
+                                 verbose=False)
+    assert tuple(out.shape[:2]) == (5, 2)
+    rec = json.load(open(meta_file))
+    rec["world_size"] = 2                          # "written by two ranks": 3 + 2 chains per call, not what the record says
+    json.dump(rec, open(meta_file, "w"))
+    with pytest.raises(meta.StreamMismatch):
+        cli.decompress_streams(6, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=OracleBackend(O.MODE_DET), small=8,
+                               verbose=False)
