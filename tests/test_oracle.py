@@ -214,3 +214,24 @@ def test_cdf_spec2_domain_is_enforced():
     sc[5] = 0.5                                        # healthy again: spec 2 codes the layer
     sym, rc = O.layer_pop(st, e, mu, sc, 31, 8, O.MODE_DET2)
     assert rc == O.OK
+
+
+def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
+    """Where the reference is present (the build container; never the GPU box), tests/golden/make_golden.py re-runs the
+    imported reference classes on the seeded inputs and must reproduce the committed table / rANS / bin fixtures byte for
+    byte: the files that pin the oracle are the reference's output, not an edited copy.  Skipped without the reference."""
+    import os
+    import subprocess
+    import sys
+    ref = os.environ.get("BITSWAP_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        pytest.skip("reference not present on this host")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    code = ("import sys; sys.path.insert(0, %r); import make_golden as mg; mg.OUT = %r; "
+            "mg.make_tables_and_rans(); mg.make_bins()") % (gold, str(tmp_path))
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    for name in ("tables_rans.npz", "bins.npz"):
+        new, old = np.load(tmp_path / name), np.load(os.path.join(gold, name))
+        assert sorted(new.files) == sorted(old.files)
+        for k in old.files:
+            assert new[k].dtype == old[k].dtype and np.array_equal(new[k], old[k]), (name, k)
