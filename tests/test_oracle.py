@@ -218,8 +218,10 @@ def test_cdf_spec2_domain_is_enforced():
 
 def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
     """Where the reference is present (the build container; never the GPU box), tests/golden/make_golden.py re-runs the
-    imported reference classes on the seeded inputs and must reproduce the committed table / rANS / bin fixtures byte for
-    byte: the files that pin the oracle are the reference's output, not an edited copy.  Skipped without the reference."""
+    imported reference classes on the seeded inputs and must reproduce EVERY committed fixture byte for byte (tables, rANS
+    word streams, bins, reference Model outputs, replayed sender / receiver chains, bit accounting, the on-disk surface,
+    the discretize() replay): the files that pin the oracle and the product are the reference's output, not an edited
+    copy.  Skipped without the reference."""
     import os
     import subprocess
     import sys
@@ -228,10 +230,13 @@ def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
         pytest.skip("reference not present on this host")
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     code = ("import sys; sys.path.insert(0, %r); import make_golden as mg; mg.OUT = %r; "
-            "mg.make_tables_and_rans(); mg.make_bins()") % (gold, str(tmp_path))
-    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-    for name in ("tables_rans.npz", "bins.npz"):
-        new, old = np.load(tmp_path / name), np.load(os.path.join(gold, name))
+            "mg.make_tables_and_rans(); mg.make_bins(); mg.make_model_and_chains(); mg.make_rgb4_chain(); "
+            "mg.make_bits_fixture(); mg.make_surface_fixture(); mg.make_discretize_fixture()") % (gold, str(tmp_path))
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    committed = sorted(f for f in os.listdir(gold) if f.endswith(".npz"))
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == committed
+    for name in committed:
+        new, old = np.load(tmp_path / name, allow_pickle=True), np.load(os.path.join(gold, name), allow_pickle=True)
         assert sorted(new.files) == sorted(old.files)
         for k in old.files:
             assert new[k].dtype == old[k].dtype and np.array_equal(new[k], old[k]), (name, k)
