@@ -240,3 +240,54 @@ def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
         assert sorted(new.files) == sorted(old.files)
         for k in old.files:
             assert new[k].dtype == old[k].dtype and np.array_equal(new[k], old[k]), (name, k)
+
+
+def test_oracle_integer_half_against_the_live_reference_on_random_tables(tmp_path):
+    """Beyond the committed fixtures: where the reference is present, its own ANS class (mnist_compress.py:14-68, Python
+    integers) builds tables for 40 random pmf sets -- peaked, flat, tied, K from 4 to 2048, quantisation 2..11 bits -- pops,
+    pushes back and pushes fresh symbols; the C oracle must produce the same integer tables and the same words."""
+    import os
+    import subprocess
+    import sys
+    ref = os.environ.get("BITSWAP_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        pytest.skip("reference not present on this host")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import make_golden as mg
+rng = np.random.RandomState(77)
+out = {}
+np.random.seed(100)
+for i in range(40):
+    q = int(rng.randint(2, 12)); K = 1 << q; D = int(rng.randint(1, 9))
+    kind = i %% 4
+    if kind == 0: p = rng.dirichlet(np.full(K, 0.05), size=D)
+    elif kind == 1: p = rng.dirichlet(np.full(K, 50.0), size=D)
+    elif kind == 2: p = np.full((D, K), 1.0 / K)
+    else:
+        p = rng.dirichlet(np.full(K, 1.0), size=D); p[:, :2] = p[:, :2].mean()
+        p /= p.sum(axis=1, keepdims=True)
+    a = mg.ANS(torch.from_numpy(p), bits=31, quantbits=q)
+    st = mg.init_state(64)
+    out[f"{i}_pmf"] = p; out[f"{i}_q"] = np.int32(q)
+    out[f"{i}_f"] = a.pmfs.astype(np.uint32); out[f"{i}_cdf"] = a.cdfs.astype(np.uint32)
+    out[f"{i}_s0"] = mg.words(st)
+    st, sym = a.decode(st)
+    out[f"{i}_sym"] = sym.numpy().astype(np.int32); out[f"{i}_s1"] = mg.words(st)
+    fresh = torch.from_numpy(rng.randint(0, K, size=D))
+    st = a.encode(st, fresh)
+    out[f"{i}_fresh"] = fresh.numpy().astype(np.int32); out[f"{i}_s2"] = mg.words(st)
+np.savez_compressed(%r, **out)
+""" % (gold, str(tmp_path / "live.npz"))
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    g = np.load(tmp_path / "live.npz")
+    for i in range(40):
+        f, cdf, rc = O.tables(g[f"{i}_pmf"], 31, int(g[f"{i}_q"]))
+        assert rc == O.OK and np.array_equal(f, g[f"{i}_f"]) and np.array_equal(cdf, g[f"{i}_cdf"]), i
+        st = O.Stack(words_to_state(g[f"{i}_s0"]))
+        sym, rc = O.pop(st, cdf)
+        assert rc == O.OK and np.array_equal(sym, g[f"{i}_sym"]) and st.tolist() == words_to_state(g[f"{i}_s1"]), i
+        assert O.push(st, cdf, g[f"{i}_fresh"]) == O.OK and st.tolist() == words_to_state(g[f"{i}_s2"]), i
