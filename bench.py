@@ -81,8 +81,14 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true", help="skip the exclusive roofline passes after the timed region")
     ap.add_argument("--regime", default=None, choices=["lowrate"],
                     help="lowrate: the calibrated synthetic model coding its own samples at a trained model's rate (workload.py)")
-    ap.add_argument("--groups", type=int, default=2,
-                    help="chain groups per GPU on separate HIP streams (serial rANS of one group under the convs of another)")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="chain groups per GPU on separate HIP streams (serial rANS of one group under the convs of another); "
+                         "0 = auto: 2 from 64 chains per GPU on, else 1 (the forked block step overlaps a group with itself)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (the driver's default): every rank codes its own --chains chains.  strong: --total-chains chains "
+                         "IN TOTAL -- the reference's 100 experiments / 100 crop images, BASELINE configs 4 and 5 -- sharded over "
+                         "the ranks by bitswap_amd.dist.shard_chains (round-robin; LPT by block count for imagenetcrop4)")
+    ap.add_argument("--total-chains", type=int, default=100, help="chains in total over all ranks (--scaling strong)")
     ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
                     help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
     ap.add_argument("--cdf-spec", type=int, default=2, choices=[1, 2])
@@ -115,7 +121,9 @@ def cpu_baseline(args, name):
     outs = [codec.decode_block(state) for _ in range(n)]
     dt = time.perf_counter() - t0
     ok = all(torch.equal(outs[n - 1 - xi], images[:, xi]) for xi in range(n))
+    import platform
     out = {"value": B * n * 1024 / dt, "unit": "pixels/s", "cores": threads, "kind": "port",
+           "host": f"the host of this GPU run ({platform.node()}, {cores} hardware threads, {threads} used)", "same_host": True,
            "sample": f"{B} chains x {n} block(s) of {name}, sender+receiver, oracle C (libm CDF) + torch-CPU convs, "
                      f"{dt:.1f} s, lossless={ok}"}
     out["reference_python"] = reference_python_baseline(name)
@@ -150,10 +158,14 @@ def reference_python_baseline(name):
         return None
 
 
-def _valu_busy(spec):
+def _valu_busy(kernel_key):
+    """SQ-counter VALU-busy share of the kernel that was actually timed (profiles/valu_busy.json, tools/pmc_valu.sh), keyed by
+    its flavour -- e.g. "k_logistic<16,float,pivot,uniform>"; None when no counter run of THAT flavour is on file (round 3
+    printed the whole-row flavour's figure under the pivot kernel's name)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "valu_busy.json")))["kernels"]
-        return d["k_logistic<16,float,decode,uniform>" if spec == 2 else "k_logistic<16,float,decode,generic>"]["valu_busy"]
+        d = json.load(open(os.path.join(ROOT, "profiles", "valu_busy.json")))
+        k = d["kernels"].get(kernel_key)
+        return None if k is None else {"valu_busy": k["valu_busy"], "source": d.get("source")}
     except Exception:
         return None
 
@@ -227,14 +239,70 @@ def gemm_roofline(model, chains, dev, warm=100, reps=100):
         return {"error": repr(e)}
 
 
-def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gather=False, want_roofline=True, regime=None):
-    """One measurement by the contract's procedure.  Returns a dict (timings are max over ranks)."""
+def strong_plan(total, world, name, steps, seed=100):
+    """--scaling strong: which chains every rank codes, and how long they are.  -> per rank (chain ids, blocks per chain).
+    Equal chains (the reference's 100 experiments, mnist_compress.py:147-161: configs 2, 3, 5): round-robin, `steps` blocks
+    each.  imagenetcrop4 (config 4, imagenetcrop_compress.py:279-300: one image = one chain): image sizes H, W ~ U{256..512}
+    cropped to multiples of 32 as SURVEY 8(d) has them -- 64..256 blocks -- scaled so that a 512 x 512 image is `steps`
+    blocks long, sharded longest-processing-time-first by block count."""
+    from bitswap_amd import dist as bdist
+    if name == "imagenetcrop4":
+        rng = np.random.RandomState(seed)
+        tiles = rng.randint(256, 513, size=(total, 2)) // 32
+        lengths = np.maximum(1, np.round(tiles[:, 0] * tiles[:, 1] * (steps / 256.0))).astype(int).tolist()
+        weights = lengths
+    else:
+        lengths, weights = [int(steps)] * total, None
+    out = []
+    for r in range(world):
+        ids = bdist.shard_chains(total, world, r, weights=weights)
+        out.append((ids, [lengths[c] for c in ids]))
+    return out
+
+
+def stream_words(stack, ln, hd):
+    """One finished chain as the words a sender ships: stack words + the 64-bit head as two (demo container order)."""
+    return np.concatenate([stack[: ln], np.array([hd & 0xffffffff, hd >> 32], dtype=np.uint32)])
+
+
+def gather_and_digest(streams, mine, total, rank):
+    """The path's only exchange (not timed): the finished bitstreams to rank 0 (RCCL over xGMI when world > 1, a local no-op
+    otherwise).  The digest -- CRC-32 over the streams in chain order -- does not depend on how the chains were sharded
+    when the conv route is batch-invariant: the same value at 1, 2, 4 and 8 GPUs (--scaling strong)."""
+    import zlib
+    from bitswap_amd import dist as bdist
+    try:
+        tg = time.perf_counter()
+        got = bdist.gather_streams(streams, mine, total)
+        tg = time.perf_counter() - tg
+        if rank != 0:
+            return None
+        crc = 0
+        for a in got:
+            crc = zlib.crc32(np.ascontiguousarray(a, dtype=np.uint32).tobytes() if a is not None else b"missing", crc)
+        return {"chains": len(got), "bytes": 4 * int(sum(len(a) for a in got if a is not None)), "ms": round(tg * 1e3, 2),
+                "complete": all(a is not None for a in got),
+                "own_streams_intact": all(np.array_equal(got[c], a) for c, a in zip(mine, streams)),
+                "crc32_of_streams_in_chain_order": f"{crc:08x}"}
+    except Exception as e:   # never lose the bench line to the reporting exchange
+        return {"error": repr(e)}
+
+
+def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gather=False, want_roofline=True, regime=None,
+                 chain_ids=None, total=None):
+    """One measurement by the contract's procedure.  Returns a dict (timings are max over ranks).  chain_ids / total:
+    --scaling strong -- this rank codes the chains `chain_ids` of `total`; inputs and initial words are a function of the
+    GLOBAL chain id, so a chain's stream does not depend on the rank that codes it."""
     from bitswap_amd import workload
     from bitswap_amd.codec import GroupedCodec, Timeline, initial_states
 
     model, zend, zcen = workload.build(name, dev, quantbits=args.quantbits, regime=regime)
     n = K + W
-    if regime == "lowrate":      # blocks from the calibrated model's own generative path (workload.lowrate_blocks)
+    strong = chain_ids is not None
+    if strong:
+        assert regime is None and B == len(chain_ids)
+        images = workload.synthetic_blocks(total * n, model.xs, seed=1000).view(total, n, -1)[chain_ids].to(torch.int32).to(dev)
+    elif regime == "lowrate":      # blocks from the calibrated model's own generative path (workload.lowrate_blocks)
         images = workload.lowrate_blocks(model, B * n, seed=1000 + rank, batch=400).view(B, n, -1).to(torch.int32).to(dev)
     else:
         images = workload.synthetic_blocks(B * n, model.xs, seed=1000 + rank).view(B, n, -1).to(torch.int32).to(dev)
@@ -249,7 +317,11 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
         c.tables_on = args.tables_on
         if args.no_graphs:
             c.use_graphs = False
-    init = initial_states(B, 10000, seed=100 + rank)
+    if strong:
+        every = initial_states(total, 10000, seed=100)
+        init = [every[c] for c in chain_ids]
+    else:
+        init = initial_states(B, 10000, seed=100 + rank)
     states = codec.new_states(B, n, states=init)
     rest_lens = [torch.zeros_like(st.len) for st in states]
 
@@ -299,24 +371,12 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     # for bits/dim -- RCCL over xGMI when world > 1 (bitswap_amd/dist.py), a local no-op otherwise
     gather = None
     if sent is not None:
-        from bitswap_amd import dist as bdist
-        try:
-            streams = []
-            for stack, ln, hd in sent:
-                stack, ln, hd = stack.cpu().numpy().view(np.uint32), ln.cpu().numpy(), hd.cpu().numpy().view(np.uint64)
-                for b in range(stack.shape[0]):   # stream = stack words + the 64-bit head as two words (demo container order)
-                    streams.append(np.concatenate([stack[b, : ln[b]], np.array([hd[b] & 0xffffffff, hd[b] >> 32], dtype=np.uint32)]))
-            mine = [rank + world * c for c in range(B)]            # global chain ids, round-robin like shard_chains()
-            tg = time.perf_counter()
-            got = bdist.gather_streams(streams, mine, world * B)
-            tg = time.perf_counter() - tg
-            if rank == 0:
-                words = int(sum(len(a) for a in got))
-                gather = {"chains": len(got), "bytes": 4 * words, "ms": round(tg * 1e3, 2),
-                          "complete": all(a is not None for a in got),
-                          "own_streams_intact": all(np.array_equal(got[c], a) for c, a in zip(mine, streams))}
-        except Exception as e:   # never lose the bench line to the reporting exchange
-            gather = {"error": repr(e)}
+        streams = []
+        for stack, ln, hd in sent:
+            stack, ln, hd = stack.cpu().numpy().view(np.uint32), ln.cpu().numpy(), hd.cpu().numpy().view(np.uint64)
+            streams += [stream_words(stack[b], ln[b], hd[b]) for b in range(stack.shape[0])]
+        mine = list(chain_ids) if strong else [rank + world * c for c in range(B)]   # global chain ids, round-robin like shard_chains()
+        gather = gather_and_digest(streams, mine, total if strong else world * B, rank)
     if dist is not None:
         tot = torch.tensor([float(bits.sum()), float(B * K * codec.X), float(ok)], device=dev, dtype=torch.float64)
         dist.all_reduce(tot)
@@ -356,20 +416,22 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
         table_bytes = Z * (Kb - 1) * 8
         alg_batched = int(table_bytes + rows * (12 + (512 if pivot else 0)))
         survey_alg = int(rows * ((Kb - 1) * 8 + 12))
-        traffic = None
+        traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp) and args.format == "reference":
             try:
-                per_row = json.load(open(tp)).get(name, {}).get("k_logistic_pivot_bytes_per_row" if pivot else "k_logistic_decode_bytes_per_row")
+                tj = json.load(open(tp)).get(name, {})
+                per_row = tj.get("k_logistic_pivot_bytes_per_row" if pivot else "k_logistic_decode_bytes_per_row")
                 traffic = None if per_row is None else int(per_row * rows)   # PMC bytes/row x rows of one launch
+                traffic_src = ["profiles/" + f for f in tj.get("source", [])]
             except Exception:
                 traffic = None
         a_block = algorithmic_bytes_per_block(codec)
-        path = 2.0 * a_block * world * B * K / dt / 1e9
+        path = 2.0 * a_block * (total if strong else world * B) * K / dt / 1e9
         hbm = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                "alg_bytes_per_launch": alg_batched, "achieved": round(alg_batched / avg / 1e9, 1),
                "frac": round(alg_batched / avg / 1e9 / HBM_PEAK_GBPS, 5),
-               "traffic_bytes_per_launch": traffic,
+               "traffic_bytes_per_launch": traffic, "traffic_source": traffic_src,
                "traffic_achieved": None if traffic is None else round(traffic / avg / 1e9, 1),
                "traffic_frac": None if traffic is None else round(traffic / avg / 1e9 / HBM_PEAK_GBPS, 4),
                "note": "alg = endpoint table once per launch + 12 B/row (mu, scale, symbol)"
@@ -378,17 +440,27 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                        + ("" if pivot else ", 98 % of it the cdf-row hand-off to k_rans_pop_wave")
                        + f"; SURVEY 8(d)'s per-block count would be {survey_alg} B per launch, of which all but the first table "
                          "pass are L2 hits"}
+        kkey = f"k_logistic<16,float,{'pivot' if pivot else 'decode'},{'uniform' if spec == 2 else 'generic'}>"
+        # the SURVEY 8(d)-literal figure for this kernel, kept visible: (K-1)*8 + 12 B per row x rows / launch time against the
+        # HBM peak.  Above 1 whenever more than one chain shares a launch: all but the first pass over the [Z, K-1] endpoint
+        # table are L2 hits, so it is not an HBM figure -- which is why `frac` is quoted on the bound the kernel sits on
+        survey = {"hbm_survey_bytes_per_launch": survey_alg, "hbm_survey_achieved_GBps": round(survey_alg / avg / 1e9, 1),
+                  "hbm_survey_frac": round(survey_alg / avg / 1e9 / HBM_PEAK_GBPS, 4),
+                  "hbm_survey_note": "SURVEY 8(d) literal: 8196 B/row x rows_per_launch / avg_launch_ms / 8 TB/s; > 1 = L2 hits "
+                                     "(the endpoint table is re-read from L2 by every chain of a launch), not HBM traffic"}
         if slots is not None:
             ach = rows * slots / avg / 1e9
             roof = {"kernel": kname, "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINSTR, 1),
-                    "unit": "Ginstr/s", "frac": round(ach / VALU_PEAK_GINSTR, 4), "slots_per_row": slots,
+                    "unit": "Ginstr/s", "frac": round(ach / VALU_PEAK_GINSTR, 4),
+                    "path_frac": round(path / world / HBM_PEAK_GBPS, 4), **survey, "slots_per_row": slots,
                     # measured by SQ counters (profiles/valu_busy.json, tools/pmc_valu.sh): share of the SIMD cycles the
-                    # VALU pipe is busy while the kernel runs, at the clock the chip actually holds under float64 load
-                    "valu_busy_pmc": _valu_busy(spec)}
+                    # VALU pipe is busy while THIS flavour of the kernel runs; None: no counter run of it on file
+                    "valu_busy_pmc": _valu_busy(kkey)}
         else:       # no issue model for this kernel shape: the counter-side HBM figure is the headline
             roof = {"kernel": kname, "bound": "hbm", "achieved": hbm["traffic_achieved"] or hbm["achieved"],
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": hbm["traffic_frac"] if hbm["traffic_frac"] is not None else hbm["frac"]}
+                    "frac": hbm["traffic_frac"] if hbm["traffic_frac"] is not None else hbm["frac"],
+                    "path_frac": round(path / world / HBM_PEAK_GBPS, 4), **survey}
         roof.update({"traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg * 1e3, 4),
                      "timing": ("exclusive: HIP events on the launch stream, single-stream pass of one chain group after the "
                                 "timed region" if excl else "time-shared: HIP events inside the timed region"),
@@ -404,32 +476,133 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                      "mfma": gemm_roofline(model, B // max(1, groups), dev)})
     breakdown = {k: round(v[0] / dt, 4) for k, v in sorted(totals.items())} if totals else None
     res = {"workload": name, "chains_per_gpu": B, "chain_groups": groups, "steps": K, "warmup": W,
-           "value": world * B * K * 1024 / dt, "ms_per_step": dt / K * 1e3, "lossless": ok, "bits_per_dim": bpd,
+           "value": (total if strong else world * B) * K * 1024 / dt, "ms_per_step": dt / K * 1e3, "lossless": ok, "bits_per_dim": bpd,
            "stream_time_fraction": breakdown, "roofline": roof, "stream_gather": gather,
            "codec": codec, "model": model}
     return res
 
 
-def extra_in_child(args, wn, ch, gr, fmt, reg, steps, warmup):
+def run_ragged(args, name, chain_ids, lengths, total, K, W, dev, rank, world, dist, want_gather=True):
+    """BASELINE config 4's shape: one chain per image, chains of different lengths in ONE lock-step run (the active set
+    shrinks as short images finish: BitSwapCodec.compress_ragged / decompress_ragged), the crop model on its fixed conv
+    micro-batches (nn_batch: an image's stream does not depend on the images it is coded with, imagenetcrop_compress.py:
+    279-300 codes them one at a time).  Timed like the contract says: W untimed block steps of every chain first, then the
+    whole sender run and the receiver run that undoes it between barriers; value = blocks coded by all ranks x 1024 / t."""
+    from bitswap_amd import workload
+    from bitswap_amd.codec import BitSwapCodec, initial_states
+
+    nn_batch = int(os.environ.get("BITSWAP_CROP_NN_BATCH", "32"))
+    model, zend, zcen = workload.build(name, dev, quantbits=args.quantbits, nn_batch=nn_batch)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=args.quantbits, bitswap=bool(args.bitswap), cdf_spec=args.cdf_spec)
+    if args.no_graphs:
+        codec.use_graphs = False
+    B = len(chain_ids)
+    chains = [workload.synthetic_blocks(n, model.xs, seed=5000 + c).to(torch.int32).to(dev) for c, n in zip(chain_ids, lengths)]
+    one = initial_states(1, 10000, 100)[0]               # every image starts from the same words (:249,122)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if W:       # warm-up: W block steps of every chain, undone
+        wch = [workload.synthetic_blocks(W, model.xs, seed=9000 + c).to(torch.int32).to(dev) for c in chain_ids]
+        st, order, met = codec.compress_ragged(wch)
+        codec.decompress_ragged(st, met["nblocks"])
+        del st, wch
+    staged = codec.stage_ragged(chains)
+    state = codec.new_states(B, staged[2][0], states=[list(one) for _ in range(B)])
+    barrier()
+    t0 = time.perf_counter()
+    state, order, met = codec.compress_ragged(chains, state=state, staged=staged)
+    sent = (state.stack.clone(), state.len.clone(), state.head.clone()) if want_gather else None
+    out = codec.decompress_ragged(state, met["nblocks"])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = all(torch.equal(out[k], chains[i]) for k, i in enumerate(order)) and state.to_lists() == [list(one)] * B
+    nblk = int(sum(lengths))
+    bits = float(met["total"].sum())
+    gather = None
+    if sent is not None:
+        stack, ln, hd = sent[0].cpu().numpy().view(np.uint32), sent[1].cpu().numpy(), sent[2].cpu().numpy().view(np.uint64)
+        streams = [None] * B
+        for k, i in enumerate(order):
+            streams[i] = stream_words(stack[k], ln[k], hd[k])
+        gather = gather_and_digest(streams, list(chain_ids), total, rank)
+    tot = torch.tensor([bits, float(nblk * codec.X), float(ok), float(nblk)], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tot)
+    return {"workload": name, "chains_per_gpu": B, "chain_groups": 1, "steps": K, "warmup": W,
+            "value": float(tot[3]) * 1024 / dt, "ms_per_step": dt / K * 1e3, "lossless": bool(tot[2].item() == world),
+            "bits_per_dim": float(tot[0] / tot[1]), "stream_time_fraction": None, "roofline": None, "stream_gather": gather,
+            "blocks_total": int(tot[3].item()), "blocks_this_rank": nblk, "nn_batch": nn_batch,
+            "codec": codec, "model": model}
+
+
+def extra_in_child(args, spec, steps, warmup):
     """One `extra` sub-result measured the way the headline is: the first workload of a fresh process.  (Measured in the
     headline's process, after its buffers came and went, ImageNet32 nz=4 at 1000 chains reads 6.3 Mpixel/s against 6.8 on
-    its own -- profiles/r03z: device memory handed out late in a process's life is more fragmented.)  -> dict or None."""
+    its own -- profiles/r03z: device memory handed out late in a process's life is more fragmented.)  -> dict."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", wn, "--chains", str(ch), "--groups", str(gr), "--format", fmt,
-           "--steps", str(steps), "--warmup", str(warmup), "--quantbits", str(args.quantbits), "--bitswap", str(args.bitswap),
-           "--cdf-spec", str(args.cdf_spec), "--no-extra", "--no-cpu-baseline", "--no-roofline"]
-    if reg:
-        cmd += ["--regime", reg]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        d = json.loads(line)
-        return {"workload": wn, "chains_per_gpu": ch, "chain_groups": gr, "steps": d["steps"], "warmup": d["warmup"],
-                "value": d["value"], "ms_per_step": d["ms_per_step"], "lossless": d["lossless"], "bits_per_dim": d["bits_per_dim"],
-                "stream_time_fraction": d.get("stream_time_fraction"), "roofline": None,
-                "process": "own process (python bench.py --no-extra ...), like the headline"}
-    except Exception:
-        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", spec["workload"], "--groups", str(spec.get("groups", 0)),
+           "--format", spec.get("format", "reference"), "--steps", str(spec.get("steps", steps)), "--warmup", str(warmup),
+           "--quantbits", str(args.quantbits), "--bitswap", str(spec.get("bitswap", args.bitswap)), "--cdf-spec", str(args.cdf_spec),
+           "--no-extra", "--no-cpu-baseline", "--no-roofline"]
+    if spec.get("scaling") == "strong":
+        cmd += ["--scaling", "strong", "--total-chains", str(spec["chains"])]
+    else:
+        cmd += ["--chains", str(spec["chains"])]
+    if spec.get("regime"):
+        cmd += ["--regime", spec["regime"]]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        raise RuntimeError((r.stderr or r.stdout)[-400:])
+    d = json.loads(lines[-1])
+    return {"config": d["config"]["workload"] + f", {d['config']['chains_per_gpu']} chains / {d['config']['chain_groups']} group(s)"
+                      + (", calibrated low-rate regime (workload.calibrate_lowrate: latent scales at the 0.1 clamp, pixel scale "
+                         "0.0035, blocks drawn from the model's own generative path)" if spec.get("regime") == "lowrate" else "")
+                      + (", opt-in 64-state stream format (not the reference's word stream)" if spec.get("format") == "wave64" else ""),
+            "why": spec.get("why"), "workload": spec["workload"], "chains_per_gpu": d["config"]["chains_per_gpu"],
+            "chain_groups": d["config"]["chain_groups"], "scaling": d["scaling"], "steps": d["steps"], "warmup": d["warmup"],
+            "value": round(d["value"], 1), "ms_per_step": round(d["ms_per_step"], 3), "lossless": d["lossless"],
+            "bits_per_dim": round(d["bits_per_dim"], 4), "stream_format": spec.get("format", "reference"),
+            "regime": spec.get("regime") or "random-init weights, unrelated synthetic blocks",
+            "forked_block_step": d["config"].get("forked_block_step"),
+            "stream_time_fraction": d.get("stream_time_fraction"), "stream_gather": d.get("stream_gather"), "roofline": None,
+            "process": "own process (python bench.py --no-extra ...), like the headline"}
+
+
+# driver-visible numbers for the other shapes DESIGN.md quotes, each measured like the headline in a process of its own
+EXTRAS = (
+    dict(workload="imagenet4", chains=1000, groups=2, why="north_star's target shape (configs[2]) at the headline's batch"),
+    dict(workload="cifar8", chains=100, scaling="strong", why="configs[1] at the reference's own shape: 100 experiments in total"),
+    dict(workload="imagenet4", chains=100, scaling="strong", why="configs[2]: 100 experiments x 32x32 blocks"),
+    dict(workload="imagenet4", chains=100, scaling="strong", bitswap=0, why="configs[4] (BB-ANS) at N = 1"),
+    dict(workload="imagenetcrop4", chains=100, scaling="strong", steps=16,
+         why="configs[3] at N = 1: 100 ragged image chains (a 512 x 512 image = 16 blocks here), crop model on nn_batch 32"),
+    dict(workload="cifar8", chains=13, groups=1, why="one GPU's share of 100 chains on 8 GPUs"),
+    dict(workload="imagenet4", chains=13, groups=1, bitswap=0, why="configs[4]: one GPU's share (13 of 100 chains) on 8 GPUs"),
+    dict(workload="imagenetcrop4", chains=13, scaling="strong", steps=16, why="configs[3]: one GPU's share (13 of 100 images) on 8 GPUs"),
+    dict(workload="cifar8", chains=1000, groups=2, regime="lowrate", why="peaked tables: a trained model's rate"),
+    dict(workload="cifar8", chains=800, groups=2, format="wave64", why="opt-in 64-state format"),
+    dict(workload="cifar8", chains=13, groups=1, format="wave64", why="opt-in 64-state format, few chains"),
+)
+
+
+def config_title(name, args, strong):
+    t = TITLES[name] + f" {'Bit-Swap' if args.bitswap else 'BB-ANS'}, batch of 32x32 blocks"
+    if strong:
+        cfg = {"imagenetcrop4": "BASELINE configs[3]", "cifar8": "BASELINE configs[1]"}.get(
+            name, "BASELINE configs[4]" if (name == "imagenet4" and not args.bitswap) else "BASELINE configs[2]" if name == "imagenet4" else None)
+        t += (f"; {args.total_chains} chains IN TOTAL sharded over the ranks"
+              + (" (ragged: one image = one chain, LPT by block count)" if name == "imagenetcrop4" else " (round-robin)")
+              + (f" -- {cfg}" if cfg else ""))
+    return t
 
 
 def main(args):
@@ -452,8 +625,24 @@ def main(args):
         dist.init_process_group(os.environ.get("BENCH_DIST_BACKEND") or "nccl", timeout=datetime.timedelta(seconds=300))
 
     name = args.workload
-    r = run_workload(args, name, args.chains, args.groups, args.steps, args.warmup, dev, rank, world, dist, want_gather=True,
-                     want_roofline=not args.no_roofline, regime=args.regime)
+    strong = args.scaling == "strong"
+    plan = None
+    if strong:
+        if args.total_chains < world:
+            raise SystemExit(f"--scaling strong: {args.total_chains} chains cannot occupy {world} ranks")
+        plan = strong_plan(args.total_chains, world, name, args.steps)
+        ids, lengths = plan[rank]
+        chains = len(ids)
+    else:
+        chains = args.chains
+    groups = args.groups or (2 if chains >= 64 else 1)
+    if strong and name == "imagenetcrop4":
+        r = run_ragged(args, name, ids, lengths, args.total_chains, args.steps, args.warmup, dev, rank, world, dist)
+        groups = 1
+    else:
+        r = run_workload(args, name, chains, groups, args.steps, args.warmup, dev, rank, world, dist, want_gather=True,
+                         want_roofline=not args.no_roofline and not strong, regime=args.regime,
+                         chain_ids=ids if strong else None, total=args.total_chains if strong else None)
     codec, model = r.pop("codec"), r.pop("model")
     gemm = ("bs_wino_gemm_f32 (own fp32 MFMA kernel, every product: results independent of chains per call)"
             if getattr(model, "own_gemm", False) else f"BLAS backend {model.gemm_backend}")
@@ -462,41 +651,22 @@ def main(args):
                  f"{'Winograd domain (bs_small_k_gemm_f32)' if getattr(model, 'wino_in5', False) else 'MIOpen'})"
                  if getattr(model, "fused", False) else "torch modules")
     Z, X = codec.Z, codec.X
+    forked = bool(sum(c.forked_steps for c in getattr(codec, "codecs", [codec])))
     del codec, model
 
     extra = None
-    if world == 1 and not args.no_extra and name == "cifar8" and args.format == "reference":
-        # driver-visible numbers for the other shapes DESIGN.md quotes: north_star's target config and the reference's
-        # 100-experiment shape, same procedure, fewer steps
+    if world == 1 and not args.no_extra and not strong and name == "cifar8" and args.format == "reference":
         extra = []
-        ks, ws = min(args.steps, 6), min(args.warmup, 1)
-        import copy
+        ks, ws = min(args.steps, 6), max(min(args.warmup, 1), 2)
         import gc
-        for (wn, ch, gr, fmt, reg) in (("imagenet4", 1000, 2, "reference", None), ("cifar8", 100, 2, "reference", None),
-                                       ("cifar8", 1000, 2, "reference", "lowrate"),
-                                       ("cifar8", 800, 2, "wave64", None), ("cifar8", 13, 1, "wave64", None)):
-            gc.collect()                       # the previous workload's model, bins and states go before the next is built
-            torch.cuda.empty_cache()
-            torch.cuda.synchronize()
+        gc.collect()                       # the headline's model, bins and states go before the children are started
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        for spec in EXTRAS:
             try:
-                e = extra_in_child(args, wn, ch, gr, fmt, reg, ks, max(ws, 2))     # a fresh process, like the headline's
-                if e is None:
-                    a2 = copy.copy(args)
-                    a2.format = fmt
-                    e = run_workload(a2, wn, ch, gr, ks, max(ws, 2), dev, rank, world, dist, want_roofline=False, regime=reg)
-                    e.pop("codec"), e.pop("model"), e.pop("stream_gather")
-                    e["process"] = "in the headline's process (a later workload in one process measures up to 8 % low)"
-                e["value"], e["ms_per_step"] = round(e["value"], 1), round(e["ms_per_step"], 3)
-                e["bits_per_dim"] = round(e["bits_per_dim"], 4)
-                e["stream_format"] = fmt
-                e["regime"] = reg or "random-init weights, unrelated synthetic blocks"
-                e["config"] = (f"{TITLES[wn]} {'Bit-Swap' if args.bitswap else 'BB-ANS'}, {ch} chains / {gr} group(s)"
-                               + (", calibrated low-rate regime (workload.calibrate_lowrate: latent scales at the 0.1 clamp, pixel "
-                                  "scale 0.0035, blocks drawn from the model's own generative path)" if reg == "lowrate" else "")
-                               + (", opt-in 64-state stream format (not the reference's word stream)" if fmt == "wave64" else ""))
-                extra.append(e)
+                extra.append(extra_in_child(args, spec, ks, ws))
             except Exception as ex:   # a sub-result never costs the headline
-                extra.append({"workload": wn, "chains_per_gpu": ch, "stream_format": fmt, "regime": reg, "error": repr(ex)})
+                extra.append({"workload": spec["workload"], "chains_per_gpu": spec["chains"], "why": spec.get("why"), "error": repr(ex)})
 
     if rank != 0:
         if dist is not None:
@@ -513,11 +683,12 @@ def main(args):
     out = {
         "metric": "pixels/s (encode+decode)", "value": round(r["value"], 1), "unit": "pixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": TITLES[name] + f" {'Bit-Swap' if args.bitswap else 'BB-ANS'}, batch of 32x32 blocks",
-                   "chains_per_gpu": args.chains, "chain_groups": args.groups, "blocks_per_chain": args.steps,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": config_title(name, args, strong),
+                   "chains_per_gpu": r["chains_per_gpu"], "chain_groups": r["chain_groups"], "blocks_per_chain": args.steps,
                    "quantbits": args.quantbits, "ansbits": 31, "cdf_spec": args.cdf_spec, "stream_format": args.format,
                    "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32", "conv_path": conv_path,
+                   "forked_block_step": forked,
                    "weights": "seeded random init (no checkpoints offline)"
                               + (", calibrated to the low-rate regime (workload.calibrate_lowrate)" if args.regime else "")},
         "rccl_ranks": (world if (world > 1 and (os.environ.get("BENCH_DIST_BACKEND") or "nccl") == "nccl") else 0),
@@ -525,6 +696,12 @@ def main(args):
         "stream_time_fraction": r["stream_time_fraction"],
         "roofline": r["roofline"], "cpu_baseline": cpu, "stream_gather": r["stream_gather"], "extra": extra,
     }
+    if strong:
+        out["config"].update({"total_chains": args.total_chains, "chains_per_rank": [len(p[0]) for p in plan],
+                              "blocks_per_rank": [int(sum(p[1])) for p in plan]})
+        for k in ("blocks_total", "nn_batch"):
+            if k in r:
+                out["config"][k] = r[k]
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -97,6 +97,13 @@ class HipBackend:
         f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits, step=step)
         hip.rans_push(state, f, c, bits)
 
+    # push in two halves, for schedules that evaluate the (f, c) of a layer early and code it later (forked block step)
+    def push_prepare(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
+        return hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits, step=step)
+
+    def push_commit(self, state, token, bits):
+        hip.rans_push(state, token[0], token[1], bits)
+
     def push_table(self, state, cdf, sym, K, bits):
         hip.rans_push_table(state, cdf, sym, K, bits)
 
@@ -160,6 +167,13 @@ class Hip64Backend(HipBackend):
         return hip.layer_pop64(state, t.endpoints, t.mu, t.scale, bits, t.quantbits, centres=centres, step=t.step)
 
     def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
+        hip.layer_push64(state, endpoints, mu, scale, sym, bits, quantbits, step=step)
+
+    def push_prepare(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
+        return (endpoints, mu, scale, sym, quantbits, step)      # table + push are ONE launch here: nothing to do early
+
+    def push_commit(self, state, token, bits):
+        endpoints, mu, scale, sym, quantbits, step = token
         hip.layer_push64(state, endpoints, mu, scale, sym, bits, quantbits, step=step)
 
     def push_table(self, state, t, sym, K, bits):
@@ -302,6 +316,15 @@ class BitSwapCodec:
         self._graph_cap = 4
         self._graph_failures = 0
         self.graph_captures = 0                      # block steps captured so far (tests, diagnostics)
+        # forked block step (round 4): with few chains the step is a latency chain, not a throughput problem, and half of that
+        # chain is not a dependence at all -- generate(i)(z_i) and infer(i+1)(z_i) both need z_i only (sender), likewise
+        # infer(i)(y) and generate(i-1)(y) on the receiver; only pop -> push -> pop on the stack is ordered
+        # (mnist_compress.py:176-205, 293-319).  "auto": fork when the chains are few enough for the step to be
+        # latency-bound (the same bound as graph replay); "1" / "0": always / never.  Scheduling only: same words.
+        self.fork = os.environ.get("BITSWAP_FORK", "auto")
+        self.fork_max_chains = int(os.environ.get("BITSWAP_FORK_MAX_CHAINS", "128"))
+        self._aux = None                              # the second stream of the forked step
+        self.forked_steps = 0                         # block steps enqueued (or captured) in the forked order (tests)
         # optional stream split (GroupedCodec): convs + table kernels on `bulk`, the serial rANS kernels
         # on `serial`; None = everything on the caller's current stream
         self.bulk = self.serial = None
@@ -436,15 +459,156 @@ class BitSwapCodec:
     def encode_block(self, state, x, rest_len=None):
         """Sender, one block per chain.  x [B, X] integer pixels.  If `rest_len` is a tensor it
         receives the word count right after the first bits-back pop(s) (restbits, :191-193,225-227)."""
+        if self._fork_ok(state):
+            return self._encode_forked(state, x, rest_len)
         for _ in self.encode_steps(state, x, rest_len):
             pass
 
     def decode_block(self, state):
         """Receiver, one block per chain (exact mirror).  Returns x [B, X] int32."""
+        if self._fork_ok(state):
+            return self._decode_forked(state)
         out = None
         for out in self.decode_steps(state):
             pass
         return out
+
+    # ---- the forked block step ------------------------------------------------------------------------
+    def _fork_ok(self, state):
+        if self.fork == "0" or self.serial is not None or self.bulk is not None or not isinstance(self.backend, HipBackend):
+            return False
+        return self.fork == "1" or state.B <= self.fork_max_chains
+
+    def _aux_stream(self):
+        if self._aux is None:
+            self._aux = torch.cuda.Stream(device=self.device)
+        return self._aux
+
+    def _encode_forked(self, state, x, rest_len=None):
+        """encode_block with the dependence structure of the schedule spelled out on two streams.  S (the caller's stream)
+        carries what the NEXT pop waits for -- infer(i), its table, the pop; A carries what only the push needs --
+        generate(i), its (f, c), the push.  The stack is touched in the reference's order, pop_i -> push_i -> pop_(i+1), by
+        stream waits; the critical path of a latent layer is pop + max(infer + table, generate + fc + push) instead of
+        their sum.  BB-ANS (:206-243): every generate(i) hangs off its pop and runs under the remaining inference chain; the
+        pushes follow the last pop.  Tensors that cross from S to A (z, symbols, x) are only released after S has waited
+        for A again, so the caching allocator cannot hand their memory to a later S kernel early; nothing crosses from A to
+        S.  Inside a hipGraph capture A joins the capture at its first wait and is joined back before the step ends."""
+        m, nz, be = self.model, self.nz, self.backend
+        S, A = torch.cuda.current_stream(self.device), self._aux_stream()
+        self.forked_steps += 1
+        x = x.to(self.device, torch.int32).contiguous()
+        given = be.centres(self.xcen, x)
+        if self.bitswap:
+            zsym = None
+            for zi in range(nz):
+                mu, sc = self._net(m.infer(zi), given)
+                with self.tl.span("tables_z"):
+                    cdf = be.tables(self.zend[zi], mu, sc, self.q, self.bits, out=self._cdf(mu.shape[0], mu.shape[1], self.K, self.zstep[zi] is not None),
+                                    step=self.zstep[zi], status=state.status)
+                if zi:
+                    S.wait_stream(A)                                  # push_(zi-1) has left the stack
+                with self.tl.span("pop_z"):
+                    zsymtop, z = be.pop(state, cdf, self.K, self.bits, centres=self.zcen[zi])
+                self._track_min(state)
+                if rest_len is not None and zi == 0:
+                    self._snap(rest_len, state)
+                A.wait_stream(S)
+                with torch.cuda.stream(A):
+                    mu, sc = self._net(m.generate(zi), z)
+                    if zi == 0:
+                        self._push_layer(state, self.xend, mu, sc, x, 8, "x", self.xstep)
+                    else:
+                        self._push_layer(state, self.zend[zi - 1], mu, sc, zsym, self.q, "z", self.zstep[zi - 1])
+                zsym, given = zsymtop, z
+        else:
+            syms, zs, pending = [], [], []
+            for zi in range(nz):
+                mu, sc = self._net(m.infer(zi), given)
+                with self.tl.span("tables_z"):
+                    cdf = be.tables(self.zend[zi], mu, sc, self.q, self.bits, out=self._cdf(mu.shape[0], mu.shape[1], self.K, self.zstep[zi] is not None),
+                                    step=self.zstep[zi], status=state.status)
+                with self.tl.span("pop_z"):
+                    s, z = be.pop(state, cdf, self.K, self.bits, centres=self.zcen[zi])
+                self._track_min(state)
+                syms.append(s)
+                zs.append(z)
+                given = z
+                if zi == nz - 1 and rest_len is not None:
+                    self._snap(rest_len, state)
+                A.wait_stream(S)
+                with torch.cuda.stream(A):                            # generate(zi) under the rest of the inference chain
+                    mu, sc = self._net(m.generate(zi), z)
+                    with self.tl.span("fc_x" if zi == 0 else "fc_z"):
+                        if zi == 0:
+                            pending.append(be.push_prepare(state, self.xend, mu, sc, x, 8, self.bits, step=self.xstep))
+                        else:
+                            pending.append(be.push_prepare(state, self.zend[zi - 1], mu, sc, syms[zi - 1], self.q, self.bits,
+                                                           step=self.zstep[zi - 1]))
+            with torch.cuda.stream(A):                                # A has waited for the last pop
+                for zi, tok in enumerate(pending):
+                    with self.tl.span("push_x" if zi == 0 else "push_z"):
+                        be.push_commit(state, tok, self.bits)
+            zsymtop = syms[-1]
+        S.wait_stream(A)
+        with self.tl.span("push_prior"):
+            be.push_table(state, self.prior_cdf, zsymtop, self.K, self.bits)
+
+    def _decode_forked(self, state):
+        """decode_block in the forked order (mirror of _encode_forked, :293-354): S carries generate(i), its table and the
+        pop; A carries infer(i), its (f, c) and the push."""
+        m, nz, be = self.model, self.nz, self.backend
+        S, A = torch.cuda.current_stream(self.device), self._aux_stream()
+        self.forked_steps += 1
+        with self.tl.span("pop_prior"):
+            zsymtop, z = be.pop(state, self.prior_cdf, self.K, self.bits, centres=self.zcen[-1])
+        self._track_min(state)
+
+        def pop_under(zi, mu, sc):
+            if zi == 0:
+                ends, cens, q, K, key, step = self.xend, self.xcen, 8, 256, "x", self.xstep
+            else:
+                ends, cens, q, K, key, step = self.zend[zi - 1], self.zcen[zi - 1], self.q, self.K, "z", self.zstep[zi - 1]
+            with self.tl.span("tables_" + key):
+                cdf = be.tables(ends, mu, sc, q, self.bits, out=self._cdf(mu.shape[0], mu.shape[1], K, step is not None),
+                                step=step, status=state.status)
+            return cdf, K, cens, key
+
+        if self.bitswap:
+            for k, zi in enumerate(reversed(range(nz))):
+                mu, sc = self._net(m.generate(zi), z)
+                cdf, K, cens, key = pop_under(zi, mu, sc)
+                if k:
+                    S.wait_stream(A)                                  # the previous layer's push has left the stack
+                with self.tl.span("pop_" + key):
+                    sym, given = be.pop(state, cdf, K, self.bits, centres=cens)
+                self._track_min(state)
+                A.wait_stream(S)
+                with torch.cuda.stream(A):
+                    mu, sc = self._net(m.infer(zi), given)
+                    self._push_layer(state, self.zend[zi], mu, sc, zsymtop, self.q, "z", self.zstep[zi])
+                zsymtop, z = sym, given
+            S.wait_stream(A)
+            return zsymtop
+        syms, cens_l, pending = [zsymtop], [z], []
+        for k, zi in enumerate(reversed(range(nz))):
+            mu, sc = self._net(m.generate(zi), cens_l[-1])
+            cdf, K, cens, key = pop_under(zi, mu, sc)
+            with self.tl.span("pop_" + key):
+                s, c = be.pop(state, cdf, K, self.bits, centres=cens)
+            self._track_min(state)
+            syms.append(s)
+            cens_l.append(c)
+            A.wait_stream(S)
+            with torch.cuda.stream(A):                                # infer(zi) under the rest of the generative chain
+                mu, sc = self._net(m.infer(zi), c)
+                with self.tl.span("fc_z"):
+                    pending.append(be.push_prepare(state, self.zend[zi], mu, sc, syms[k], self.q, self.bits, step=self.zstep[zi]))
+        with torch.cuda.stream(A):                                    # A has waited for the last pop
+            for tok in pending:
+                with self.tl.span("push_z"):
+                    be.push_commit(state, tok, self.bits)
+        S.wait_stream(A)
+        return syms[-1]
 
     def _graph_ok(self, state):
         if not self.use_graphs or self.serial is not None or self.bulk is not None or not isinstance(self.backend, HipBackend):
@@ -638,21 +802,27 @@ class BitSwapCodec:
         return state, dict(nets=nets, cma=cma, total=total.astype(np.float64), rest_len=rest_len, init_len=init_len)
 
     # ---- chains of different lengths (one image = one chain, imagenetcrop_compress.py:279-300) ---------
-    def compress_ragged(self, chains, state=None, nwords=10000, seed=100, same_init=True):
-        """chains: list of integer tensors [n_i, X].  All chains run in lock-step; with the chains sorted
-        by decreasing length the active set at block xi is a PREFIX of the batch, so the kernels simply see
-        fewer chains as the short ones finish (no masking, no padding work).  Returns (state, order,
-        metrics) where state/metrics rows follow `order` (indices into `chains`, longest first).
-        same_init: every chain starts from the same initial words, like the crop script (:249,122)."""
+    def stage_ragged(self, chains):
+        """chains: list of integer tensors [n_i, X] -> (x [B, nmax, X] int32 on the device, rows sorted by decreasing length
+        and zero-padded; order; ns): what compress_ragged codes.  Callers that time the coding stage first."""
         n = [int(c.shape[0]) for c in chains]
         assert min(n) >= 1
         order = sorted(range(len(chains)), key=lambda i: (-n[i], i))
         ns = [n[i] for i in order]
-        B, nmax = len(chains), ns[0]
-        x = torch.zeros((B, nmax, self.X), dtype=torch.int32)
+        x = torch.zeros((len(chains), ns[0], self.X), dtype=torch.int32, device=self.device)
         for k, i in enumerate(order):
-            x[k, : ns[k]] = torch.as_tensor(chains[i]).to(torch.int32)
-        x = x.to(self.device)
+            x[k, : ns[k]] = torch.as_tensor(chains[i]).to(self.device, torch.int32)
+        return x, order, ns
+
+    def compress_ragged(self, chains, state=None, nwords=10000, seed=100, same_init=True, staged=None):
+        """chains: list of integer tensors [n_i, X].  All chains run in lock-step; with the chains sorted
+        by decreasing length the active set at block xi is a PREFIX of the batch, so the kernels simply see
+        fewer chains as the short ones finish (no masking, no padding work).  Returns (state, order,
+        metrics) where state/metrics rows follow `order` (indices into `chains`, longest first).
+        same_init: every chain starts from the same initial words, like the crop script (:249,122).
+        staged: the result of stage_ragged(chains), if the caller made it ahead of time."""
+        x, order, ns = staged if staged is not None else self.stage_ragged(chains)
+        B, nmax = len(ns), ns[0]
         if state is None:
             one = initial_states(1, nwords, seed)[0]
             states = [list(one) for _ in range(B)] if same_init else initial_states(B, nwords, seed)

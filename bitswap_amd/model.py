@@ -680,6 +680,7 @@ class Model(nn.Module):
             if i == 0:
                 h = (h - 127.5) / 127.5
             return self._infer_stack(i, h)
+        distribution.bs_key = ("infer", i)        # which stack this closure is (schedulers and tests tell them apart by it)
         return distribution
 
     def generate(self, i):
@@ -696,6 +697,7 @@ class Model(nn.Module):
                     return mu.view(-1).to(in_dtype), scale.view(-1).to(in_dtype)
                 return mu, scale
             return self._gen_stack(i, h)
+        distribution.bs_key = ("generate", i)
         return distribution
 
     # ELBO terms for the `elbos` metric of the CLIs (mnist_train.py:441-490) ------------------

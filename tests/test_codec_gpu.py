@@ -13,13 +13,32 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+class _NetRecord:
+    """Conv outputs of a GPU run, per stack ("infer"/"generate", layer) in the order the blocks were coded -- the forked
+    block step (codec._encode_forked) calls the stacks in another order than the reference's loop, per stack the order
+    is the same."""
+
+    def __init__(self):
+        self.by_key, self.n = {}, 0
+
+    def add(self, fn, out):
+        self.by_key.setdefault(fn.bs_key, []).append(out)
+        self.n += 1
+
+    def replay(self, fn, given):
+        return tuple(t.cpu() for t in self.by_key[fn.bs_key].pop(0))
+
+    def __len__(self):
+        return self.n
+
+
 def record_nets(codec):
     codec.use_graphs = False        # every conv output is wanted, block by block: no graph replay
-    rec, orig = [], codec._net
+    rec, orig = _NetRecord(), codec._net
 
     def wrapped(fn, given):
         out = orig(fn, given)
-        rec.append(out)
+        rec.add(fn, out)
         return out
     codec._net = wrapped
     return rec, orig
@@ -40,10 +59,9 @@ def test_round_trip_and_oracle_word_parity(name, q, bitswap):
     sent = state.to_lists()
     assert np.all(met["total"][:, -1] > 0)
 
-    it = iter(rec)
     oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=q, bitswap=bool(bitswap),
                       backend=OracleBackend(O.MODE_DET, threads=4))
-    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    oc._net = rec.replay
     ostate, omet = oc.compress(images)
     assert ostate.to_lists() == sent
     assert np.array_equal(omet["cma"], met["cma"]) and np.array_equal(omet["rest_len"], met["rest_len"])
@@ -215,6 +233,7 @@ def test_grouped_codec_equals_plain_codec(bitswap, fmt, graphs, monkeypatch):
     # the same two groups through the plain codec, one after the other on the default stream
     plain = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap), backend=mk())
     plain.use_graphs = False
+    plain.fork = "0"                              # the reference's order of operations on ONE stream
     want = []
     for sl in gc.split(B):
         st = plain.new_states(sl.stop - sl.start, n, states=init[sl])
@@ -229,6 +248,8 @@ def test_grouped_codec_equals_plain_codec(bitswap, fmt, graphs, monkeypatch):
     assert gc.to_lists(states) == ([split_state(s) for s in init] if fmt == "wave64" else init)
     if fmt == "reference":
         assert (sum(c.graph_captures for c in gc.codecs) > 0) == (graphs == "1")
+    if graphs == "1":        # few chains per group: every group's step runs (and is captured) in the forked order
+        assert all(c.forked_steps > 0 for c in gc.codecs) and plain.forked_steps == 0
 
 
 def test_config3_shape_many_blocks_lossless():
@@ -324,9 +345,11 @@ class _Count:
 
 
 @pytest.mark.parametrize("name,bitswap,n,regime", [("cifar8", 1, 1, None), ("imagenet4", 1, 2, None), ("imagenet4", 0, 1, None),
-                                                   ("cifar8", 1, 2, "lowrate")])
+                                                   ("cifar8", 1, 2, "lowrate"), ("mnist2", 1, 2, None), ("cifar8", 0, 1, None)])
 def test_full_width_oracle_word_parity(name, bitswap, n, regime):
-    """BASELINE configs 2, 3 and 5 at FULL model width (reswidth 252 / 254, Z = 2048, X = 3072, K = 1024 / 256) on the
+    """BASELINE configs 1 (MNIST nz = 2 at its real width: reswidth 63 padded to 64, Z = 256, X = 1024,
+    mnist_compress.py:85-86,107), 2, 3 and 5, and the 8-layer BB-ANS schedule (cifar_compress.py --bitswap 0: the deepest
+    dip into the initial stack, :206-243), at FULL model width (reswidth 252 / 254, Z = 2048, X = 3072, K = 1024 / 256) on the
     route the bench takes: 32 chains per call, every convolution of the stacks in the Winograd domain on OUR fp32 MFMA
     GEMM (asserted: bs_wino_gemm_f32 is called, the BLAS library is not), and the production kernel pair (k_logistic wave
     layout, CDF spec 2 + k_rans_pop_wave + systolic push).  The oracle replays the schedule on the CPU with the GPU's conv
@@ -350,11 +373,13 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime):
     codec.backend.pivot_min_bytes = 0
     assert codec.backend.table_layout(codec.K, True, codec.Z, B) == hip.LAYOUT_PIVOT
     assert codec.backend.table_layout(codec.K, False, codec.Z, B) == hip.LAYOUT_WAVE
-    assert HipBackend(DEV).table_layout(codec.K, True, codec.Z, 400) == hip.LAYOUT_PIVOT       # ... as the default picks it
+    if codec.Z == 2048:
+        assert HipBackend(DEV).table_layout(codec.K, True, codec.Z, 400) == hip.LAYOUT_PIVOT   # ... as the default picks it
     assert HipBackend(DEV).table_layout(codec.K, True, codec.Z, B) == hip.LAYOUT_WAVE
     rec, plain_net = record_nets(codec)
     with _Count("wino_fused") as wf, _Count("wino_gemm") as wg, _NoBlas() as nb:
         state, met = codec.compress(images.to(DEV))
+    assert codec.forked_steps == n, "32 chains per call: the block step runs in the forked (two-stream) order"
     assert wf.n > 0 and wg.n > 0, "the Winograd-domain conv route / the own GEMM was not taken"
     assert nb.n == 0, f"{nb.n} library GEMM / conv call(s) inside the compress path: the route would depend on the batch"
     sent = state.to_lists()
@@ -362,10 +387,9 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime):
         assert 2.0 < met["nets"].mean() < 8.0, met["nets"].mean()     # a trained model's rate, not 26 bits/dim
         print(f"lowrate {name}: net {met['nets'].mean():.3f} bits/dim")
 
-    it = iter(rec)
     oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=bool(bitswap),
                       backend=OracleBackend(O.MODE_DET, threads=16))
-    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    oc._net = rec.replay
     ostate, omet = oc.compress(images)
     assert ostate.to_lists() == sent
     assert np.array_equal(omet["cma"], met["cma"]) and np.array_equal(omet["rest_len"], met["rest_len"])
@@ -374,6 +398,38 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime):
     out = codec.decompress(state, n)
     assert torch.equal(out.cpu(), images)
     assert state.to_lists() == initial_states(B)
+
+
+def test_bench_launch_size_oracle_word_parity_on_sampled_chains():
+    """One block step at the bench's own launch size -- 500 chains in one call, the size of a chain group of the 1000-chain
+    headline: 1,024,000 rows per table launch, BS_LAYOUT_PIVOT picked by the DEFAULT size rule (not forced), the grids,
+    LDS and occupancy of the timed run, 8000-column GEMMs -- checked against the oracle.  The oracle is per chain, so it
+    replays 16 sampled chains (cost 16/500 of a full replay) with the GPU's conv outputs for those rows: same words;
+    then the GPU receiver returns all 500 blocks and unwinds all 500 chains (VERDICT r3 missing #4)."""
+    from bitswap_amd import hip
+    model, zend, zcen = workload.build("cifar8", DEV, quantbits=10)
+    B, n = 500, 1
+    images = workload.synthetic_blocks(B * n, model.xs, seed=41).view(B, n, -1).to(torch.int32)
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
+    assert codec.backend.table_layout(codec.K, True, codec.Z, B) == hip.LAYOUT_PIVOT        # the default rule at this size
+    rec, plain_net = record_nets(codec)
+    with _Count("rans_pop_pivot") as pp, _NoBlas() as nb:
+        state, met = codec.compress(images.to(DEV))
+    assert pp.n >= codec.nz - 1 and nb.n == 0 and codec.forked_steps == 0       # big batch: one stream, pivot hand-off
+    sent = state.to_lists()
+    idx = [0, 1, 63, 64, 127, 128, 200, 249, 250, 255, 256, 311, 400, 457, 498, 499]
+    sub = torch.tensor(idx)
+    init = initial_states(B)
+    oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=True, backend=OracleBackend(O.MODE_DET, threads=16))
+    oc._net = lambda fn, given: tuple(t.cpu()[sub].contiguous() for t in rec.by_key[fn.bs_key].pop(0))
+    ostate, omet = oc.compress(images[sub], state=oc.new_states(len(idx), n, states=[init[i] for i in idx]))
+    got = ostate.to_lists()
+    for k, i in enumerate(idx):
+        assert got[k] == sent[i], f"chain {i}: HIP words differ from the oracle's"
+    assert np.array_equal(omet["cma"], met["cma"][idx])
+    codec._net = plain_net
+    out = codec.decompress(state, n)
+    assert torch.equal(out.cpu(), images) and state.to_lists() == init
 
 
 class _NoBlas:
@@ -414,9 +470,8 @@ def test_full_width_crop_model_oracle_word_parity():
     assert wg.n > 0 and nb.n == 0
     sent = state.to_lists()
 
-    it = iter(rec)
     oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=True, backend=OracleBackend(O.MODE_DET, threads=16))
-    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    oc._net = rec.replay
     ostate, oorder, omet = oc.compress_ragged(chains)
     assert oorder == order and ostate.to_lists() == sent
     assert np.array_equal(omet["total"], met["total"]) and np.array_equal(omet["rest_len"], met["rest_len"])
@@ -655,10 +710,9 @@ def test_wave64_hip_words_equal_oracle(name, q, bitswap):
     rec, plain_net = record_nets(codec)
     state, met = codec.compress(images.to(DEV))
     sent = state.to_lists()
-    it = iter(rec)
     oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=q, bitswap=bool(bitswap),
                       backend=Oracle64Backend(O.MODE_DET, threads=4))
-    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    oc._net = rec.replay
     ostate, omet = oc.compress(images)
     assert ostate.to_lists() == sent
     assert np.array_equal(omet["cma"], met["cma"]) and np.array_equal(omet["rest_len"], met["rest_len"])
@@ -681,9 +735,8 @@ def test_wave64_full_width_and_container_on_gpu():
     rec, plain_net = record_nets(codec)
     state, met = codec.compress(images.to(DEV))
     sent = state.to_lists()
-    it = iter(rec)
     oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=True, backend=Oracle64Backend(O.MODE_DET, threads=16))
-    oc._net = lambda fn, given: tuple(t.cpu() for t in next(it))
+    oc._net = rec.replay
     ostate, _ = oc.compress(images)
     assert ostate.to_lists() == sent
     codec._net = plain_net
@@ -714,11 +767,13 @@ def test_block_step_graph_equals_eager(fmt, bitswap):
     mk = (lambda: Hip64Backend(DEV)) if fmt == "wave64" else (lambda: HipBackend(DEV))
     eager = BitSwapCodec(model, zend, zcen, quantbits=8, bitswap=bool(bitswap), backend=mk())
     eager.use_graphs = False
+    eager.fork = "0"                              # one stream, the reference's order of operations
     graphed = BitSwapCodec(model, zend, zcen, quantbits=8, bitswap=bool(bitswap), backend=mk())
     graphed.use_graphs = True
     s1, m1 = eager.compress(images)
     s2, m2 = graphed.compress(images)
     assert graphed.graph_captures == 1, "the block step was not captured"
+    assert graphed.forked_steps >= 2 and eager.forked_steps == 0, "the captured step is the forked (two-stream) one"
     assert not graphed._graphs, "a finished run must not leave graphs (and the state they pin) behind"
     assert s1.to_lists() == s2.to_lists() and np.array_equal(m1["cma"], m2["cma"])
     out = graphed.decompress(s2, n)
@@ -731,6 +786,42 @@ def test_block_step_graph_equals_eager(fmt, bitswap):
     assert s2.to_lists() == init
     out1 = eager.decompress(s1, n)
     assert torch.equal(out1, images)
+
+
+@pytest.mark.parametrize("fmt", ["reference", "wave64"])
+@pytest.mark.parametrize("bitswap", [1, 0])
+def test_forked_block_step_equals_reference_order(fmt, bitswap):
+    """The forked block step (generate(i) + its (f, c) + push on a second stream beside infer(i+1) + its
+    table, stack order pop -> push -> pop kept by stream waits; BB-ANS: every generate under the inference chain) is a
+    scheduling device only: eager launches in the forked order give the words, restbits and metrics of the reference's
+    order on one stream (mnist_compress.py:176-251), with the per-span timing events on; the forked receiver undoes the
+    unforked sender and the other way round."""
+    from bitswap_amd.codec import Hip64Backend, HipBackend, Timeline
+    model, zend, zcen = workload.build("cifar8", DEV, quantbits=8, small=16)
+    B, n = 7, 3
+    images = workload.synthetic_blocks(B * n, model.xs, seed=78).view(B, n, -1).to(torch.int32).to(DEV)
+    mk = (lambda: Hip64Backend(DEV)) if fmt == "wave64" else (lambda: HipBackend(DEV))
+    res = {}
+    for fork in ("0", "1"):
+        c = BitSwapCodec(model, zend, zcen, quantbits=8, bitswap=bool(bitswap), backend=mk(), timeline=Timeline(True))
+        c.use_graphs, c.fork = False, fork
+        st, met = c.compress(images)
+        torch.cuda.synchronize()
+        assert (c.forked_steps > 0) == (fork == "1")
+        res[fork] = (c, st, met)
+    (c0, s0, m0), (c1, s1, m1) = res["0"], res["1"]
+    assert s0.to_lists() == s1.to_lists()
+    for k in ("nets", "cma", "total", "rest_len"):
+        assert np.array_equal(m0[k], m1[k]), k
+    assert {"net", "tables_z", "pop_z", "push_prior"} <= set(c1.tl.totals()) and {"net", "pop_z"} <= set(c0.tl.totals())
+    out1 = c1.decompress(s0, n)                              # forked receiver on the unforked sender's state
+    out0 = c0.decompress(s1, n)
+    assert torch.equal(out1, images) and torch.equal(out0, images)
+    init = initial_states(B)
+    if fmt == "wave64":
+        from bitswap_amd.hip import split_state
+        init = [split_state(s) for s in init]
+    assert s0.to_lists() == init and s1.to_lists() == init
 
 
 def test_ragged_chains_with_graph_replay():

@@ -107,6 +107,74 @@ def test_shard_chains_policies():
     assert dist.shard_chains(3, 1, 0) == [0, 1, 2]
 
 
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_strong_scaling_plan_partitions_and_balances():
+    """bench.py --scaling strong (BASELINE configs 4 / 5: 100 chains IN TOTAL over the ranks): at every world size the
+    plan is a partition of the chains; equal chains go round-robin (12-13 per rank at 8 ranks), the ragged crop chains
+    longest-processing-time-first with the ranks' block counts within one longest chain of each other; a chain's length
+    does not depend on the world size."""
+    bench = _bench()
+    for name in ("imagenet4", "imagenetcrop4"):
+        ref = None
+        for world in (1, 2, 3, 4, 8):
+            plan = bench.strong_plan(100, world, name, 16)
+            ids = sorted(c for p in plan for c in p[0])
+            assert ids == list(range(100)) and len(plan) == world
+            lens = dict((c, n) for p in plan for c, n in zip(*p))
+            ref = ref or lens
+            assert lens == ref
+            loads = [sum(p[1]) for p in plan]
+            if name == "imagenetcrop4":
+                assert 4 <= min(lens.values()) and max(lens.values()) <= 16 and len(set(lens.values())) > 3
+                assert max(loads) - min(loads) <= 16
+            else:
+                assert set(lens.values()) == {16} and max(len(p[0]) for p in plan) - min(len(p[0]) for p in plan) <= 1
+    assert [len(p[0]) for p in bench.strong_plan(100, 8, "imagenet4", 6)] == [13, 13, 13, 13, 12, 12, 12, 12]
+
+
+def _worker_strong(rank, world, port, outdir):
+    """bench.py's strong-scaling exchange at world size 2 over gloo: every rank makes the streams of ITS chains of the plan
+    (here: a function of the global chain id), rank 0 gathers all of them and the digest is the one a single process gets."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as td
+    from bitswap_amd import dist
+    bench = _bench()
+    assert dist.init("gloo") == (rank, world)
+    for name in ("imagenet4", "imagenetcrop4"):
+        ids, lengths = bench.strong_plan(11, world, name, 8)[rank]
+        streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
+        g = bench.gather_and_digest(streams, ids, 11, rank)
+        if rank == 0:
+            assert g["complete"] and g["own_streams_intact"] and g["chains"] == 11
+            with open(os.path.join(outdir, f"digest_{name}_w{world}.txt"), "w") as f:
+                f.write(g["crc32_of_streams_in_chain_order"])
+        else:
+            assert g is None
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_strong_scaling_gather_digest_is_independent_of_world_size(tmp_path):
+    mp.spawn(_worker_strong, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    bench = _bench()
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    for name in ("imagenet4", "imagenetcrop4"):
+        ids, lengths = bench.strong_plan(11, 1, name, 8)[0]
+        streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
+        one = bench.gather_and_digest(streams, ids, 11, 0)
+        assert one["crc32_of_streams_in_chain_order"] == open(tmp_path / f"digest_{name}_w2.txt").read()
+
+
 def test_two_rank_gather_and_sharded_experiment(tmp_path):
     port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

@@ -52,3 +52,43 @@ def test_rccl_branch_with_one_rank(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", WORKER % ROOT, str(port)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def _bench(args, env=None, timeout=900):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--no-extra", "--no-cpu-baseline", "--no-roofline"],
+                       capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {})))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout + r.stderr)[-3000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_strong_scaling_mode_one_and_two_ranks():
+    """bench.py --scaling strong (BASELINE configs 4 / 5: the chains are a fixed total, sharded by dist.shard_chains): at
+    N = 1 and with two ranks on this one device (gloo: control flow of the sharded run, the gather and the max-over-ranks
+    timing; RCCL refuses two ranks per GPU) the line says `strong`, is lossless, and -- every convolution runs on
+    batch-invariant kernels of our own -- the gathered streams are THE SAME whichever rank coded them (one digest)."""
+    base = ["--scaling", "strong", "--total-chains", "6", "--workload", "mnist2", "--steps", "2", "--warmup", "1"]
+    one = _bench(base)
+    assert one["scaling"] == "strong" and one["lossless"] and one["n_gpus"] == 1
+    assert one["config"]["chains_per_rank"] == [6] and one["config"]["total_chains"] == 6
+    assert one["stream_gather"]["complete"] and one["value"] > 0
+    two = _bench(base + ["--gpus", "2"], env={"BENCH_DIST_BACKEND": "gloo"})
+    assert two["scaling"] == "strong" and two["lossless"] and two["n_gpus"] == 2 and two["config"]["chains_per_rank"] == [3, 3]
+    assert two["stream_gather"]["complete"] and two["stream_gather"]["chains"] == 6
+    assert two["stream_gather"]["crc32_of_streams_in_chain_order"] == one["stream_gather"]["crc32_of_streams_in_chain_order"]
+    # the weak default is untouched by the new mode
+    weak = _bench(["--chains", "4", "--workload", "mnist2", "--steps", "2", "--warmup", "1"])
+    assert weak["scaling"] == "weak" and weak["lossless"] and weak["config"]["chains_per_gpu"] == 4
+
+
+def test_bench_strong_scaling_ragged_crop_chains():
+    """Config 4's shape through bench.py: ragged image chains (LPT-sharded), the crop model on its fixed conv micro-batch;
+    lossless, every chain unwound, blocks counted over all ranks; two ranks give the digest of one."""
+    base = ["--scaling", "strong", "--total-chains", "5", "--workload", "imagenetcrop4", "--steps", "4", "--warmup", "1"]
+    one = _bench(base)
+    assert one["scaling"] == "strong" and one["lossless"] and "configs[3]" in one["config"]["workload"]
+    assert one["config"]["blocks_total"] == sum(one["config"]["blocks_per_rank"]) > 5
+    two = _bench(base + ["--gpus", "2"], env={"BENCH_DIST_BACKEND": "gloo"})
+    assert two["lossless"] and two["config"]["blocks_total"] == one["config"]["blocks_total"]
+    assert two["stream_gather"]["crc32_of_streams_in_chain_order"] == one["stream_gather"]["crc32_of_streams_in_chain_order"]
