@@ -490,14 +490,17 @@ class BitSwapCodec:
         generate(i), its (f, c), the push.  The stack is touched in the reference's order, pop_i -> push_i -> pop_(i+1), by
         stream waits; the critical path of a latent layer is pop + max(infer + table, generate + fc + push) instead of
         their sum.  BB-ANS (:206-243): every generate(i) hangs off its pop and runs under the remaining inference chain; the
-        pushes follow the last pop.  Tensors that cross from S to A (z, symbols, x) are only released after S has waited
-        for A again, so the caching allocator cannot hand their memory to a later S kernel early; nothing crosses from A to
-        S.  Inside a hipGraph capture A joins the capture at its first wait and is joined back before the step ends."""
+        pushes follow the last pop.  Tensors that cross from S to A (z, symbols, x) stay referenced (`keep`) until S has
+        waited for A at the end of the step: released earlier, the caching allocator would hand their memory to the next S
+        kernel -- infer(i+2) starts right behind pop(i+1), while push(i+1) on A has yet to read the symbols of pop(i);
+        nothing crosses from A to S.  Inside a hipGraph capture A joins the capture at its first wait and is joined back
+        before the step ends."""
         m, nz, be = self.model, self.nz, self.backend
         S, A = torch.cuda.current_stream(self.device), self._aux_stream()
         self.forked_steps += 1
         x = x.to(self.device, torch.int32).contiguous()
         given = be.centres(self.xcen, x)
+        keep = [x]
         if self.bitswap:
             zsym = None
             for zi in range(nz):
@@ -509,6 +512,7 @@ class BitSwapCodec:
                     S.wait_stream(A)                                  # push_(zi-1) has left the stack
                 with self.tl.span("pop_z"):
                     zsymtop, z = be.pop(state, cdf, self.K, self.bits, centres=self.zcen[zi])
+                keep += [zsymtop, z]
                 self._track_min(state)
                 if rest_len is not None and zi == 0:
                     self._snap(rest_len, state)
@@ -552,6 +556,7 @@ class BitSwapCodec:
         S.wait_stream(A)
         with self.tl.span("push_prior"):
             be.push_table(state, self.prior_cdf, zsymtop, self.K, self.bits)
+        del keep                                                      # S is behind everything A read
 
     def _decode_forked(self, state):
         """decode_block in the forked order (mirror of _encode_forked, :293-354): S carries generate(i), its table and the
@@ -562,6 +567,7 @@ class BitSwapCodec:
         with self.tl.span("pop_prior"):
             zsymtop, z = be.pop(state, self.prior_cdf, self.K, self.bits, centres=self.zcen[-1])
         self._track_min(state)
+        keep = [zsymtop, z]                                           # see _encode_forked: alive until S has waited for A
 
         def pop_under(zi, mu, sc):
             if zi == 0:
@@ -581,6 +587,7 @@ class BitSwapCodec:
                     S.wait_stream(A)                                  # the previous layer's push has left the stack
                 with self.tl.span("pop_" + key):
                     sym, given = be.pop(state, cdf, K, self.bits, centres=cens)
+                keep += [sym, given]
                 self._track_min(state)
                 A.wait_stream(S)
                 with torch.cuda.stream(A):
@@ -588,6 +595,7 @@ class BitSwapCodec:
                     self._push_layer(state, self.zend[zi], mu, sc, zsymtop, self.q, "z", self.zstep[zi])
                 zsymtop, z = sym, given
             S.wait_stream(A)
+            del keep
             return zsymtop
         syms, cens_l, pending = [zsymtop], [z], []
         for k, zi in enumerate(reversed(range(nz))):
