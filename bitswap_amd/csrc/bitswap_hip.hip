@@ -734,7 +734,6 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
         __builtin_amdgcn_sched_barrier(0);           // issue order == consumption order (counted vmcnt)
     }
 
-    int d = D - 1;
     for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
         // this chunk's words: realign the 128-word window by what the previous chunk consumed
         const int idx = (wtop - n) + lane;  // 0..127
@@ -745,7 +744,11 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
         const int ntop = n;
         const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
         int o = 0;  // words consumed in this chunk
-        uint32_t mysym = 0;
+        // the chunk's symbols: lane i of (symr, symp) = (register, position) of symbol 64 c64 + i.  Both are scalars the
+        // search has in hand, the lane is a compile-time constant of the unrolled chunk: two v_writelane per symbol (round 3
+        // spent eight instructions per symbol on `(lane == d % 64) ? 64 r + p : mysym`)
+        uint32_t symr = 0, symp = 0;
+#pragma unroll
         for (int g = 64 / PF - 1; g >= 0; --g) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -757,7 +760,8 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
                 const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)x, pos & 63);
                 const uint32_t cnx = (uint32_t)__builtin_amdgcn_readlane((int)buf[u].pivot, r1);
                 const uint32_t f = (pos == 64 ? cnx : cin) - cs;
-                mysym = (lane == (d & 63)) ? (uint32_t)((r1 - 1) * 64 + pos - 1) : mysym;
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(symr) : "s"(r1 - 1), "n"(g * PF + (PF - 1 - u)));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(symp) : "s"(pos - 1), "n"(g * PF + (PF - 1 - u)));
                 // this row's registers are free again: fetch the row PF steps ahead
                 buf[u].load(rs, voff_row, voff_piv, soff);
                 soff = (uint32_t)max((int)(soff - ld4), 0);
@@ -770,10 +774,9 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
                     h = (h << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, o);
                     ++o;
                 }
-                --d;
             }
         }
-        sh_sym[c64 * 64 + lane] = (int32_t)mysym;
+        sh_sym[c64 * 64 + lane] = (int32_t)(symr * 64u + symp);
         n -= o;
         if (n < 0) {  // popped below the bottom: garbage from here on (reads stay in bounds), reported below
             st = BS_ST_UNDERFLOW;
@@ -1737,7 +1740,7 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, cons
                        chain_stride, ld, D, bits, sym_out, centres, c_stride, centre_out, status)
         if (K == 256) BS_POPW(4, 32);
         else if (K == 512) BS_POPW(8, 16);
-        else if (K == 1024) BS_POPW(16, 16);
+        else if (K == 1024) BS_POPW(16, 8);
         else if (K == 2048) BS_POPW(32, 8);
         else return BS_EUNSUPPORTED;
 #undef BS_POPW

@@ -108,15 +108,41 @@ struct Stager {
     }
 };
 
+// The K steps run through NS LDS stages (round 4).  NS = 2 is the double buffer of round 3: the DMA of step k + 1 under the
+// multiplies of step k, `__syncthreads()` (vmcnt(0) + barrier) between steps.  NS = 3 keeps the DMA of TWO steps in flight:
+// with few columns per launch (13 chains: 208 columns, one 32-column unit per workgroup) a K step has 16 MFMAs per wave
+// (0.4 us) and the loop ran at one memory latency per step (16 x 1.4 us = 23 us per launch, profiles/r04b); the wait at the
+// end of step k is then `vmcnt(LPS)` -- everything but the newest stage's LPS DMA instructions of this wave has landed --
+// followed by a bare s_barrier.  Stage (k + NS - 1) % NS was last read in step k - 1, whose barrier every wave has passed
+// before the DMA of step k + NS - 1 is issued in step k.  The summation order does not change.
+__device__ __forceinline__ constexpr int waitcnt_vm(int v) {        // s_waitcnt simm16 (gfx9): vmcnt = v, lgkmcnt = 0, expcnt free
+    return (v & 15) | (7 << 4) | ((v >> 4) << 14);
+}
+template <int NS, int LPS>
+__device__ __forceinline__ void stage_barrier() {
+    if constexpr (NS == 2) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm((NS - 2) * LPS));
+        __builtin_amdgcn_s_barrier();
+    }
+}
+template <int NS>
+__device__ __forceinline__ int stage_next(int buf, int by = 1) {
+    if constexpr (NS == 2) return buf ^ (by & 1);
+    const int b = buf + by;
+    return b >= NS ? b - NS : b;
+}
+
 // One chunk of NBLK column blocks: the K loop (the stage of its first step is in LDS buffer `buf` and synchronised), then
 // the stores.  The last step prefetches the first stage of the chunk that follows.  A wavefront owns MI x NBLK MFMA tiles
 // (32 MI rows x 32 NBLK columns); ALL operand fragments of a K step are requested from LDS before its first MFMA, so the
 // wave pays one LDS latency per 32 MI NBLK / 2 MFMAs instead of one per pair (round-3 visit A: the matrix pipe was busy
 // 70 % of the time with the reads interleaved).
-template <int NW, int MI, int NBLK>
+template <int NW, int MI, int NBLK, int NS = 2>
 __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float* __restrict__ M, const Chunk& cur,
                                           const Chunk& nxt, bool more, int& buf, int wave, int l32, int g) {
-    constexpr int BM = 32 * MI * NW, STAGE = Stager<NW, MI>::STAGE;
+    constexpr int BM = 32 * MI * NW, STAGE = Stager<NW, MI>::STAGE, LPS = Stager<NW, MI>::NA + Stager<NW, MI>::NB;
     f32x16 acc[MI][NBLK];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -126,11 +152,12 @@ __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float*
             for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.0f;
     const int nk = sg.Cin / G_BK;
     for (int kt = 0; kt < nk; ++kt) {
-        const bool last = kt + 1 == nk;
-        // DMA of the next step into the other buffer (its last reads completed before the previous barrier): in flight
-        // under the multiplies below, landed by the barrier at the end of this step
-        if (!last) sg.load(cur, (kt + 1) * G_BK, lds, buf ^ 1);
-        else if (more) sg.load(nxt, 0, lds, buf ^ 1);        // ... the next chunk's first stage under this chunk's last
+        // DMA of the step NS - 1 ahead into the stage whose last reads completed before the previous barrier: in flight under
+        // the multiplies below (NS = 3: and under the next step's).  Past the chunk's last step it is the next chunk's
+        // first stage(s); past the last chunk of the range a harmless reload (NS = 3 counts DMA instructions at its barrier)
+        const int ahead = kt + NS - 1;
+        if (ahead < nk) sg.load(cur, ahead * G_BK, lds, stage_next<NS>(buf, NS - 1));
+        else if (more || NS > 2) sg.load(more ? nxt : cur, (ahead - nk) * G_BK, lds, stage_next<NS>(buf, NS - 1));
         const float* As = lds + buf * STAGE + (wave * 32 * MI + l32) * G_LDA;
         const float* Bs = lds + buf * STAGE + BM * G_LDA + (g * 4) * G_LDB + l32;
         const int sw = (l32 >> 2) & 3;                       // source-side swizzle of the A granules, see Stager
@@ -154,8 +181,8 @@ __device__ __forceinline__ void run_chunk(Stager<NW, MI>& sg, float* lds, float*
 #pragma unroll
                     for (int ni = 0; ni < NBLK; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi][i], b[j][ni][i], acc[mi][ni], 0, 0, 0);
-        __syncthreads();
-        buf ^= 1;
+        stage_barrier<NS, LPS>();
+        buf = stage_next<NS>(buf);
     }
     // C layout of the 32x32 MFMA: register v of lane l is row (v/4)*8 + (l/32)*4 + v%4, column l%32
     float* Mt = M + (int64_t)cur.t * sg.Cout * sg.cols;
@@ -212,10 +239,10 @@ __device__ __forceinline__ void read_b(float (&b)[NBLK], const float* p) {
 //  * the operands of sub-step s + 1 (one k pair: MI x NBLK MFMAs) are requested before the MFMAs of sub-step s are issued
 //    and held in a second register set (sched_barrier keeps the order), across the barrier too: the barrier sits before the
 //    LAST sub-step's MFMAs, whose operands are in registers, and the first reads of the next stage follow it immediately.
-template <int NW, int MI, int NBLK, int DMA_AT, int LAB = 0>
+template <int NW, int MI, int NBLK, int DMA_AT, int LAB = 0, int NS = 2>
 __device__ __forceinline__ void run_chunk_p(Stager<NW, MI>& sg, float* lds, float* __restrict__ M, const Chunk& cur,
                                             const Chunk& nxt, bool more, int& buf, int wave, int l32, int g) {
-    constexpr int BM = 32 * MI * NW, STAGE = Stager<NW, MI>::STAGE;
+    constexpr int BM = 32 * MI * NW, STAGE = Stager<NW, MI>::STAGE, LPS = Stager<NW, MI>::NA + Stager<NW, MI>::NB;
     f32x16 acc[MI][NBLK];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -259,8 +286,8 @@ __device__ __forceinline__ void run_chunk_p(Stager<NW, MI>& sg, float* lds, floa
                 if (LAB & 3) {               // LAB: timing experiments with WRONG results (tools/gemm_probe.py --lab)
                     if (!(LAB & 2)) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
                 } else
-                __syncthreads();             // the next stage has landed (vmcnt) and nobody reads this one any more
-                buf ^= 1;
+                stage_barrier<NS, LPS>();    // the next stage has landed (vmcnt) and nobody reads this one any more
+                buf = stage_next<NS>(buf);
                 As = lds + buf * STAGE + offA;
                 Bs = lds + buf * STAGE + offB;
 #pragma unroll
@@ -271,9 +298,11 @@ __device__ __forceinline__ void run_chunk_p(Stager<NW, MI>& sg, float* lds, floa
             if (s == DMA_AT) {
                 // the DMA of the next step, branch-free so that its address arithmetic can sit between this sub-step's MFMAs
                 // (after the very last step of the workgroup's range: a harmless reload of this chunk's first stage)
+                const int ahead = kt + NS - 1;
+                const bool over = ahead >= nk;
                 Chunk c = cur;
-                if (last & more) c = nxt;
-                if (!(LAB & 8)) sg.template load<(LAB >> 4) & 3>(c, last ? 0 : (kt + 1) * G_BK, lds, buf ^ 1);
+                if (over & more) c = nxt;
+                if (!(LAB & 8)) sg.template load<(LAB >> 4) & 3>(c, (over ? ahead - nk : ahead) * G_BK, lds, stage_next<NS>(buf, NS - 1));
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -328,12 +357,12 @@ __device__ __forceinline__ void run_chunk_p(Stager<NW, MI>& sg, float* lds, floa
     }
 }
 
-template <int NW, int MI, int PIPE>
+template <int NW, int MI, int PIPE, int NS>
 __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
                                                           float* __restrict__ M, int Cout, int Cin, int64_t cols,
                                                           int ncb, int nrt, int units, int even_ranges) {
     constexpr int BM = 32 * MI * NW;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][STAGE]
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [NS][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;
 
@@ -377,7 +406,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restric
     sg.init(U, V, Cout, Cin, cols, tid);
     Chunk cur = decode(u);
     sg.load(cur, 0, lds, 0);
-    __syncthreads();
+    if constexpr (NS > 2) sg.load(cur, G_BK, lds, 1);      // (host: Cin >= 2 G_BK) two steps in flight from the start
+    stage_barrier<NS, Stager<NW, MI>::NA + Stager<NW, MI>::NB>();
     int buf = 0;
     while (true) {
         const int unext = u + cur.nb;
@@ -388,15 +418,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restric
             constexpr int AT = 1;                 // the sub-step whose MFMAs the DMA issue of the next stage is spread over
             constexpr int LAB = PIPE >= 16 ? PIPE - 16 : 0;
             // full chunks pipelined; a range's ragged ends (1-3 column blocks: too few MFMAs per sub-step to cover a read) as before
-            if (cur.nb == 4) run_chunk_p<NW, MI, 4, AT, LAB>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-            else if (cur.nb == 3) run_chunk<NW, MI, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-            else if (cur.nb == 2) run_chunk<NW, MI, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-            else run_chunk<NW, MI, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            if (cur.nb == 4) run_chunk_p<NW, MI, 4, AT, LAB, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 3) run_chunk<NW, MI, 3, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 2) run_chunk<NW, MI, 2, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else run_chunk<NW, MI, 1, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
         } else {
-            if (cur.nb == 4) run_chunk<NW, MI, 4>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-            else if (cur.nb == 3) run_chunk<NW, MI, 3>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-            else if (cur.nb == 2) run_chunk<NW, MI, 2>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
-            else run_chunk<NW, MI, 1>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            if (cur.nb == 4) run_chunk<NW, MI, 4, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 3) run_chunk<NW, MI, 3, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else if (cur.nb == 2) run_chunk<NW, MI, 2, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
+            else run_chunk<NW, MI, 1, NS>(sg, lds, M, cur, nxt, more, buf, wave, l32, g);
         }
         if (!more) break;
         u = unext;
@@ -419,35 +449,52 @@ int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int C
     const int64_t ncb = (cols + 31) / 32, nrt = (Cout + BM - 1) / BM;
     const int64_t units = (int64_t)T * nrt * ncb;
     if (units > 0x7fffffff || (int64_t)Cin * cols > 0x7fffffff) return BS_EUNSUPPORTED;
-    const size_t shm = 2 * (size_t)(BM * G_LDA + G_BK * G_LDB) * sizeof(float);
-    // workgroups per CU: two of the 256-row shape (48 KB of LDS each, one wavefront per SIMD each, up to 256 registers per lane);
-    // the one-wave shape of the head convolutions is bounded by its 22 KB of LDS
-    const int per_cu = BM >= 128 ? 2 : BM == 64 ? 4 : 6;
+    // LDS stages: 3 for launches with little work per workgroup (latency-bound K loop, see stage_barrier), else 2.  Small =
+    // at most BITSWAP_GEMM_NS3_UNITS units (default: four per resident workgroup slot of the two-stage shape); results are
+    // bitwise the same either way
+    const int per_cu2 = BM >= 128 ? 2 : BM == 64 ? 4 : 6;
+    static const long ns3_units = [] { const char* e = getenv("BITSWAP_GEMM_NS3_UNITS"); return e ? atol(e) : -1L; }();
+    const int64_t small = ns3_units >= 0 ? ns3_units : (int64_t)cu_count() * per_cu2 * 4;
+    const bool ns3 = Cin >= 2 * G_BK && units <= small;
+    const size_t shm = (ns3 ? 3 : 2) * (size_t)(BM * G_LDA + G_BK * G_LDB) * sizeof(float);
+    // workgroups per CU: two of the 256-row shape (48 / 72 KB of LDS each, one wavefront per SIMD each, up to 256 registers per
+    // lane); the one-wave shape of the head convolutions is bounded by its 20 / 30 KB of LDS
+    const int per_cu = ns3 ? (BM >= 128 ? 2 : BM == 64 ? 4 : 5) : per_cu2;
     int64_t G = (int64_t)cu_count() * per_cu;
-    if (const char* e = getenv("BITSWAP_GEMM_WGS_PER_CU")) {    // tuning only: the summation order does not depend on it
-        const int v = atoi(e);
-        if (v > 0) G = (int64_t)cu_count() * v;
-    }
+    static const int wgs_env = [] { const char* e = getenv("BITSWAP_GEMM_WGS_PER_CU"); return e ? atoi(e) : 0; }();   // tuning only
+    if (wgs_env > 0) G = (int64_t)cu_count() * wgs_env;
     if (G > units) G = units;
-    const char* ev = getenv("BITSWAP_GEMM_VARIANT");           // tuning only: the summation order does not depend on it
-    const int variant = ev ? atoi(ev) : 2;
+    static const int variant = [] { const char* e = getenv("BITSWAP_GEMM_VARIANT"); return e ? atoi(e) : 2; }();     // tuning only
+    static const int even = getenv("BITSWAP_GEMM_EVEN_RANGES") ? 1 : 0;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), shm, st, U, V, M, Cout, Cin, cols, (int)ncb, (int)nrt, (int)units,
-                           getenv("BITSWAP_GEMM_EVEN_RANGES") ? 1 : 0);
+        if (shm > 48 * 1024) {                 // more than the default dynamic LDS limit: raise it once per kernel and device
+            static bool raised[16] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev >= 0 && dev < 16 && !raised[dev]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                    return false;
+                raised[dev] = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), shm, st, U, V, M, Cout, Cin, cols, (int)ncb, (int)nrt, (int)units, even);
+        return true;
     };
-    if (variant == 0) go(k_wino_gemm<NW, MI, 0>);     // the visit-A/B kernel (operand reads where the compiler puts them), for the probe
+    bool ok = true;
+    if (variant == 0) ok = go(k_wino_gemm<NW, MI, 0, 2>);     // the visit-A/B kernel (operand reads where the compiler puts them), for the probe
 #ifdef BS_GEMM_LAB    // timing experiments with WRONG results (tools/gemm_probe.py --lab builds its own library with this)
-    else if (NW == 4 && MI == 2 && variant == 17) go(k_wino_gemm<4, 2, 17>);      // no vmcnt wait at the barrier
-    else if (NW == 4 && MI == 2 && variant == 19) go(k_wino_gemm<4, 2, 19>);      // no barrier at all
-    else if (NW == 4 && MI == 2 && variant == 20) go(k_wino_gemm<4, 2, 20>);      // no stores
-    else if (NW == 4 && MI == 2 && variant == 24) go(k_wino_gemm<4, 2, 24>);      // no DMA
-    else if (NW == 4 && MI == 2 && variant == 31) go(k_wino_gemm<4, 2, 31>);      // MFMAs and LDS reads only
-    else if (NW == 4 && MI == 2 && variant == 32) go(k_wino_gemm<4, 2, 32>);      // no DMA of the A tile (U)
-    else if (NW == 4 && MI == 2 && variant == 48) go(k_wino_gemm<4, 2, 48>);      // no DMA of the B tile (V)
-    else if (NW == 4 && MI == 2 && variant == 80) go(k_wino_gemm<4, 2, 80>);      // (right results) plain stores instead of nt
+    else if (NW == 4 && MI == 2 && variant == 17) ok = go(k_wino_gemm<4, 2, 17, 2>);      // no vmcnt wait at the barrier
+    else if (NW == 4 && MI == 2 && variant == 19) ok = go(k_wino_gemm<4, 2, 19, 2>);      // no barrier at all
+    else if (NW == 4 && MI == 2 && variant == 20) ok = go(k_wino_gemm<4, 2, 20, 2>);      // no stores
+    else if (NW == 4 && MI == 2 && variant == 24) ok = go(k_wino_gemm<4, 2, 24, 2>);      // no DMA
+    else if (NW == 4 && MI == 2 && variant == 31) ok = go(k_wino_gemm<4, 2, 31, 2>);      // MFMAs and LDS reads only
+    else if (NW == 4 && MI == 2 && variant == 32) ok = go(k_wino_gemm<4, 2, 32, 2>);      // no DMA of the A tile (U)
+    else if (NW == 4 && MI == 2 && variant == 48) ok = go(k_wino_gemm<4, 2, 48, 2>);      // no DMA of the B tile (V)
+    else if (NW == 4 && MI == 2 && variant == 80) ok = go(k_wino_gemm<4, 2, 80, 2>);      // (right results) plain stores instead of nt
 #endif
-    else go(k_wino_gemm<NW, MI, 2>);
-    return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
+    else if (ns3) ok = go(k_wino_gemm<NW, MI, 2, 3>);
+    else ok = go(k_wino_gemm<NW, MI, 2, 2>);
+    return ok && hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
 }
 
 }  // namespace

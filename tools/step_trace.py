@@ -20,11 +20,10 @@ def main():
             n = n.split("(")[0][-60:]
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), n))
     ev.sort()
-    # the last stretch without a gap of more than 20 ms
-    end = len(ev) - 1
-    hi = max(e[1] for e in ev)
+    # the window ends with the last coding kernel of the run (the receiver's last push: verification copies follow it)
+    hi = max(e[1] for e in ev if "k_rans_" in e[3] or "k_layer" in e[3])
     lo = hi - int(ms * 1e6)
-    win = [e for e in ev if e[0] >= lo]
+    win = [e for e in ev if e[0] >= lo and e[1] <= hi]
     t0 = win[0][0]
     lastq = {}
     per = defaultdict(lambda: [0, 0.0, 0.0])
