@@ -83,7 +83,9 @@ def parse():
                     help="lowrate: the calibrated synthetic model coding its own samples at a trained model's rate (workload.py)")
     ap.add_argument("--groups", type=int, default=0,
                     help="chain groups per GPU on separate HIP streams (serial rANS of one group under the convs of another); "
-                         "0 = auto: 2 from 64 chains per GPU on, else 1 (the forked block step overlaps a group with itself)")
+                         "0 = auto: 2 above 128 chains per GPU, else 1 (few chains: ONE group whose forked block step is replayed "
+                         "from a hipGraph -- 100 chains: 24.0 ms per step against 24.5 in two groups and 34.6 in three, "
+                         "profiles/r04e: concurrent graph replays cost each other more than the overlap returns)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (the driver's default): every rank codes its own --chains chains.  strong: --total-chains chains "
                          "IN TOTAL -- the reference's 100 experiments / 100 crop images, BASELINE configs 4 and 5 -- sharded over "
@@ -635,7 +637,7 @@ def main(args):
         chains = len(ids)
     else:
         chains = args.chains
-    groups = args.groups or (2 if chains >= 64 else 1)
+    groups = args.groups or (2 if chains > 128 else 1)
     if strong and name == "imagenetcrop4":
         r = run_ragged(args, name, ids, lengths, args.total_chains, args.steps, args.warmup, dev, rank, world, dist)
         groups = 1

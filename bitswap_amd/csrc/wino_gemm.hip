@@ -463,7 +463,12 @@ int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int C
     int64_t G = (int64_t)cu_count() * per_cu;
     static const int wgs_env = [] { const char* e = getenv("BITSWAP_GEMM_WGS_PER_CU"); return e ? atoi(e) : 0; }();   // tuning only
     if (wgs_env > 0) G = (int64_t)cu_count() * wgs_env;
+    // few units per workgroup slot: fewer workgroups with whole four-block chunks (an A tile fetched per 128 columns instead of
+    // per 32 or 64, the hand-pipelined chunk code) beat one or two units on every slot -- BITSWAP_GEMM_MIN_UNITS per workgroup
+    static const int min_units = [] { const char* e = getenv("BITSWAP_GEMM_MIN_UNITS"); return e ? atoi(e) : 1; }();
+    if (min_units > 1 && G * min_units > units) G = (units + min_units - 1) / min_units;
     if (G > units) G = units;
+    if (G < 1) G = 1;
     static const int variant = [] { const char* e = getenv("BITSWAP_GEMM_VARIANT"); return e ? atoi(e) : 2; }();     // tuning only
     static const int even = getenv("BITSWAP_GEMM_EVEN_RANGES") ? 1 : 0;
     auto go = [&](auto kern) {
