@@ -6,13 +6,19 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bitswap_hip.hip")
-SRCS = [SRC, os.path.join(HERE, "csrc", "net_epilogue.hip"), os.path.join(HERE, "csrc", "wino_gemm.hip")]
+# one translation unit per kernel family (round 4: the 1,850-line bitswap_hip.hip with ~100 template instantiations took
+# 20 s on one core; the units compile in parallel) around the shared device helpers of csrc/bitswap_dev.h
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("bitswap_hip.hip", "tables.hip", "pop.hip", "push.hip", "layer64.hip",
+                                                 "net_epilogue.hip", "wino_gemm.hip")]
 HDR = os.path.join(HERE, "..", "include", "bitswap_hip.h")
+DEV_HDR = os.path.join(HERE, "csrc", "bitswap_dev.h")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 LIB = os.environ.get("BITSWAP_HIP_LIB") or os.path.join(HERE, "csrc", "libbitswap_hip.so")
 
 # -ffp-contract=off: the deterministic CDF spec forbids any fusion the source does not spell out
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-pass-failed"]   # K = 2048 rows cannot reach the occupancy hint of k_logistic; that is expected
+EXTRA_FLAGS = [f for f in os.environ.get("BITSWAP_HIPCC_EXTRA", "").split() if f]   # e.g. -DBS_GEMM_LAB (tools/gemm_probe.py)
 
 
 def hipcc_path():
@@ -26,7 +32,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SRCS + [HDR] if os.path.exists(p))
+    return any(os.path.getmtime(p) > t for p in SRCS + [HDR, DEV_HDR] if os.path.exists(p))
 
 
 ASAN_LIB = os.path.join(HERE, "csrc", "libbitswap_hip_asan.so")
@@ -49,12 +55,32 @@ def build_asan(verbose=False):
 
 
 def build_hip(force=False, verbose=False):
-    """Compile the HIP library if missing or older than its sources.  Returns the .so path."""
-    if force or is_stale():
-        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-o", LIB] + SRCS
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    """Compile the HIP library if missing or older than its sources: every translation unit to an object file (in parallel,
+    only the stale ones), then one link.  Returns the .so path."""
+    if not (force or is_stale()):
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    import hashlib
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS
+    # objects of another flag set (tools/gemm_probe.py --lab appends -DBS_GEMM_LAB) never mix with the product's
+    objdir = OBJ_DIR + "_" + hashlib.md5(" ".join(cflags).encode()).hexdigest()[:8]
+    os.makedirs(objdir, exist_ok=True)
+    deps = max(os.path.getmtime(p) for p in (HDR, DEV_HDR, os.path.abspath(__file__)))
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), deps):
+            cmd = [hipcc_path()] + cflags + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(SRCS), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SRCS))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
     return LIB
 
 

@@ -1,0 +1,623 @@
+// pop.hip -- the serial pop kernels of the reference stream format: k_rans_pop_wave (BS_LAYOUT_WAVE rows), k_rans_pop_pivot (BS_LAYOUT_PIVOT: rebuilds one group of bins), k_rans_pop / _generic (linear rows)
+// (one of the translation units of libbitswap_hip.so; shared device helpers: bitswap_dev.h; entry points: include/bitswap_hip.h)
+#include "bitswap_dev.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// k_rans_pop: one wavefront per chain.  NV = uint4 loads per lane per row (K = 256*NV), rows
+// 16-byte aligned.  Rows are streamed PF deep into registers (the table lives in HBM: at B=100,
+// Z=2048, K=1024 it is 0.84 GB, far beyond L2), the symbol is the popcount of 4*NV 64-wide ballots,
+// c_s / c_{s+1} come out of the row registers by scalar-indexed VGPR read + v_readlane (no dependent
+// memory access), the next two stack words wait in scalar registers, and the 64-bit head never
+// leaves the scalar unit.
+// ------------------------------------------------------------------------------------------
+template <int NV>
+struct RowRegs {
+    static constexpr int K = NV * 256;
+    typedef uint32_t vec_t __attribute__((ext_vector_type(4 * NV)));
+    vec_t v;
+    __device__ __forceinline__ void find(uint32_t m, int bits, int& s, uint32_t& cs, uint32_t& cs1) const {
+        s = count_le(m) - 1;  // c_0 = 0 <= m always, so s >= 0
+        cs = entry(s);
+        cs1 = (s + 1 < K) ? entry(s + 1) : (1u << bits);
+    }
+    __device__ __forceinline__ void load(const uint32_t* row, int lane) {
+        const uint4* r = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint4 t = r[i * 64 + lane];
+            v[4 * i + 0] = t.x;
+            v[4 * i + 1] = t.y;
+            v[4 * i + 2] = t.z;
+            v[4 * i + 3] = t.w;
+        }
+    }
+    // entry j of the row: uint4 index q = j/4 lives in lane q%64, load i = q/64, component j%4
+    __device__ __forceinline__ uint32_t entry(int j) const {
+        const int e = ((j >> 8) << 2) | (j & 3);
+        return (uint32_t)__builtin_amdgcn_readlane((int)v[e], (j >> 2) & 63);
+    }
+    __device__ __forceinline__ int count_le(uint32_t m) const {
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 4 * NV; ++e) cnt += __popcll(__ballot(v[e] <= m));
+        return cnt;
+    }
+};
+
+template <class ROW, int PF>
+__global__ __launch_bounds__(64) void k_rans_pop(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                 int32_t* __restrict__ len, int64_t cap,
+                                                 const uint32_t* __restrict__ cdf, int64_t chain_stride, int64_t ld,
+                                                 int D, int bits, int32_t* __restrict__ sym_out,
+                                                 const double* __restrict__ centres, int64_t c_stride,
+                                                 float* __restrict__ centre_out, int32_t* __restrict__ status) {
+    // D is a multiple of 64 here (host dispatch).  The main loop contains NO conditional memory
+    // operation: row prefetches are unconditional (clamped addresses), stack words are fetched one
+    // 64-row chunk ahead, decoded symbols go to LDS and are written out in a coalesced epilogue.
+    // That keeps hipcc's s_waitcnt vmcnt(N) counted (PF-1 rows stay in flight) instead of vmcnt(0).
+    extern __shared__ int32_t sh_sym[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) {  // failed chain: skipped, but its outputs stay well-defined
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
+    // latency-critical serial wave: win instruction-issue arbitration against co-resident bulk
+    // kernels (the convs of another chain group run concurrently on other streams)
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t* tab = cdf + (int64_t)b * chain_stride;
+    const uint64_t mask = (1ull << bits) - 1;
+    int st = BS_ST_OK;
+
+    auto stack_window = [&](int top, int off) -> uint32_t {  // lane l <- stk[top-1-off-l] (0 if below the stack)
+        const int i = top - 1 - off - lane;
+        return stk[max(i, 0)];
+    };
+    // words this chunk may consume (at most 64): loaded against `wtop`, the word count at load time
+    int wtop = n;
+    uint32_t wa = stack_window(wtop, 0), wb = stack_window(wtop, 64);
+    // materialise the first window now (one exposed latency per launch): otherwise its loads count as
+    // 'possibly still in flight' at every window read of the main loop and turn the counted waits into ~vmcnt(0)
+    asm volatile("" : "+v"(wa), "+v"(wb));
+
+    ROW buf[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        buf[u].load(tab + (int64_t)max(D - 1 - u, 0) * ld, lane);
+        // keep issue order == consumption order: the counted vmcnt of the main loop must also be valid
+        // on the first trip, when these loads (not the in-loop refills) are the ones in flight
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
+        // fetch the window the NEXT chunk will read; it has a whole chunk to arrive
+        const int ntop = n;
+        const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
+        int mysym = 0;
+        for (int g = 64 / PF - 1; g >= 0; --g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int d = c64 * 64 + g * PF + (PF - 1 - u);
+                const uint32_t m = (uint32_t)(h & mask);
+                int s;
+                uint32_t cs, cs1;
+                buf[u].find(m, bits, s, cs, cs1);
+                // this row's registers are free again: fetch the row PF steps ahead (clamped, unconditional)
+                buf[u].load(tab + (int64_t)max(d - PF, 0) * ld, lane);
+                const uint64_t f = (uint64_t)(cs1 - cs);
+                h = f * (h >> bits) + (uint64_t)(m - cs);
+                if (h < (1ull << 32)) {
+                    if (n <= 0) {
+                        st = BS_ST_UNDERFLOW;  // keep going on garbage (reads stay in bounds); reported below
+                    } else {
+                        const int o = wtop - n;  // 0..127 within this chunk's window
+                        const uint32_t w = (o < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)wa, o & 63)
+                                                    : (uint32_t)__builtin_amdgcn_readlane((int)wb, o & 63);
+                        h = (h << 32) | (uint64_t)w;
+                        --n;
+                    }
+                }
+                mysym = (lane == (d & 63)) ? s : mysym;
+            }
+        }
+        sh_sym[c64 * 64 + lane] = mysym;
+        wtop = ntop;
+        wa = na;
+        wb = nb;
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+    __syncthreads();
+    for (int dd = lane; dd < D; dd += 64) {
+        const int sy = sh_sym[dd];
+        const int64_t o = (int64_t)b * D + dd;
+        sym_out[o] = sy;
+        if (centres) centre_out[o] = (float)centres[(int64_t)dd * c_stride + sy];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rans_pop_wave: BS_LAYOUT_WAVE rows, one wavefront per chain.
+//
+// A lone wavefront issues about one instruction every 3-4 ns whatever it is (tools/probes/instr_latency.hip),
+// so the step is written for instruction count.  A row is NR = K/64 registers (register r, lane l =
+// c_{64r+l}) plus one pivot register (lane r = c_{64r}, lane NR = 2^bits, other lanes 0xffffffff):
+//   ballot(pivot <= m)      -> which register holds the symbol (scalar-indexed VGPR read)
+//   ballot(R[r] <= m)       -> its lane; the entries are strictly increasing, so the popcount IS the
+//                              position, no shifting or masking of the ballot
+//   c_s, c_{s+1}            -> two v_readlane of that same register (the pivot of the next register when
+//                              the symbol sits in lane 63)
+// Rows arrive through buffer loads whose only per-row address arithmetic is one scalar subtract; PF rows
+// stay in flight (counted vmcnt).  Stack words for a 64-symbol chunk wait in ONE register (lane k = the k-th
+// word the chunk will consume), realigned once per chunk with ds_bpermute, so a renormalisation is one
+// v_readlane.  The 64-bit head never leaves the scalar unit; decoded symbols go to a lane of a register
+// (one select per symbol), to LDS once per chunk, and to HBM with the centre gather in a coalesced epilogue.
+// ------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NR>
+struct WaveRow2 {
+    typedef uint32_t vec_t __attribute__((ext_vector_type(NR)));
+    vec_t R;
+    uint32_t pivot;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, uint32_t voff_row, uint32_t voff_piv, uint32_t soff) {
+#pragma unroll
+        for (int i = 0; i < NR / 4; ++i) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_row + i * 1024, soff, 2);  // nt: read once
+            R[4 * i + 0] = t.x;
+            R[4 * i + 1] = t.y;
+            R[4 * i + 2] = t.z;
+            R[4 * i + 3] = t.w;
+        }
+        pivot = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_piv, soff, 2);
+    }
+};
+
+template <int NR, int PF>
+__global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                      int32_t* __restrict__ len, int64_t cap,
+                                                      const uint32_t* __restrict__ cdf, int64_t chain_stride,
+                                                      int64_t ld, int D, int bits, int32_t* __restrict__ sym_out,
+                                                      const double* __restrict__ centres, int64_t c_stride,
+                                                      float* __restrict__ centre_out, int32_t* __restrict__ status) {
+    // host dispatch guarantees: D % 64 == 0, rows 16-byte aligned, D * ld * 4 < 2^31
+    constexpr int K = NR * 64;
+    extern __shared__ int32_t sh_sym[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) {  // failed chain: skipped, but its outputs stay well-defined
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
+    // latency-critical serial wave: win instruction-issue arbitration against co-resident bulk kernels
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t ld4 = (uint32_t)ld * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cdf + (int64_t)b * chain_stride), 0, (int)((uint32_t)D * ld4), 0x00020000);
+    const uint32_t voff_row = (uint32_t)lane * 16u, voff_piv = (uint32_t)K * 4u + (uint32_t)lane * 4u;
+    const uint32_t mask = (1u << bits) - 1u;
+    int st = BS_ST_OK;
+
+    auto stack_window = [&](int top, int off) -> uint32_t {  // lane l <- stk[top-1-off-l] (clamped at the bottom)
+        const int i = top - 1 - off - lane;
+        return stk[max(i, 0)];
+    };
+    // the 128 words below `wtop`: whatever the previous chunk consumed (<= 64), the next 64 are in here
+    int wtop = n;
+    uint32_t wa = stack_window(wtop, 0), wb = stack_window(wtop, 64);
+    asm volatile("" : "+v"(wa), "+v"(wb));  // see k_rans_pop: keep these loads out of the counted waits
+
+    WaveRow2<NR> buf[PF];
+    uint32_t soff = (uint32_t)(D - 1) * ld4;  // byte offset of the row the NEXT refill fetches
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        buf[u].load(rs, voff_row, voff_piv, soff);
+        soff = (uint32_t)max((int)(soff - ld4), 0);  // clamped: the last PF refills re-read row 0, unused
+        __builtin_amdgcn_sched_barrier(0);           // issue order == consumption order (counted vmcnt)
+    }
+
+    for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
+        // this chunk's words: realign the 128-word window by what the previous chunk consumed
+        const int idx = (wtop - n) + lane;  // 0..127
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wa);
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wb);
+        const uint32_t win = idx < 64 ? pa : pb;
+        // and fetch the window the NEXT chunk will realign; it has a whole chunk to arrive
+        const int ntop = n;
+        const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
+        int o = 0;  // words consumed in this chunk
+        // the chunk's symbols: lane i of (symr, symp) = (register, position) of symbol 64 c64 + i.  Both are scalars the
+        // search has in hand, the lane is a compile-time constant of the unrolled chunk: two v_writelane per symbol (round 3
+        // spent eight instructions per symbol on `(lane == d % 64) ? 64 r + p : mysym`)
+        uint32_t symr = 0, symp = 0;
+#pragma unroll
+        for (int g = 64 / PF - 1; g >= 0; --g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const uint32_t m = (uint32_t)h & mask;
+                const int r1 = __popcll(__ballot(buf[u].pivot <= m));  // 1..NR (c_0 = 0 <= m)
+                const uint32_t x = buf[u].R[r1 - 1];
+                const int pos = __popcll(__ballot(x <= m));            // 1..64
+                const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)x, pos - 1);
+                const uint32_t cin = (uint32_t)__builtin_amdgcn_readlane((int)x, pos & 63);
+                const uint32_t cnx = (uint32_t)__builtin_amdgcn_readlane((int)buf[u].pivot, r1);
+                const uint32_t f = (pos == 64 ? cnx : cin) - cs;
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(symr) : "s"(r1 - 1), "n"(g * PF + (PF - 1 - u)));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(symp) : "s"(pos - 1), "n"(g * PF + (PF - 1 - u)));
+                // this row's registers are free again: fetch the row PF steps ahead
+                buf[u].load(rs, voff_row, voff_piv, soff);
+                soff = (uint32_t)max((int)(soff - ld4), 0);
+                h = (uint64_t)f * (h >> bits) + (uint64_t)(m - cs);
+                uint32_t hhi = (uint32_t)(h >> 32);
+#if !__has_feature(address_sanitizer)   // (the ASan build, bitswap_amd/build.py --asan, keeps the head in vector registers)
+                asm("" : "+s"(hhi));  // keep this a 32-bit scalar compare (hipcc otherwise builds a 64-bit VALU one)
+#endif
+                if (hhi == 0u) {  // h < 2^32, mnist_compress.py:65
+                    h = (h << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, o);
+                    ++o;
+                }
+            }
+        }
+        sh_sym[c64 * 64 + lane] = (int32_t)(symr * 64u + symp);
+        n -= o;
+        if (n < 0) {  // popped below the bottom: garbage from here on (reads stay in bounds), reported below
+            st = BS_ST_UNDERFLOW;
+            n = 0;
+        }
+        wtop = ntop;
+        wa = na;
+        wb = nb;
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+    __syncthreads();
+    for (int dd = lane; dd < D; dd += 64) {
+        const int sy = sh_sym[dd];
+        const int64_t oo = (int64_t)b * D + dd;
+        sym_out[oo] = sy;
+        if (centres) centre_out[oo] = (float)centres[(int64_t)dd * c_stride + sy];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rans_pop_pivot: BS_LAYOUT_PIVOT rows (uniform-width bins, CDF spec 2), one wavefront per chain.
+//
+// The table kernel hands over 64 cumulative values per row (one per group of NPL bins) plus which bin took the remnant
+// and how much.  Per symbol: ballot(pivot <= m) names the group L; lanes 0 .. NPL-1 rebuild the cdf of its NPL bins and
+// lane NPL the last cdf of group L-1, each with exactly the operations logistic_row spends on that bin (own anchor
+// exponential, own geometric factor, residual of the stored endpoint, correctly rounded reciprocal) -- the truncated
+// differences are therefore the table's, and a 6-step scan on top of the pivot gives c_s and f_s.  About 2.5x the
+// instructions of k_rans_pop_wave per symbol, but 512 B of HBM traffic per row instead of 4352 B: at 400 chains the
+// row-reading pop kernel ran at the HBM roof (3.57 GB per launch in 0.57 ms) and nothing overlapped with it
+// (profiles/r03m_overlap2.txt); this one touches the L2-resident endpoint table and little else.
+// Endpoints of the group are fetched AFTER the group is known (data dependent) and consumed after the two exponentials
+// that do not need them; pivots and the 64 anchor endpoints of a row are prefetched PF rows ahead like the rows of
+// k_rans_pop_wave; (mu, scale, bin width) wait in registers per 64-symbol chunk.
+// ------------------------------------------------------------------------------------------
+// lane i <- lane i-1 of the whole wavefront (DPP wave_shr:1; lane 0 keeps its value)
+__device__ __forceinline__ double wave_shr1_f64(double v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+template <int NPL, typename PT, int PF>
+__global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                       int32_t* __restrict__ len, int64_t cap,
+                                                       const uint32_t* __restrict__ piv, int64_t ld,
+                                                       const double* __restrict__ endpoints, int64_t e_stride,
+                                                       const double* __restrict__ step, const PT* __restrict__ mu,
+                                                       const PT* __restrict__ scale, int D, int bits, int quantbits,
+                                                       int32_t* __restrict__ sym_out, const double* __restrict__ centres,
+                                                       int64_t c_stride, float* __restrict__ centre_out,
+                                                       int32_t* __restrict__ status) {
+    constexpr int K = NPL * 64;
+    constexpr bool ONE_EXP = NPL <= 16;      // both exponentials of a symbol in ONE instruction stream (lower / upper half-wave)
+    extern __shared__ int32_t sh_sym[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) {  // failed chain (a bad table among them): skipped, outputs well-defined
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
+    __builtin_amdgcn_s_setprio(BS_SERIAL_PRIO);
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t mask = (1u << bits) - 1u;
+    const double M = (double)((1ll << bits) - (1ll << quantbits));
+    int st = BS_ST_OK;
+    const int64_t ld2 = ld / 2;
+    // this lane's role in the rebuild.  Lanes 0 .. NPL-1: bin `bi` of the symbol's group; lane NPL: the last bin of the group
+    // below it.  With ONE_EXP the upper half-wave evaluates the geometric factors Q_b = exp(-b h/scale) in the same
+    // instructions in which the lower half evaluates the anchors exp(-t_a); lane 32 + k serves lane k.
+    const bool is_bin = lane < NPL;
+    const int role = ONE_EXP ? (lane & 31) : lane;
+    const int bi = role < NPL ? role : NPL - 1;
+    const bool q_lane = ONE_EXP && lane >= 32;
+
+    auto stack_window = [&](int top, int off) -> uint32_t {
+        const int i = top - 1 - off - lane;
+        return stk[max(i, 0)];
+    };
+    int wtop = n;
+    uint32_t wa = stack_window(wtop, 0), wb = stack_window(wtop, 64);
+
+    uint2 pv[PF];
+    double anc[PF];
+    const uint2* pp = reinterpret_cast<const uint2*>(piv + (int64_t)b * D * ld) + (int64_t)(D - 1) * ld2 + lane;   // row of the next refill
+    const double* ap = endpoints + (int64_t)(D - 1) * e_stride + lane * NPL;
+    int dl = D - 1;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        pv[u] = *pp;
+        anc[u] = *ap;
+        if (dl > 0) { pp -= ld2; ap -= e_stride; }
+        --dl;
+    }
+    const double* erow = endpoints + (int64_t)(D - 1) * e_stride;   // endpoint row of the symbol being popped
+
+    int d = D - 1;
+    for (int c64 = D / 64 - 1; c64 >= 0; --c64) {
+        const int idx = (wtop - n) + lane;  // 0..127
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wa);
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_ds_bpermute((idx & 63) << 2, (int)wb);
+        const uint32_t win = idx < 64 ? pa : pb;
+        const int ntop = n;
+        const uint32_t na = stack_window(ntop, 0), nb = stack_window(ntop, 64);
+        // parameters of this chunk's 64 rows: lane k <- row c64*64 + k
+        const int64_t prm = (int64_t)b * D + c64 * 64 + lane;
+        const double mu_l = (double)mu[prm], h_l = step[c64 * 64 + lane];
+        const double rs_l = recip_scale((double)scale[prm]);
+        const double hr_l = h_l * rs_l;
+        int o = 0;
+        uint32_t mysym = 0;
+        for (int g = 64 / PF - 1; g >= 0; --g) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int dk = d & 63;
+                const uint32_t m = (uint32_t)h & mask;
+                const int L = __popcll(__ballot(pv[u].x <= m)) - 1;          // group of the symbol: 0..63 (c_0 = 0 <= m)
+                const int Lb = max(L - 1, 0);
+                const int j = (is_bin ? L : Lb) * NPL + bi;                  // this lane's bin (lanes 0 .. NPL)
+                // its upper endpoint: data dependent, requested first, used last
+                const double e_j = erow[min(j, K - 2)];
+                erow -= d > 0 ? e_stride : 0;
+                const double m_ = readlane_f64(mu_l, dk), rs = readlane_f64(rs_l, dk), hstep = readlane_f64(h_l, dk);
+                const double hr = readlane_f64(hr_l, dk);
+                const double eL = readlane_f64(anc[u], L), eLb = readlane_f64(anc[u], Lb);
+                const double e_a = is_bin ? eL : eLb;
+                const uint32_t piv_L = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].x, L);
+                const uint32_t bumped = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 0);
+                const uint32_t rem = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 1);
+                // refill: the row PF steps ahead
+                pv[u] = *pp;
+                anc[u] = *ap;
+                if (dl > 0) { pp -= ld2; ap -= e_stride; }
+                --dl;
+                // logistic_row, one bin per lane
+                double A, Q;
+                if (ONE_EXP) {
+                    const double x = det_exp(q_lane ? -((double)bi * hr) : -((e_a - m_) * rs));
+                    A = x;
+                    Q = __shfl(x, lane | 32, 64);                            // lane k < 32 <- lane 32 + k
+                } else {
+                    A = det_exp(-((e_a - m_) * rs));
+                    Q = det_exp(-((double)bi * hr));
+                }
+                const double r = e_j - fma((double)bi, hstep, e_a);
+                const double eps = r * rs;
+                const double uu = fma(-A, eps, A);
+                double c = recip_1_to_huge(fma(Q, uu, 1.0));
+                if (j == K - 1) c = 1.0;                                     // the last bin has no upper endpoint
+                // cdf of the bin below: lane-1 within the group, lane NPL for bin 0, nothing for the very first bin
+                double below = wave_shr1_f64(c);
+                const double c_grp_below = readlane_f64(c, NPL);
+                if (lane == 0) below = L == 0 ? 0.0 : c_grp_below;
+                uint32_t f = trunc_u32((c - below) * M) + 1u;
+                if ((uint32_t)j == bumped) f += rem;
+                if (!is_bin) f = 0u;
+                uint32_t incl = f;                                           // inclusive scan over the NPL bins
+                incl += dpp_or0<0x111, 0xf>(incl);
+                incl += dpp_or0<0x112, 0xf>(incl);
+                if (NPL > 4) incl += dpp_or0<0x114, 0xf>(incl);
+                if (NPL > 8) incl += dpp_or0<0x118, 0xf>(incl);
+                if (NPL > 16) incl += dpp_or0<0x142, 0xa>(incl);
+                const uint32_t cst = piv_L + incl - f;                       // c of this lane's bin
+                const int pos = __popcll(__ballot(is_bin && cst <= m));      // 1..NPL
+                const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)cst, pos - 1);
+                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)f, pos - 1);
+                mysym = (lane == dk) ? (uint32_t)(L * NPL + pos - 1) : mysym;
+                h = (uint64_t)fs * (h >> bits) + (uint64_t)(m - cs);
+                if ((uint32_t)(h >> 32) == 0u) {  // h < 2^32, mnist_compress.py:65
+                    h = (h << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, o);
+                    ++o;
+                }
+                --d;
+            }
+        }
+        sh_sym[c64 * 64 + lane] = (int32_t)mysym;
+        n -= o;
+        if (n < 0) {
+            st = BS_ST_UNDERFLOW;
+            n = 0;
+        }
+        wtop = ntop;
+        wa = na;
+        wb = nb;
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+    __syncthreads();
+    for (int dd = lane; dd < D; dd += 64) {
+        const int sy = sh_sym[dd];
+        const int64_t oo = (int64_t)b * D + dd;
+        sym_out[oo] = sy;
+        if (centres) centre_out[oo] = (float)centres[(int64_t)dd * c_stride + sy];
+    }
+}
+
+// any K / any alignment (reference layout ld = K+1): scalar strided loads, no prefetch
+__global__ __launch_bounds__(64) void k_rans_pop_generic(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
+                                                         int32_t* __restrict__ len, int64_t cap,
+                                                         const uint32_t* __restrict__ cdf, int64_t chain_stride,
+                                                         int64_t ld, int D, int K, int bits,
+                                                         int32_t* __restrict__ sym_out,
+                                                         const double* __restrict__ centres, int64_t c_stride,
+                                                         float* __restrict__ centre_out,
+                                                         int32_t* __restrict__ status) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[b] != BS_ST_OK) {
+        for (int dd = lane; dd < D; dd += 64) {
+            sym_out[(int64_t)b * D + dd] = 0;
+            if (centres) centre_out[(int64_t)b * D + dd] = 0.0f;
+        }
+        return;
+    }
+    uint64_t h = head[b];
+    int n = len[b];
+    const uint32_t* stk = stack + (int64_t)b * cap;
+    const uint32_t* tab = cdf + (int64_t)b * chain_stride;
+    const uint64_t mask = (1ull << bits) - 1;
+    int st = BS_ST_OK;
+    for (int d = D - 1; d >= 0; --d) {
+        const uint32_t* row = tab + (int64_t)d * ld;
+        const uint32_t m = (uint32_t)(h & mask);
+        int cnt = 0;
+        for (int j0 = 0; j0 < K; j0 += 64) {
+            const int j = j0 + lane;
+            const bool le = (j < K) && (row[j] <= m);
+            cnt += __popcll(__ballot(le));
+        }
+        const int s = cnt - 1;
+        const uint32_t cs = row[s];
+        const uint32_t cs1 = row[s + 1];
+        const uint64_t f = (uint64_t)(cs1 - cs);
+        h = f * (h >> bits) + (uint64_t)(m - cs);
+        if (h < (1ull << 32)) {
+            if (n <= 0) { st = BS_ST_UNDERFLOW; break; }
+            h = (h << 32) | (uint64_t)stk[--n];
+        }
+        if (lane == 0) {
+            const int64_t o = (int64_t)b * D + d;
+            sym_out[o] = s;
+            if (centres) centre_out[o] = (float)centres[(int64_t)d * c_stride + s];
+        }
+    }
+    if (lane == 0) {
+        head[b] = h;
+        len[b] = n;
+        if (st != BS_ST_OK) status[b] = st;
+    }
+}
+
+}  // namespace
+
+template <typename PT>
+int dispatch_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* piv, int64_t ld,
+                       const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale, int B,
+                       int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres, int64_t c_stride,
+                       float* centre_out, int32_t* status, hipStream_t st) {
+    dim3 grid(B), block(64);
+    const PT* m = static_cast<const PT*>(mu);
+    const PT* s = static_cast<const PT*>(scale);
+#define BS_POPP(NPL, PF)                                                                                              \
+    hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, endpoints, \
+                       e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status)
+    if (K == 256) BS_POPP(4, BS_POP_PF);
+    else if (K == 512) BS_POPP(8, BS_POP_PF);
+    else if (K == 1024) BS_POPP(16, BS_POP_PF);
+    else if (K == 2048) BS_POPP(32, BS_POP_PF);
+    else return BS_EUNSUPPORTED;
+#undef BS_POPP
+    return launch_rc();
+}
+
+extern "C" {
+
+int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* cdf, int64_t chain_stride,
+                int64_t ld, int layout, int B, int D, int K, int bits, int32_t* sym_out, const double* centres,
+                int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
+    if (!head || !stack || !len || !cdf || !sym_out || !status || B < 0 || D < 0 || cap < 0 || K < 1 ||
+        chain_stride < 0 || bits < 1 || bits > 31 || (centres && !centre_out) || c_stride < 0)
+        return BS_EINVAL;
+    if (layout == BS_LAYOUT_LINEAR ? ld < K + 1 : (layout != BS_LAYOUT_WAVE || ld < K + 64)) return BS_EINVAL;
+    if (B == 0 || D == 0) return BS_OK;
+    hipStream_t st = S(stream);
+    // fast paths: 16-byte aligned rows, whole 64-row chunks, symbols of one chain fit in LDS
+    const bool fast = aligned16(cdf) && (ld % 4 == 0) && (chain_stride % 4 == 0) && (D % 64 == 0) && (D <= 16384);
+    dim3 grid(B), block(64);
+#define BS_POP(ROW, PF)                                                                                          \
+    hipLaunchKernelGGL((k_rans_pop<ROW, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, cdf,        \
+                       chain_stride, ld, D, bits, sym_out, centres, c_stride, centre_out, status)
+    if (layout == BS_LAYOUT_WAVE) {
+        if (!fast) return BS_EINVAL;  // the wave layout only exists for the fast path
+        if ((int64_t)D * ld * 4 >= (1ll << 31)) return BS_EINVAL;  // one chain's rows must fit a 32-bit buffer offset
+#define BS_POPW(NR, PF)                                                                                          \
+    hipLaunchKernelGGL((k_rans_pop_wave<NR, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, cdf,    \
+                       chain_stride, ld, D, bits, sym_out, centres, c_stride, centre_out, status)
+        if (K == 256) BS_POPW(4, 32);
+        else if (K == 512) BS_POPW(8, 16);
+        else if (K == 1024) BS_POPW(16, 8);
+        else if (K == 2048) BS_POPW(32, 8);
+        else return BS_EUNSUPPORTED;
+#undef BS_POPW
+    } else if (fast && K == 256) BS_POP(RowRegs<1>, 8);
+    else if (fast && K == 512) BS_POP(RowRegs<2>, 8);
+    else if (fast && K == 1024) BS_POP(RowRegs<4>, 8);
+    else if (fast && K == 2048) BS_POP(RowRegs<8>, 4);
+    else
+        hipLaunchKernelGGL(k_rans_pop_generic, grid, block, 0, st, head, stack, len, cap, cdf, chain_stride, ld, D, K,
+                           bits, sym_out, centres, c_stride, centre_out, status);
+#undef BS_POP
+    return launch_rc();
+}
+
+int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* pivots, int64_t ld,
+                      const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu, const void* scale,
+                      int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres,
+                      int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
+    if (!head || !stack || !len || !pivots || !endpoints || !bin_step || !mu || !scale || !sym_out || !status || B < 0 ||
+        D < 0 || cap < 0 || bits < 1 || bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || c_stride < 0 ||
+        (centres && !centre_out) || ld < 128 || ld % 2 || (reinterpret_cast<uintptr_t>(pivots) & 7u))
+        return BS_EINVAL;
+    if (D % 64 != 0 || D > 16384) return BS_EUNSUPPORTED;      // whole 64-symbol chunks; a chain's symbols fit in LDS
+    if (B == 0 || D == 0) return BS_OK;
+    if (param_dtype == BS_PARAM_F32)
+        return dispatch_pop_pivot<float>(head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
+                                         bits, quantbits, sym_out, centres, c_stride, centre_out, status, S(stream));
+    if (param_dtype == BS_PARAM_F64)
+        return dispatch_pop_pivot<double>(head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
+                                          bits, quantbits, sym_out, centres, c_stride, centre_out, status, S(stream));
+    return BS_EINVAL;
+}
+
+}  // extern "C"

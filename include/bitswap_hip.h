@@ -221,9 +221,13 @@ int bs_selftest(int64_t* failures_host, void* stream);
 int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
 
 /*
- * Conv-stack epilogues (bitswap_amd/csrc/net_epilogue.hip).  The convolutions of Model.infer /
- * Model.generate (model/mnist_train.py:315-438) remain MIOpen calls; these two entry points replace
- * the pointwise launches between them.  NCHW float32, contiguous; N images, C channels, HW pixels.
+ * Conv-stack kernels (bitswap_amd/csrc/net_epilogue.hip, wino_gemm.hip).  Since round 3 NO convolution of Model.infer /
+ * Model.generate (model/mnist_train.py:315-438) in compress mode is a library call: the ResNet, head and 5x5 input
+ * convolutions run in the Winograd domain (bs_wino_fused_f32 transform passes around ONE batched fp32 MFMA product,
+ * bs_wino_gemm_f32 / bs_small_k_gemm_f32), the 3x3 input convolutions in bs_conv3_wino_f32 -- every output summed in
+ * one fixed order, so (mu, scale) do not depend on how many chains are coded per call.  The two entry points below are the
+ * pointwise passes of the unfused fallback routes (narrow test models, BITSWAP_OWN_GEMM=0).
+ * NCHW float32, contiguous; N images, C channels, HW pixels.
  *
  * bs_bias_residual_elu_f32 -- s = x + bias[c] (+ res); sum_out = s (nullable); act_out = ELU(s)
  *   (nullable; at least one output).  Covers `act(conv(x))` of the input convs and

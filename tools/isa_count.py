@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction mix of one kernel in a hipcc -S listing (which kernels are issue-bound and by what).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only -o /tmp/x.s bitswap_amd/csrc/bitswap_hip.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only -o /tmp/x.s bitswap_amd/csrc/tables.hip   (or pop.hip, push.hip, layer64.hip)
     python tools/isa_count.py /tmp/x.s k_logisticILi16EfLi3ELb1E [more substrings of mangled names ...]
 """
 import sys
