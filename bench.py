@@ -560,7 +560,7 @@ def extra_in_child(args, spec, steps, warmup):
         cmd += ["--chains", str(spec["chains"])]
     if spec.get("regime"):
         cmd += ["--regime", spec["regime"]]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, **spec.get("env", {})))
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not lines:
         raise RuntimeError((r.stderr or r.stdout)[-400:])
@@ -574,7 +574,7 @@ def extra_in_child(args, spec, steps, warmup):
             "value": round(d["value"], 1), "ms_per_step": round(d["ms_per_step"], 3), "lossless": d["lossless"],
             "bits_per_dim": round(d["bits_per_dim"], 4), "stream_format": spec.get("format", "reference"),
             "regime": spec.get("regime") or "random-init weights, unrelated synthetic blocks",
-            "forked_block_step": d["config"].get("forked_block_step"),
+            "forked_block_step": d["config"].get("forked_block_step"), "conv_dtype": d["config"].get("conv_dtype"),
             "stream_time_fraction": d.get("stream_time_fraction"), "stream_gather": d.get("stream_gather"), "roofline": None,
             "process": "own process (python bench.py --no-extra ...), like the headline"}
 
@@ -591,6 +591,9 @@ EXTRAS = (
     dict(workload="imagenet4", chains=13, groups=1, bitswap=0, why="configs[4]: one GPU's share (13 of 100 chains) on 8 GPUs"),
     dict(workload="imagenetcrop4", chains=13, scaling="strong", steps=16, why="configs[3]: one GPU's share (13 of 100 images) on 8 GPUs"),
     dict(workload="cifar8", chains=1000, groups=2, regime="lowrate", why="peaked tables: a trained model's rate"),
+    dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_GEMM_ARITH": "bf16x3"},
+         why="OPT-IN conv arithmetic, not the headline: the ResNet products as three bf16 limbs per float32 operand, 6 limb products "
+             "per k block on the bf16 matrix cores, float32 accumulate (bs_wino_gemm_bf16x3; error table: profiles/r04_bf16x3_error.json)"),
     dict(workload="cifar8", chains=800, groups=2, format="wave64", why="opt-in 64-state format"),
     dict(workload="cifar8", chains=13, groups=1, format="wave64", why="opt-in 64-state format, few chains"),
 )
@@ -653,6 +656,10 @@ def main(args):
                  f"{'Winograd domain (bs_small_k_gemm_f32)' if getattr(model, 'wino_in5', False) else 'MIOpen'})"
                  if getattr(model, "fused", False) else "torch modules")
     Z, X = codec.Z, codec.X
+    arith = getattr(model, "gemm_arith", "fp32") if getattr(model, "_ufrags", None) else "fp32"
+    if arith != "fp32":
+        conv_path = conv_path.replace("(fp32;", f"(float32 activations and weights, OPT-IN {arith} arithmetic in the ResNet products: "
+                                      "three bf16 limbs per operand on the bf16 matrix cores, float32 accumulate;")
     forked = bool(sum(c.forked_steps for c in getattr(codec, "codecs", [codec])))
     del codec, model
 
@@ -689,7 +696,7 @@ def main(args):
         "config": {"workload": config_title(name, args, strong),
                    "chains_per_gpu": r["chains_per_gpu"], "chain_groups": r["chain_groups"], "blocks_per_chain": args.steps,
                    "quantbits": args.quantbits, "ansbits": 31, "cdf_spec": args.cdf_spec, "stream_format": args.format,
-                   "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32", "conv_path": conv_path,
+                   "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32" if arith == "fp32" else arith, "conv_path": conv_path,
                    "forked_block_step": forked,
                    "weights": "seeded random init (no checkpoints offline)"
                               + (", calibrated to the low-rate regime (workload.calibrate_lowrate)" if args.regime else "")},

@@ -9,7 +9,7 @@ SRC = os.path.join(HERE, "csrc", "bitswap_hip.hip")
 # one translation unit per kernel family (round 4: the 1,850-line bitswap_hip.hip with ~100 template instantiations took
 # 20 s on one core; the units compile in parallel) around the shared device helpers of csrc/bitswap_dev.h
 SRCS = [os.path.join(HERE, "csrc", f) for f in ("bitswap_hip.hip", "tables.hip", "pop.hip", "push.hip", "layer64.hip",
-                                                 "net_epilogue.hip", "wino_gemm.hip")]
+                                                 "net_epilogue.hip", "wino_gemm.hip", "wino_gemm_bf16x3.hip")]
 HDR = os.path.join(HERE, "..", "include", "bitswap_hip.h")
 DEV_HDR = os.path.join(HERE, "csrc", "bitswap_dev.h")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")

@@ -10,7 +10,7 @@ import torch
 
 from . import build as _build
 
-ABI_VERSION = 4   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
+ABI_VERSION = 5   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
 PARAM_F32, PARAM_F64 = 0, 1
@@ -21,7 +21,7 @@ SYMBOLS = [
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_rans_pop_pivot", "bs_gather_centres", "bs_layer_pop64",
     "bs_layer_push64",
     "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
-    "bs_small_k_gemm_f32", "bs_conv3_wino_f32", "bs_wino_gemm_f32",
+    "bs_small_k_gemm_f32", "bs_conv3_wino_f32", "bs_wino_gemm_f32", "bs_wino_gemm_bf16x3",
 ]
 HEAD_SIGMOID, HEAD_SOFTPLUS = 0, 1
 
@@ -73,6 +73,7 @@ def load():
     L.bs_wino_in_f32.argtypes = [p, p, p, i64, i32, i32, i32, i32, i32, i32, p]
     L.bs_small_k_gemm_f32.argtypes = [p, p, p, i32, i32, i32, i64, p]
     L.bs_wino_gemm_f32.argtypes = [p, p, p, i32, i32, i32, i64, p]
+    L.bs_wino_gemm_bf16x3.argtypes = [p, p, p, i32, i32, i32, i64, i32, p]
     L.bs_conv3_wino_f32.argtypes = [p, p, p, i32, p, p, i32, i64, i32, i32, i32, i32, p]
     L.bs_wino_out_f32.argtypes = [p, p, p, p, p, i64, i32, i32, i32, i32, i32, p]
     for n in SYMBOLS:
@@ -635,6 +636,52 @@ def wino_gemm(U, V, out=None):
     M = out if out is not None else torch.empty((T, Cout, cols), dtype=torch.float32, device=V.device)
     assert M.is_contiguous() and tuple(M.shape) == (T, Cout, cols) and M.dtype == torch.float32
     _check(load().bs_wino_gemm_f32(_ptr(U), _ptr(V), _ptr(M), T, Cout, Cin, cols, _stream()), "bs_wino_gemm_f32")
+    return M
+
+
+def split_bf16x3(U):
+    """U float32 -> limbs [3, *U.shape] bfloat16 with U == limbs[0] + limbs[1] + limbs[2] exactly (round-to-nearest split:
+    3 x 8 significand bits cover the 24 of float32)."""
+    assert U.dtype == torch.float32
+    x0 = U.to(torch.bfloat16)
+    r1 = U - x0.float()
+    x1 = r1.to(torch.bfloat16)
+    r2 = r1 - x1.float()
+    x2 = r2.to(torch.bfloat16)
+    return torch.stack([x0, x1, x2], 0).contiguous()
+
+
+def frags_bf16x3(U):
+    """The weight operand bs_wino_gemm_bf16x3 takes: U [T, Cout, Cin] float32 split into its three bfloat16 limbs and
+    pre-tiled as MFMA A fragments, [T, ceil(Cout/32), Cin/16, 3, 64, 8] -- lane l = 32 (k // 8) + row of a 32-row tile holds 8
+    consecutive k of a 16-deep block (include/bitswap_hip.h).  Rows beyond Cout are zero.  Done once per model (Model.fuse())."""
+    assert U.dtype == torch.float32 and U.dim() == 3 and U.shape[2] % 16 == 0
+    T, Cout, Cin = U.shape
+    pad = (-Cout) % 32
+    if pad:
+        U = torch.cat([U, U.new_zeros((T, pad, Cin))], 1)
+    L = split_bf16x3(U)                                              # [3, T, R, Cin]
+    R = Cout + pad
+    L = L.view(3, T, R // 32, 32, Cin // 16, 2, 8)                  # limb, t, row tile, row, k block, k half, k
+    L = L.permute(1, 2, 4, 0, 5, 3, 6).contiguous()                 # t, row tile, k block, limb, k half, row, k
+    out = L.view(T, R // 32, Cin // 16, 3, 64, 8)
+    out.bs_shape = (T, Cout, Cin)
+    return out
+
+
+def wino_gemm_bf16x3(Uf, V, nprod=6, out=None):
+    """M [T, Cout, cols] = U x V with U given as frags_bf16x3(U) and V [T, Cin, cols] float32 split in the kernel: nprod limb
+    products per k block on the bf16 matrix cores, float32 accumulation, one fixed order per output
+    (include/bitswap_hip.h, bs_wino_gemm_bf16x3).  Opt-in arithmetic."""
+    _need_cuda(Uf, V, out)
+    T, Cout, Cin = Uf.bs_shape
+    assert Uf.dtype == torch.bfloat16 and Uf.is_contiguous() and tuple(Uf.shape) == (T, (Cout + 31) // 32, Cin // 16, 3, 64, 8)
+    assert V.dtype == torch.float32 and V.dim() == 3 and V.is_contiguous()
+    assert V.shape[0] == T and V.shape[1] == Cin and V.shape[2] % 4 == 0
+    cols = V.shape[2]
+    M = out if out is not None else torch.empty((T, Cout, cols), dtype=torch.float32, device=V.device)
+    assert M.is_contiguous() and tuple(M.shape) == (T, Cout, cols) and M.dtype == torch.float32
+    _check(load().bs_wino_gemm_bf16x3(_ptr(Uf), _ptr(V), _ptr(M), T, Cout, Cin, cols, int(nprod), _stream()), "bs_wino_gemm_bf16x3")
     return M
 
 

@@ -32,6 +32,9 @@ def route(model):
         r.update({"conv_algo": model.conv_algo, "wino_inputs": bool(model.wino_inputs), "wino_in5": bool(model.wino_in5),
                   "fused_inputs": bool(model.fused_inputs), "pad_channels": bool(model.pad_channels),
                   "gemm": "own" if own else f"blas:{model.gemm_backend}", "gemm_min_batch": int(model.gemm_min_batch)})
+        arith = getattr(model, "gemm_arith", "fp32")
+        if own and arith != "fp32":      # opt-in arithmetic of the big products (bs_wino_gemm_bf16x3): other float32 bits
+            r["gemm_arith"] = arith
     return r
 
 

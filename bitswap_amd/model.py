@@ -258,6 +258,16 @@ class Model(nn.Module):
         # made a stream decodable only with the sender's chains-per-call).  BITSWAP_OWN_GEMM=0 restores the library for
         # experiments; the choice is part of the stream fingerprint (route_fingerprint()).
         self.own_gemm = os.environ.get("BITSWAP_OWN_GEMM", "1") == "1"
+        # arithmetic of those products.  "fp32" (default): v_mfma_f32_32x32x2_f32, float32 in, float32 accumulate.  OPT-IN
+        # "bf16x3" / "bf16x3x9" (round 4): every float32 operand split exactly into three bfloat16 limbs, the
+        # product assembled from 6 / 9 limb products per k block on the bf16 matrix cores (bs_wino_gemm_bf16x3), float32
+        # accumulate, one fixed order per output -- batch-invariant like the fp32 kernel, but a different rounding of
+        # (mu, scale): its own conv route in the stream fingerprint, never the default.  Taken for the products with at
+        # least 128 output channels (the ResNet convolutions: 96 of the 130 products of a block step and ~95 % of their
+        # flops); the 16- / 24-channel head products stay on the fp32 kernel.
+        self.gemm_arith = os.environ.get("BITSWAP_GEMM_ARITH", "fp32")
+        assert self.gemm_arith in ("fp32", "bf16x3", "bf16x3x9"), self.gemm_arith
+        self._ufrags = {}
         self._cp = reswidth
         self.gemm_min_batch = int(os.environ.get("BITSWAP_GEMM_MIN_BATCH", "1"))
         # torch.backends.cuda.preferred_blas_library for the Winograd-domain GEMMs ("" = torch's default)
@@ -318,7 +328,7 @@ class Model(nn.Module):
     # ----------------------------------------------------------------------------------------
     def load_state_dict(self, *a, **k):
         """New weights invalidate everything derived from the old ones: call fold()/fuse() again."""
-        self.fused, self._heads, self._heads_u, self._gen_mu_u = False, {}, {}, None
+        self.fused, self._heads, self._heads_u, self._gen_mu_u, self._ufrags = False, {}, {}, None, {}
         return super().load_state_dict(*a, **k)
 
     def compress(self, compress=True):
@@ -410,6 +420,14 @@ class Model(nn.Module):
                     # 5x5 as five GEMMs (one per kernel row), the alternative path: W_dy [Cout, Cin*5]
                     if isinstance(m, WnConv2d) and m.kernel_size == 5 and m.in_dim == m.out_dim and m.stride == 1:
                         m._w5 = [m._w[:, :, dy, :].reshape(m.out_dim, m.in_dim * 5).contiguous() for dy in range(5)]
+                # opt-in bf16x3 arithmetic: the weights' limbs, split and tiled as MFMA fragments once
+                self._ufrags = {}
+                if self.gemm_arith != "fp32" and self.own_gemm:
+                    from . import hip as _hip
+                    for m in self.modules():
+                        u = getattr(m, "_wu", None)
+                        if isinstance(m, WnConv2d) and u is not None and u.is_cuda and u.shape[1] >= 128 and u.shape[2] % 16 == 0:
+                            self._ufrags[u.data_ptr()] = _hip.frags_bf16x3(u)
         return self
 
     @staticmethod
@@ -529,6 +547,9 @@ class Model(nn.Module):
         library (narrow test models) -- a property of the model, never of the call."""
         from . import hip
         if self.own_gemm and hip.wino_gemm_supported(U, V):
+            uf = self._ufrags.get(U.data_ptr()) if self._ufrags else None
+            if uf is not None:
+                return hip.wino_gemm_bf16x3(uf, V, 9 if self.gemm_arith == "bf16x3x9" else 6)
             return hip.wino_gemm(U, V)
         return torch.bmm(U, V)
 

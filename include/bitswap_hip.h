@@ -41,7 +41,7 @@ extern "C" {
 /* 2: layout argument, BS_LAYOUT_WAVE pivot words, conv-stack epilogue entry points
  * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop64 / _push64
  * 4: BS_LAYOUT_PIVOT and bs_rans_pop_pivot (64 cumulative values per row instead of the whole row) */
-#define BS_ABI_VERSION 4
+#define BS_ABI_VERSION 5
 /* highest version of the deterministic logistic-CDF specification this library implements;
  * a stream written with one CDF spec can only be decoded with the same one.
  *   spec 1: one float64 sigmoid per bin endpoint (bin_step == NULL); any bins.
@@ -279,6 +279,17 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *   every product of the conv stacks takes it, the 16-channel head convolutions included.  Cin % 16 == 0, cols % 4 == 0,
  *   Cin * cols < 2^31, 16-byte aligned operands (BS_EUNSUPPORTED / BS_EINVAL otherwise).
  *
+ * bs_wino_gemm_bf16x3 -- the same product with every float32 operand split exactly into three bfloat16 limbs and assembled
+ *   from nprod = 6 (limb products down to relative size 2^-16; the three of size 2^-24 dropped) or 9 (all: every product
+ *   exact) v_mfma_f32_32x32x16_bf16 per 16-deep k block, float32 accumulation, one fixed order per output that depends on
+ *   Cin alone (bitswap_amd/csrc/wino_gemm_bf16x3.hip).  U_frags [T, ceil(Cout/32), Cin/16, 3, 64, 8] bfloat16 bit patterns:
+ *   the three limbs of U (U = limb0 + limb1 + limb2 exactly), split and tiled once by the caller as MFMA A fragments --
+ *   entry [t, r, kb, i, l, e] = limb i of U[t, 32 r + l % 32, 16 kb + 8 (l / 32) + e], rows beyond Cout zero
+ *   (bitswap_amd.hip.frags_bf16x3); V float32 as above, split in registers.  OPT-IN
+ *   (BITSWAP_GEMM_ARITH): a different rounding of (mu, scale) than bs_wino_gemm_f32, hence its own conv route in the stream
+ *   fingerprint -- sender and receiver must both take it.  No reference counterpart (the reference's convolutions are cuDNN
+ *   float32, utils/torch/modules.py:233-241).  Cin % 16 == 0, cols % 4 == 0, 16-byte aligned operands.
+ *
  * bs_small_k_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols] for small Cin (<= 64): the batched product
  *   of the INPUT convolutions of the stacks in the Winograd domain (Cin = zchannels or 4 x image channels); a write of M
  *   with a dozen multiply-adds per element.  cols % 4 == 0, 16-byte aligned operands.
@@ -292,6 +303,8 @@ int bs_head_params_f32(const float* x, const float* bias, float* mu, float* scal
 int bs_expand_rows5_f32(const float* in, const float* bias, float* out, int64_t N, int C, int H, int W,
                         int act, void* stream);
 int bs_wino_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream);
+int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, float* M, int T, int Cout, int Cin, int64_t cols,
+                        int nprod, void* stream);
 int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act, float* act_out, float* V, int ts_out,
                       int64_t N, int Cin, int C, int H, int W, void* stream);
 int bs_small_k_gemm_f32(const float* U, const float* V, float* M, int T, int Cout, int Cin, int64_t cols, void* stream);
