@@ -432,6 +432,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restric
         u = unext;
         cur = nxt;
     }
+    // the range's last K steps issue a redundant DMA (branch-free pipelining): it must have landed before this workgroup's LDS
+    // is handed to the next one on the CU (round 4: bs_wino_gemm_bf16x3 decoded garbage beside other kernels until it waited)
+    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0)
 }
 
 int cu_count() {

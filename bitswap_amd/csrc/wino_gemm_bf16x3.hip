@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/bitswap_hip.h"
 
 namespace {
@@ -40,7 +42,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // coalesced global loads, one step ahead, straight into registers -- no other wavefront needs them.  Only V goes through
 // LDS (every wavefront multiplies all 256 columns): a [16 k][256] float32 stage of 16 KB, double buffered, filled by LDS-DMA.
 constexpr int X_BM = 256, X_BN = 256, X_BK = 16, X_NT = 256;
-constexpr int X_STAGE = X_BK * X_BN * 4;                  // 16 KB
+constexpr int X_STAGE = X_BK * X_BN * 4;                  // 16 KB; three stages per workgroup
 
 union Pack8 {
     u32x4 u;
@@ -54,11 +56,25 @@ template <int NPROD, int LAB = 0>     // LAB != 0: timing experiments with WRONG
 __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
                                                               float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                               int ncc, int nrt) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][X_STAGE]
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [3][X_STAGE]
+    // The wavefront claims the WHOLE register file of its SIMD (256 architectural + 256 accumulation registers).  It needs
+    // 436 / 444 of the 512; allocated as 440 (NPROD = 6), a 72-register wavefront of another kernel fits beside it -- and with
+    // one there (k_logistic<4> or k_wino_fused of the other stream, round 4 visit K) this kernel's products came out wrong:
+    // the forked and the two-group codecs decoded garbage, while the kernel alone, beside other launches in a stress loop
+    // (tools/bf16x3_stress.py), with one hardware queue, or with 448 registers (NPROD = 9) was bit-exact every time.  With
+    // nothing beside it: lossless 6 / 6.  Cause not established (LABNOTES.md); occupancy is one by design, so this costs
+    // nothing but the co-residency of small wavefronts on these SIMDs.
+    asm volatile("" ::: "v255");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;
-    // chunk of this workgroup: (t, row tile, 256-column chunk); consecutive workgroups share t and the row tile (U in L2)
-    const int wg = blockIdx.x;
+    // chunk of this workgroup: (t, row tile, 256-column chunk).  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8),
+    // each XCD with an L2 of its own: XCD x takes the x-th contiguous eighth of the chunk list, so the workgroups that share
+    // an L2 work through the same few t one after the other and the limbs of U[t] (393 KB at 256 x 256) are fetched from HBM
+    // once per XCD instead of once per workgroup (visit H: with consecutive chunks on consecutive XCDs every XCD touched all
+    // 36 U[t], 14 MB against 4 MB of L2, and the launch moved 1 GB).
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
     const int t = wg / (nrt * ncc), rem = wg - t * (nrt * ncc), rt = rem / ncc, cc = rem - rt * ncc;
     const int co0 = rt * X_BM;
     const int64_t c0 = (int64_t)cc * X_BN;
@@ -121,27 +137,35 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
         for (int kk = 0; kk < 8; ++kk) raw[h][kk] = *reinterpret_cast<const f32x4*>(Bs + kk * X_BN);
     };
     auto split_group = [&](int h) {                  // truncation split into three bf16 limbs: exact
+        // Stage by stage over the 8 k of a tile, not float by float: the four operations of one float form a dependent chain
+        // (and, subtract, and, subtract), and a lone wavefront pays the full VALU latency for every dependent instruction --
+        // written float by float the split did not hide under the MFMAs at all (visit H: 5700 cycles per K step with NO memory
+        // instruction in the loop, 3072 of them MFMA).  Eight independent chains side by side issue back to back.
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            Pack8 p0, p1, p2;
+            uint32_t u0[8], u1[8];
+            float r1[8], r2[8];
 #pragma unroll
-            for (int kp = 0; kp < 4; ++kp) {
-                uint32_t w0[2], w1[2], w2[2];
+            for (int e = 0; e < 8; ++e) u0[e] = __float_as_uint(raw[h][e][ni]) & 0xffff0000u;
+            if (LAB & 1) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float x = raw[h][2 * kp + e][ni];
-                    if (LAB & 1) { w0[e] = w1[e] = w2[e] = __float_as_uint(x); continue; }      // (no split arithmetic)
-                    const uint32_t u0 = __float_as_uint(x) & 0xffff0000u;
-                    const float r1 = x - __uint_as_float(u0);
-                    const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
-                    const float r2 = r1 - __uint_as_float(u1);
-                    w0[e] = u0, w1[e] = u1, w2[e] = __float_as_uint(r2);
-                }
-                // bf16 pair: low half = even k, high half = odd k (the top 16 bits of each float32 word)
-                p0.u[kp] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
-                p1.u[kp] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u);
-                p2.u[kp] = __builtin_amdgcn_perm(w2[1], w2[0], 0x07060302u);
+                for (int e = 0; e < 8; ++e) u1[e] = u0[e], r2[e] = raw[h][e][ni];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r1[e] = raw[h][e][ni] - __uint_as_float(u0[e]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u1[e] = __float_as_uint(r1[e]) & 0xffff0000u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(u1[e]);
             }
+            Pack8 p0, p1, p2;
+            // bf16 pair: low half = even k, high half = odd k (the top 16 bits of each float32 word)
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p0.u[kp] = __builtin_amdgcn_perm(u0[2 * kp + 1], u0[2 * kp], 0x07060302u);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p1.u[kp] = __builtin_amdgcn_perm(u1[2 * kp + 1], u1[2 * kp], 0x07060302u);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p2.u[kp] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * kp + 1]), __float_as_uint(r2[2 * kp]), 0x07060302u);
             b[h][ni][0] = p0.b, b[h][ni][1] = p1.b, b[h][ni][2] = p2.b;
         }
     };
@@ -163,39 +187,87 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
         }
     };
 
+    // ---- operands run ahead of the multiplies (visit H: with one step of prefetch and vmcnt(0) barriers a step took 7000
+    // cycles -- 3072 of MFMA plus a memory wait that nothing covered: one wavefront per SIMD has no partner to hide behind, and
+    // the launch moves 1 GB through L2 and HBM, ~4000 cycles per step and CU at the rate the chip sustains).
+    //   V: three LDS stages, the DMA of stage k + 3 issued at the barrier of step k (two steps of flight);
+    //   U: the fragments of step k + 1 requested at the top of step k by INLINE-ASM loads, so that the wait is ours to place
+    //      (hipcc's own s_waitcnt for a register load in a loop is vmcnt(0), which would also wait for the DMA just issued).
+    // Counted waits, per wavefront in issue order  top(s): 6 fragment loads of step s + 1 | mid(s): 4 DMA of stage s + 3:
+    //   barrier of step k needs stage k + 1: all but the newest 10 (4 DMA of stage k + 2, 6 loads of step k + 1) -> vmcnt(10)
+    //   end of step k needs the fragments of step k + 1: all but the newest 4 (DMA of stage k + 3)              -> vmcnt(4)
+    // The last three steps issue no DMA and use vmcnt(0).
+    auto load_a_async = [&](bf16x8 (&dst)[2][3], int kb) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                const uint16_t* src = a_base[mi] + ((int64_t)kb * 3 + i) * 64 * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(p.u) : "v"(src) : "memory");
+                dst[mi][i] = p.b;
+            }
+    };
+    auto landed = [&](bf16x8 (&x)[2][3]) {                                 // ties later uses to this point (after our s_waitcnt)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                p.b = x[mi][i];
+                asm volatile("" : "+v"(p.u));
+                x[mi][i] = p.b;
+            }
+    };
+    auto stage_of = [&](int st_idx) -> const char* { return lds + (st_idx % 3) * X_STAGE; };
     load_stage(0, 0);
-    load_a(a, 0);
-    __syncthreads();
-    load_stage(min(1, nk - 1) * X_BK, 1);
+    load_a_async(a, 0);
+    if (nk > 1) load_stage(X_BK, 1);
+    if (nk > 2) load_stage(2 * X_BK, 2);
+    __syncthreads();                                                      // (vmcnt(0): everything above has landed)
+    landed(a);
     read_b(lds, 0);
     read_b(lds, 1);
     split_group(0);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K step; DMA = false for the last three (nothing left to fetch).  No branch inside: a branch would end the scheduling
+    // region the interleaving lives in, so past the last stage the LDS reads and the split simply work on a stale stage
+    // whose limbs are never multiplied.  A workgroup never leaves with an LDS-DMA in flight (the write would land in the LDS
+    // of whatever workgroup the CU runs next).
+    auto step = [&](int kt, auto dma) {
         __builtin_amdgcn_sched_barrier(0);
-        load_a(an, min(kt + 1, nk - 1));                                  // next step's fragments: a whole step to arrive
+        if (!(LAB & 4)) load_a_async(an, min(kt + 1, nk - 1));            // fragments of step kt + 1
         products(0);
         split_group(1);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                                                  // stage kt + 1 landed; stage kt is in registers everywhere
-        const char* nx = lds + (buf ^ 1) * X_STAGE;
-        // branch-free (a branch would end the scheduling region the interleaving lives in): past the last stage this is a
-        // harmless reload into a buffer nobody reads, and the reads / the split below work on a stale stage whose limbs are
-        // never multiplied
-        load_stage(min(kt + 2, nk - 1) * X_BK, buf);                     // into the buffer stage kt lived in
+        if constexpr (decltype(dma)::value) {
+            __builtin_amdgcn_s_waitcnt(0x007A);                           // vmcnt(10), lgkmcnt(0): stage kt + 1 has landed
+            __builtin_amdgcn_s_barrier();                                 // ... in every wavefront; stage kt is in registers everywhere
+            if (!(LAB & 4)) load_stage((kt + 3) * X_BK, kt % 3);          // into the buffer stage kt lived in
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+        const char* nx = stage_of(kt + 1);
         read_b(nx, 0);
         products(1);
         split_group(0);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
         read_b(nx, 1);
+        if constexpr (decltype(dma)::value) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): the fragments of step kt + 1 are here
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
+        if (!(LAB & 4)) {
+            landed(an);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) a[mi][i] = an[mi][i];
-        buf ^= 1;
-    }
+                for (int i = 0; i < 3; ++i) a[mi][i] = an[mi][i];
+        }
+    };
+    int kt = 0;
+    for (; kt < nk - 3; ++kt) step(kt, std::true_type{});
+    for (; kt < nk; ++kt) step(kt, std::false_type{});
     // register v of lane l: row (v/4)*8 + (l/32)*4 + v%4 of the 32x32 tile, column l%32 -> chunk column 128 h + 4 (l%32) + ni
     float* Mt = M + (int64_t)t * Cout * cols;
 #pragma unroll
@@ -216,6 +288,7 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0): nothing of this workgroup is in flight when its LDS is handed on
 }
 
 }  // namespace
@@ -230,11 +303,23 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     const int64_t wgs = (int64_t)T * nrt * ncc;
     if (wgs > 0x7fffffff || (int64_t)Cin * cols > 0x7fffffff) return BS_EUNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t shm = 2 * (size_t)X_STAGE;
+    size_t shm = 3 * (size_t)X_STAGE;
+    static const long lds_pad = [] { const char* e = getenv("BITSWAP_BF16X3_LDS_PAD"); return e ? atol(e) : 0L; }();   // diagnostics
+    shm += (size_t)lds_pad;
+    if (shm > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
 #ifdef BS_GEMM_LAB
     if (const char* e = getenv("BITSWAP_BF16X3_LAB")) {
         const int lab = atoi(e);
-        if (lab == 1) hipLaunchKernelGGL((k_wino_gemm_bf16x3<6, 1>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
+        if (lab == 4) hipLaunchKernelGGL((k_wino_gemm_bf16x3<6, 4>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
+        else if (lab == 6) hipLaunchKernelGGL((k_wino_gemm_bf16x3<6, 6>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
+        else if (lab == 1) hipLaunchKernelGGL((k_wino_gemm_bf16x3<6, 1>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
         else if (lab == 2) hipLaunchKernelGGL((k_wino_gemm_bf16x3<6, 2>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
         else hipLaunchKernelGGL((k_wino_gemm_bf16x3<6, 3>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;

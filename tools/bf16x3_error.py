@@ -32,6 +32,7 @@ def main():
     ref = copy.deepcopy(base).double()
     ref.fused = False
     ref.fold()
+    ref.compress(False)          # (compress mode casts its input to float32: call the stacks directly)
     N = 32
     g = torch.Generator().manual_seed(5)
     rows = []
@@ -41,8 +42,9 @@ def main():
         for kind in ("infer", "generate"):
             inp = x if (kind == "infer" and i == 0) else z
             with torch.no_grad():
-                mu64, sc64 = getattr(ref, kind)(i)(inp.double())
-                sc64 = sc64.expand_as(mu64)
+                h64 = inp.double().view((-1,) + (ref.xs if (kind == "infer" and i == 0) else ref.zdim))
+                mu64, sc64 = (ref._infer_stack if kind == "infer" else ref._gen_stack)(i, h64)
+                mu64, sc64 = mu64.reshape(N, -1), sc64.expand_as(mu64).reshape(N, -1)
                 rng = float(mu64.abs().max())
                 row = {"stack": f"{kind}({i})", "mu_range": rng}
                 outs = {}

@@ -3,7 +3,7 @@
 OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 export BITSWAP_HIP_LIB=/tmp/libbitswap_lab.so BITSWAP_HIPCC_EXTRA=-DBS_GEMM_LAB
 python -m bitswap_amd.build > /dev/null 2>&1
-for lab in "" 1 2 3; do
+for lab in "" 4 1; do
   BITSWAP_BF16X3_LAB=$lab python - <<'PY'
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
