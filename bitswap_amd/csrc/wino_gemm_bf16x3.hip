@@ -291,6 +291,178 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
     __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0): nothing of this workgroup is in flight when its LDS is handed on
 }
 
+
+// ---- the two-wavefronts-per-SIMD shape: 256 rows x 128 columns per workgroup (4 wavefronts of 64 x 128 = 2 x 4 MFMA tiles, 128
+// accumulator registers in the architectural file, <= 256 registers per lane), TWO workgroups per CU.  Why: inside ONE
+// wavefront nothing hides under an MFMA on this chip the way the split needs it -- visit H, no memory instruction in the K
+// loop: 96 MFMAs + 450 other instructions per step took the SUM of their issue times (48 cycles per MFMA group), interleaved
+// or not -- so the overlap has to come from a partner wavefront on the same SIMD: each wavefront alternates a VALU burst (the
+// split of two column tiles) with a burst of 4 NPROD back-to-back MFMAs, and while one splits the other multiplies.
+constexpr int Y_BN = 128, Y_STAGE = X_BK * Y_BN * 4;      // 8 KB per stage, three stages per workgroup
+
+template <int NPROD>
+__global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
+                                                                 float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
+                                                                 int ncc, int nrt) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [3][Y_STAGE]
+    asm volatile("" ::: "v255");                                 // the whole 256-register share of the SIMD (see k_wino_gemm_bf16x3)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, g = lane >> 5;
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);  // an XCD works through a contiguous eighth of the chunk list
+    const int t = wg / (nrt * ncc), rem = wg - t * (nrt * ncc), rt = rem / ncc, cc = rem - rt * ncc;
+    const int co0 = rt * X_BM;
+    const int64_t c0 = (int64_t)cc * Y_BN;
+    const int cols_left = (int)min((int64_t)Y_BN, cols - c0);
+    const int nk = Cin / X_BK, nrt32 = (Cout + 31) / 32;
+
+    const uint16_t* a_base[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r32 = min(co0 / 32 + wave * 2 + mi, nrt32 - 1);
+        a_base[mi] = Uf + (((int64_t)t * nrt32 + r32) * nk * 3 * 64 + lane) * 8;
+    }
+    bf16x8 a[2][3], b[2][3];
+    auto load_a_async = [&](int kb) {          // straight into `a`: every MFMA that reads the old fragments has been issued
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                const uint16_t* src = a_base[mi] + ((int64_t)kb * 3 + i) * 64 * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(p.u) : "v"(src) : "memory");
+                a[mi][i] = p.b;
+            }
+    };
+    auto landed_a = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                p.b = a[mi][i];
+                asm volatile("" : "+v"(p.u));
+                a[mi][i] = p.b;
+            }
+    };
+    // B: LDS-DMA granule q = tid + j * 256 (j = 0, 1): k = q >> 5, columns 4 (q & 31) ..; beyond the chunk: column 0
+    const float* b_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + j * X_NT, k = q >> 5, cg = (q & 31) * 4;
+        b_src[j] = V + ((int64_t)t * Cin + k) * cols + c0 + (cg < cols_left ? cg : 0);
+    }
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    auto load_stage = [&](int k0, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds(b_src[j] + (int64_t)k0 * cols, (lds_ptr_t)(lds + buf * Y_STAGE + (wbase + j * X_NT) * 16), 16, 0, 0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.0f;
+
+    f32x4 raw[8];                                  // this lane's 8 k (8 g ..) of columns 4 l32 .. + 3 (tile ni = column 4 l32 + ni)
+    auto read_b = [&](const char* st) {
+        const float* Bs = reinterpret_cast<const float*>(st) + (g * 8) * Y_BN + 4 * l32;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) raw[kk] = *reinterpret_cast<const f32x4*>(Bs + kk * Y_BN);
+    };
+    auto split_pair = [&](int h) {                 // tiles 2 h, 2 h + 1 -> b[0], b[1]: truncation split, exact
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            uint32_t u0[8], u1[8];
+            float r1[8], r2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u0[e] = __float_as_uint(raw[e][2 * h + ni]) & 0xffff0000u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r1[e] = raw[e][2 * h + ni] - __uint_as_float(u0[e]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u1[e] = __float_as_uint(r1[e]) & 0xffff0000u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(u1[e]);
+            Pack8 p0, p1, p2;
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p0.u[kp] = __builtin_amdgcn_perm(u0[2 * kp + 1], u0[2 * kp], 0x07060302u);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p1.u[kp] = __builtin_amdgcn_perm(u1[2 * kp + 1], u1[2 * kp], 0x07060302u);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p2.u[kp] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * kp + 1]), __float_as_uint(r2[2 * kp]), 0x07060302u);
+            b[ni][0] = p0.b, b[ni][1] = p1.b, b[ni][2] = p2.b;
+        }
+    };
+    auto products = [&](int h) {                   // back to back: limb-product index outermost, four accumulators in turn
+#pragma unroll
+        for (int p = 9 - NPROD; p < 9; ++p)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][2 * h + ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][X_ORDER9[p][0]], b[ni][X_ORDER9[p][1]],
+                                                                                  acc[mi][2 * h + ni], 0, 0, 0);
+    };
+    // per wavefront, in issue order:  end of step s: 6 fragment loads of step s + 1, then (after the barrier) 2 DMA of stage s + 3
+    //   top of step k needs the fragments of step k: all but the newest 2 (DMA of stage k + 2)                 -> vmcnt(2)
+    //   barrier of step k needs stage k + 1: all but the newest 8 (2 DMA of stage k + 2, 6 loads of step k + 1) -> vmcnt(8)
+    load_stage(0, 0);
+    if (nk > 1) load_stage(X_BK, 1);
+    if (nk > 2) load_stage(2 * X_BK, 2);
+    load_a_async(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    read_b(lds);
+    auto step = [&](int kt, auto dma) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(dma)::value) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): this step's fragments are here
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        landed_a();
+        split_pair(0);
+        __builtin_amdgcn_sched_barrier(0);
+        products(0);
+        __builtin_amdgcn_sched_barrier(0);
+        split_pair(1);
+        __builtin_amdgcn_sched_barrier(0);
+        products(1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a_async(min(kt + 1, nk - 1));
+        if constexpr (decltype(dma)::value) {
+            __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8), lgkmcnt(0): stage kt + 1 has landed
+            __builtin_amdgcn_s_barrier();
+            load_stage((kt + 3) * X_BK, kt % 3);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+        }
+        read_b(lds + ((kt + 1) % 3) * Y_STAGE);
+    };
+    int kt = 0;
+    for (; kt < nk - 3; ++kt) step(kt, std::true_type{});
+    for (; kt < nk; ++kt) step(kt, std::false_type{});
+    float* Mt = M + (int64_t)t * Cout * cols;
+    const int cl = 4 * l32;
+    if (cl < cols_left) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row0 = co0 + wave * 64 + mi * 32 + g * 4;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = row0 + (v >> 2) * 8 + (v & 3);
+                if (row < Cout) {
+                    f32x4 o = {acc[mi][0][v], acc[mi][1][v], acc[mi][2][v], acc[mi][3][v]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Mt + (int64_t)row * cols + c0 + cl));
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0): nothing of this workgroup is in flight when its LDS is handed on
+}
+
 }  // namespace
 
 extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, float* M, int T, int Cout, int Cin, int64_t cols,
@@ -325,6 +497,17 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
     }
 #endif
+    static const int shape = [] { const char* e = getenv("BITSWAP_BF16X3_SHAPE"); return e ? atoi(e) : 2; }();   // tuning only: same bits
+    if (shape == 2) {                     // two workgroups of 256 x 128 per CU (default)
+        const int64_t ncc2 = (cols + Y_BN - 1) / Y_BN, wgs2 = (int64_t)T * nrt * ncc2;
+        if (wgs2 > 0x7fffffff) return BS_EUNSUPPORTED;
+        const size_t shm2 = 3 * (size_t)Y_STAGE;
+        if (nprod == 9)
+            hipLaunchKernelGGL(k_wino_gemm_bf16x3_o2<9>, dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
+        else
+            hipLaunchKernelGGL(k_wino_gemm_bf16x3_o2<6>, dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
+        return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
+    }
     if (nprod == 9)
         hipLaunchKernelGGL(k_wino_gemm_bf16x3<9>, dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
     else
