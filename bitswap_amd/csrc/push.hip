@@ -180,7 +180,7 @@ __device__ __forceinline__ void push_chain_fast(uint64_t* __restrict__ head, uin
         const uint32_t nf = (1u << bits) - f;  // a repaired quotient adds 2^bits - f to the low word
         const int cnt = min(64, D - ck * 64);
         uint32_t out_lo = 0, out_hi = 0;
-        for (int t = 0; t < cnt; ++t) {
+        auto systolic_step = [&](int t) {
             if (t) {  // lane i's input <- lane i-1's output of the previous step
                 in_lo = from_lane_below(in_lo, out_lo);
                 in_hi = from_lane_below(in_hi, out_hi);
@@ -200,6 +200,12 @@ __device__ __forceinline__ void push_chain_fast(uint64_t* __restrict__ head, uin
             out_lo = l + w;
             // (q_est >> sh): alignbit only looks at the low `sh` bits of q_hi, the exponent bits fall out
             out_hi = __builtin_amdgcn_alignbit(q_hi, q_lo, (uint32_t)sh) + (out_lo < l ? 1u : 0u);
+        };
+        if (cnt == 64) {                // whole chunks (every table of the codec): no loop counter, compare and branch per symbol
+#pragma unroll
+            for (int t = 0; t < 64; ++t) systolic_step(t);
+        } else {
+            for (int t = 0; t < cnt; ++t) systolic_step(t);
         }
         const bool ren = (in_hi >> sh) >= f;  // of the final inputs
         // words: lane i emitted the low half of its input iff it renormalised
