@@ -463,6 +463,13 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
     __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0): nothing of this workgroup is in flight when its LDS is handed on
 }
 
+
+// (A third shape -- V split ONCE per workgroup, each thread 8 floats fetched straight from global memory two steps ahead, the
+// limbs written to LDS in MFMA B-fragment layout: 44 VALU per wavefront and K step instead of 176 -- was built and measured in
+// round 4, visit N: 232-250 us against 221-239 us for the shape above on the 36 x 256 x 256 x 8000 launch, with or without a
+// second register buffer for the U fragments.  The matrix pipe's idle share is not the split; LABNOTES.md has the numbers.
+// The kernel is not kept.)
+
 }  // namespace
 
 extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, float* M, int T, int Cout, int Cin, int64_t cols,

@@ -10,4 +10,4 @@ for l in sys.stdin:
     d=json.loads(m.group(2)); print(m.group(1), {k:(round(v['rms_err_over_rms']*1e7,3), round(v['max_err_over_range']*1e7,2), v['ms'], v['TFLOPs_equiv'], v.get('prefix_columns_same_bits')) for k,v in d.items()})
 "
 done
-timeout 900 python -m pytest tests -m gpu -x -q -k "bf16x3" 2>&1 | tail -2
+for shape in 2 1; do BITSWAP_BF16X3_SHAPE=$shape timeout 900 python -m pytest tests -m gpu -x -q -k "bf16x3" 2>&1 | tail -2; done
