@@ -229,9 +229,15 @@ template <int NPL, typename PT>
 int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
                     const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0, uint32_t* out1,
                     int64_t ld, int32_t* status, hipStream_t st) {
-    // chains per wavefront: amortise the endpoint fetch, but keep >= ~8 waves per SIMD in flight
-    int nb = 4;
-    while (nb > 1 && (int64_t)((D + 3) / 4) * ((B + nb - 1) / nb) < 4096) nb >>= 1;
+    // chains per wavefront: amortise the endpoint fetch (8 KB of L2 reads per row at K = 1024: with one chain per wavefront the
+    // launch is bound by them), but keep ~8 wavefronts per SIMD in flight.  Round 4, visit W (alone, us, z layer; nb = 1 / 4 / 16):
+    // 13 chains 34.3 / 27.5 / - (encode flavour), 40.0 / 29.2 / - (rows); 500 chains - / 792 / 714 and - / 790 / 748 (pivot).
+    // In the two-group pipeline of 1000 chains (same box, ms per step): nb = 4 / 8 / 16 = 180.1 / 178.3 / 183.7 -- sixteen rows per
+    // wavefront make the launch's tail too coarse when it shares the chip.
+    int nb = 8;
+    while (nb > 1 && (int64_t)((D + 3) / 4) * ((B + nb - 1) / nb) < 2048) nb >>= 1;
+    static const int nb_env = [] { const char* e = getenv("BITSWAP_TABLE_NB"); return e ? atoi(e) : 0; }();   // tuning only
+    if (nb_env > 0) nb = nb_env;
     dim3 grid((D + 3) / 4, (B + nb - 1) / nb), block(256);
     const PT* m = static_cast<const PT*>(mu);
     const PT* s = static_cast<const PT*>(scale);

@@ -427,7 +427,7 @@ class Model(nn.Module):
                     for m in self.modules():
                         u = getattr(m, "_wu", None)
                         if isinstance(m, WnConv2d) and u is not None and u.is_cuda and u.shape[1] >= 128 and u.shape[2] % 16 == 0:
-                            self._ufrags[u.data_ptr()] = _hip.frags_bf16x3(u)
+                            self._ufrags[u.data_ptr()] = (u, _hip.frags_bf16x3(u))   # the tensor itself pins the address
         return self
 
     @staticmethod
@@ -548,8 +548,8 @@ class Model(nn.Module):
         from . import hip
         if self.own_gemm and hip.wino_gemm_supported(U, V):
             uf = self._ufrags.get(U.data_ptr()) if self._ufrags else None
-            if uf is not None:
-                return hip.wino_gemm_bf16x3(uf, V, 9 if self.gemm_arith == "bf16x3x9" else 6)
+            if uf is not None and uf[0] is U:
+                return hip.wino_gemm_bf16x3(uf[1], V, 9 if self.gemm_arith == "bf16x3x9" else 6)
             return hip.wino_gemm(U, V)
         return torch.bmm(U, V)
 
