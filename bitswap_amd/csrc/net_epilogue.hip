@@ -268,6 +268,53 @@ __global__ __launch_bounds__(256) void k_wino_out(const float* __restrict__ M, c
     }
 }
 
+// floats per LDS plane of k_wino_fused: (H + 4) rows of W + 4, + 4 for the last row's right halo, rounded up to 256 bytes
+__host__ __device__ __forceinline__ constexpr int fused_lp(int H, int W) { return ((H + 4) * (W + 4) + 4 + 63) & ~63; }
+
+__device__ __forceinline__ void lds_wave_sync() {
+    // a wavefront's LDS operations execute in issue order: all that is needed is that the compiler keeps them in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the TS x TS window whose 4x4 centre starts at `mine` (a 16-byte aligned interior position), PAD = (TS - 4) / 2
+// WHOLE (k_wino_fused): the empty asm statements keep every 16-byte read whole.  Left alone, hipcc fetches exactly the TS x TS
+// dwords it needs as ds_read2_b32 pairs -- 32-lane groups whose lanes sit 4 dwords apart, on 8 of the 32 banks: a 4-way conflict
+// on every read.  k_conv3_wino keeps the dword reads (WHOLE = false): whole rows cost it 13-38 registers, and at 78 two of its
+// wavefronts fit beside the persistent GEMM's on a SIMD -- with whole reads it was 8 us faster alone and cost the 1000-chain
+// step 7 ms (round 4, visit Y).
+typedef float lds_f4 __attribute__((ext_vector_type(4)));
+template <int TS, bool WHOLE = true>
+__device__ __forceinline__ void lds_window(const float* mine, int LW, float (&p)[TS][TS]) {
+    constexpr int PAD = (TS - 4) / 2;
+#pragma unroll
+    for (int r = 0; r < TS; ++r) {
+        const float* row = mine + (r - PAD) * LW;
+        float ax, ay, az, aw, mx, my, mz, mw, zx, zy;
+        if (WHOLE) {
+            lds_f4 a = *reinterpret_cast<const lds_f4*>(row - 4);
+            lds_f4 m = *reinterpret_cast<const lds_f4*>(row);
+            lds_f4 z = *reinterpret_cast<const lds_f4*>(row + 4);
+            asm volatile("" : "+v"(a), "+v"(m), "+v"(z));
+            __builtin_amdgcn_sched_barrier(0);          // one row (12 registers) in flight, not TS: these kernels sit beside the GEMM
+            ax = a.x, ay = a.y, az = a.z, aw = a.w, mx = m.x, my = m.y, mz = m.z, mw = m.w, zx = z.x, zy = z.y;
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(row - 4);
+            const float4 m = *reinterpret_cast<const float4*>(row);
+            const float4 z = *reinterpret_cast<const float4*>(row + 4);
+            ax = a.x, ay = a.y, az = a.z, aw = a.w, mx = m.x, my = m.y, mz = m.z, mw = m.w, zx = z.x, zy = z.y;
+        }
+        (void)ax; (void)ay; (void)zy;
+        if (PAD == 1) {
+            p[r][0] = aw; p[r][1] = mx; p[r][2] = my; p[r][3] = mz; p[r][4] = mw; p[r][TS - 1] = zx;
+        } else {
+            p[r][0] = az; p[r][1] = aw; p[r][2] = mx; p[r][3] = my; p[r][4] = mz; p[r][5] = mw;
+            p[r][(TS == 8) ? 6 : 0] = zx; p[r][(TS == 8) ? 7 : 0] = zy;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_wino_fused<TS_IN, TS_OUT>: everything between two batched GEMMs of a ResNet layer in ONE pass.
 //   source   TS_IN == 0: x [N,C,H,W]              TS_IN in {6,8}: M [TS_IN^2, C, N*T] -> A^T M A
@@ -290,11 +337,15 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
                                                     const float* __restrict__ res, float* __restrict__ sum_out,
                                                     float* __restrict__ act_out, float* __restrict__ V, int64_t N,
                                                     int C, int H, int W, int act) {
-    constexpr int LW_PAD = 8;                       // halo 4 left (keeps the 16-byte row writes aligned) + 4 right
-    extern __shared__ float lds[];                  // [IMG][H+4][W+8], zero halo
+    // LDS planes as in k_conv3_wino (round 4, visit Y): rows W + 4 apart -- a row's right halo IS the next row's left halo -- and
+    // the window cut out with three aligned 16-byte reads per row.  Round 3 read it dword by dword from rows W + 8 apart: the 32
+    // lanes of a ds_read_b32 group then sit 4 dwords apart on rows and planes that are multiples of 32 dwords apart, i.e. on 4 of
+    // the 32 banks (SQ_LDS_BANK_CONFLICT 81 % of SQ_LDS_IDX_ACTIVE, profiles/r04s).  With 16 W + 64 bytes per tile row and plane
+    // strides that are multiples of 256 bytes, the 16 lanes of a ds_read_b128 group cover the 64 banks once.
+    extern __shared__ float lds[];                  // [IMG][fused_lp(H, W)], zero halo
     const int ntx = W / 4, T = (H / 4) * ntx;       // tiles per plane, divides 256
     const int IMG = 256 / T;
-    const int LW = W + LW_PAD, LP = (H + 4) * LW;   // padded row / plane size
+    const int LW = W + 4, LP = fused_lp(H, W);      // padded row / plane size
     const int tid = threadIdx.x;
     const int img = tid / T, tile = tid - img * T;
     const int ty = tile / ntx, tx = tile - ty * ntx;
@@ -304,7 +355,7 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
     const int64_t col = n * T + tile;
     const bool live = n < N;
     if (TS_OUT) {
-        for (int k = tid; k < IMG * LP; k += 256) lds[k] = 0.0f;
+        for (int k = tid * 4; k < IMG * LP; k += 1024) *reinterpret_cast<float4*>(lds + k) = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
     }
     float v[4][4];
@@ -357,17 +408,15 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
     }
     if (TS_OUT) {
         constexpr int TO = TS_OUT ? TS_OUT : 6;
-        constexpr int PAD = (TO - 4) / 2;
         __syncthreads();
         if (!live) return;
-        // window origin in halo coordinates: row ty*4 - PAD + 2, column tx*4 - PAD + 4
-        const float* wbase = lds + img * LP + (ty * 4 - PAD + 2) * LW + tx * 4 - PAD + 4;
-        float t1[TO][TO];  // B^T d, window read column by column
+        float d[TO][TO], t1[TO][TO];
+        lds_window<TO>(lds + img * LP + (ty * 4 + 2) * LW + tx * 4 + 4, LW, d);   // the tile's interior position, 16-byte aligned
 #pragma unroll
-        for (int q = 0; q < TO; ++q) {
+        for (int q = 0; q < TO; ++q) {               // B^T d, column by column
             float colv[TO], o[TO];
 #pragma unroll
-            for (int r = 0; r < TO; ++r) colv[r] = wbase[r * LW + q];
+            for (int r = 0; r < TO; ++r) colv[r] = d[r][q];
             wino_bt<TO>(colv, o);
 #pragma unroll
             for (int r = 0; r < TO; ++r) t1[r][q] = o[r];
@@ -422,32 +471,6 @@ int launch_bre(const float* x, const float* bias, const float* res, float* sum_o
 //   2 x 9 weights are wave-uniform (scalar loads), no block barrier inside the channel loop.  The activated tile goes
 //   through a wave-private LDS tile (LDS is in order within a wavefront) to reach the neighbours' windows for B^T d B.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_wave_sync() {
-    // a wavefront's LDS operations execute in issue order: all that is needed is that the compiler keeps them in order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// the TS x TS window whose 4x4 centre starts at `mine` (a 16-byte aligned interior position), PAD = (TS - 4) / 2
-template <int TS>
-__device__ __forceinline__ void lds_window(const float* mine, int LW, float (&p)[TS][TS]) {
-    constexpr int PAD = (TS - 4) / 2;
-#pragma unroll
-    for (int r = 0; r < TS; ++r) {
-        const float* row = mine + (r - PAD) * LW;
-        const float4 a = *reinterpret_cast<const float4*>(row - 4);
-        const float4 m = *reinterpret_cast<const float4*>(row);
-        const float4 z = *reinterpret_cast<const float4*>(row + 4);
-        if (PAD == 1) {
-            p[r][0] = a.w; p[r][1] = m.x; p[r][2] = m.y; p[r][3] = m.z; p[r][4] = m.w; p[r][TS - 1] = z.x;
-        } else {
-            p[r][0] = a.z; p[r][1] = a.w; p[r][2] = m.x; p[r][3] = m.y; p[r][4] = m.z; p[r][5] = m.w;
-            p[r][(TS == 8) ? 6 : 0] = z.x; p[r][(TS == 8) ? 7 : 0] = z.y;
-        }
-    }
-}
-
 template <int TS_OUT>
 __device__ __forceinline__ void conv3_tail(float (&v)[4][4], float b, int act, bool live, float* __restrict__ act_plane,
                                            float* __restrict__ vout, int64_t tstride, float* smine, int LW, int W) {
@@ -467,7 +490,7 @@ __device__ __forceinline__ void conv3_tail(float (&v)[4][4], float b, int act, b
     }
     lds_wave_sync();
     float d[TS_OUT][TS_OUT], t1[TS_OUT][TS_OUT];
-    lds_window<TS_OUT>(smine, LW, d);
+    lds_window<TS_OUT, false>(smine, LW, d);
     lds_wave_sync();                                 // the tile may be overwritten by the next channel from here on
     if (!live) return;
 #pragma unroll
@@ -505,7 +528,8 @@ __global__ __launch_bounds__(256) void k_conv3_wino(const float* __restrict__ x,
     const int64_t n = n0 + img;
     const bool live = n < N;
     const int nin = IMG * Cin * LP + 4;              // input planes (+ the last row's right halo)
-    const int nscr = IMG * LP + 4;                   // one wavefront's activation tile
+    const int LPS = fused_lp(H, W);                  // plane stride of the activation tiles: a multiple of 256 bytes (bank-clean)
+    const int nscr = IMG * LPS + 4;                  // one wavefront's activation tile
     for (int k = tid * 4; k < nin + 4 * nscr; k += 1024) *reinterpret_cast<float4*>(lds + k) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     {   // x[n0 .. n0+IMG) is one contiguous run of IMG*Cin*H*W floats
@@ -521,7 +545,7 @@ __global__ __launch_bounds__(256) void k_conv3_wino(const float* __restrict__ x,
     __syncthreads();
     const int toff = (ty * 4 + 2) * LW + tx * 4 + 4;  // this tile's interior position (16-byte aligned)
     const float* tin = lds + img * Cin * LP + toff;
-    float* smine = lds + nin + wave * nscr + img * LP + toff;
+    float* smine = lds + nin + wave * nscr + img * LPS + toff;
     const int64_t ncols = N * T, col = n * T + tile;
     const int64_t tstride = (int64_t)C * ncols;
     const int cbase = blockIdx.y * cpb;
@@ -538,7 +562,7 @@ __global__ __launch_bounds__(256) void k_conv3_wino(const float* __restrict__ x,
         const float* w1 = w + (int64_t)c1 * Cin * 9;
         for (int ci = 0; ci < Cin; ++ci) {
             float p[6][6];
-            lds_window<6>(tin + ci * LP, LW, p);
+            lds_window<6, false>(tin + ci * LP, LW, p);
             float k0[9], k1[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) { k0[k] = w0[ci * 9 + k]; k1[k] = w1[ci * 9 + k]; }
@@ -662,7 +686,7 @@ int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act
     if (T > 64 || 64 % T) return BS_EUNSUPPORTED;
     const int IMG = 64 / T;
     const size_t LP = (size_t)(H + 4) * (W + 4);
-    const size_t shm = ((size_t)IMG * Cin * LP + 4 + 4 * ((size_t)IMG * LP + 4)) * sizeof(float);
+    const size_t shm = ((size_t)IMG * Cin * LP + 4 + 4 * ((size_t)IMG * fused_lp(H, W) + 4)) * sizeof(float);
     if (shm > 160 * 1024) return BS_EUNSUPPORTED;
     if (N == 0) return BS_OK;
     const int64_t groups = (N + IMG - 1) / IMG;
@@ -728,7 +752,7 @@ int bs_wino_fused_f32(const float* src, int ts_in, const float* bias, const floa
     if (N == 0) return BS_OK;
     const int IMG = 256 / T;
     dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
-    const size_t shm = ts_out ? (size_t)IMG * (H + 4) * (W + 8) * sizeof(float) : 0;
+    const size_t shm = ts_out ? (size_t)IMG * fused_lp(H, W) * sizeof(float) : 0;
 #define BS_WF(TI, TO)                                                                                             \
     hipLaunchKernelGGL((k_wino_fused<TI, TO>), grid, block, shm, S(stream), src, bias, res, sum_out, act_out, V, N, C, H, \
                        W, act)
