@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4 full visit on the final code: GPU suite, default bench line, microbench, kernel stats + PMC FETCH / WRITE passes,
 # SQ counters of the table kernels (valu_busy.json keyed by flavour), BASELINE configs through the reference-named scripts
-TAG=${1:-r04Z}
+TAG=${1:-visit}
 OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_pytest.log 2>&1
 echo "pytest exit $?"; tail -3 $OUT/${TAG}_pytest.log
