@@ -44,6 +44,15 @@ def test_argument_validation_needs_no_gpu():
                             None, None) == hip.EINVAL
     assert L.bs_layer_push64(None, None, None, 0, None, 0, None, None, None, 0, 0, None, 1, 64, 256, 31, 8, None,
                              None) == hip.EINVAL
+    # the conv-stack products: null operands, a limb-product count that does not exist, a K that is not a multiple of 16
+    assert L.bs_wino_gemm_f32(None, None, None, 36, 256, 256, 128, None) == hip.EINVAL
+    assert L.bs_wino_gemm_bf16x3(None, None, None, 36, 256, 256, 128, 6, None) == hip.EINVAL
+    buf = (ctypes.c_char * 64)()
+    addr = (ctypes.addressof(buf) + 15) & ~15
+    p = ctypes.c_void_p(addr)
+    assert L.bs_wino_gemm_bf16x3(p, p, p, 36, 256, 256, 128, 7, None) == hip.EINVAL
+    assert L.bs_wino_gemm_bf16x3(p, p, p, 36, 256, 250, 128, 6, None) == hip.EUNSUPPORTED
+    assert L.bs_wino_gemm_bf16x3(p, p, p, 0, 256, 256, 128, 6, None) == hip.OK          # nothing to do: no launch
     assert L.bs_cdf_spec() == 2
 
 
