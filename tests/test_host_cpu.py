@@ -632,3 +632,29 @@ def test_timeline_tool_classifies_wall_time(tmp_path):
     g64 = [v for k, v in calls.items() if "[T=64]" in k][0]
     assert g36["beside_serial"] == {"calls": 1, "mean_us": 2000.0} and g36["shared"]["calls"] == 0
     assert g64["shared"] == {"calls": 1, "mean_us": 2000.0} and g64["beside_serial"]["calls"] == 0
+
+
+def test_overlap_stats_tool(tmp_path):
+    """tools/overlap_stats.py (is the many-chain step bound by its bulk work or by the serial chain): union of the
+    bulk / serial intervals over the window that ends with the last coding kernel."""
+    import csv
+    import subprocess
+    import sys
+    ms = 1_000_000
+    rows = [("void k_wino_gemm<4, 2, 2, 2>(float)", 0, 4 * ms), ("void k_logistic<16, float, 4, true>(y)", 2 * ms, 5 * ms),
+            ("void k_rans_pop_pivot<16, float, 4>(x)", 1 * ms, 3 * ms), ("k_rans_push(z)", 6 * ms, 7 * ms)]
+    d = tmp_path / "trace" / "host"
+    d.mkdir(parents=True)
+    with open(d / "t_kernel_trace.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Queue_Id"])
+        for n, a, b in rows:
+            w.writerow([n, a, b, 1])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "overlap_stats.py"), str(tmp_path / "trace"), "--ms", "7"],
+                                  text=True)
+    head = out.splitlines()[0]
+    # bulk union 0..5 = 5 ms, serial union 1..3 + 6..7 = 3 ms, anything 0..5 + 6..7 = 6 ms, only serial 1 ms, nothing 1 ms
+    assert "some kernel 6.0 ms" in head and "a bulk kernel 5.0 ms" in head and "a serial kernel 3.0 ms" in head
+    assert "only serial 1.0 ms" in head and "nothing 1.0 ms" in head
+    assert "sum of bulk kernel time 7.0 ms, of serial kernel time 3.0 ms" in out
