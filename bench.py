@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--total-chains", type=int, default=100, help="chains in total over all ranks (--scaling strong)")
     ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
                     help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
-    ap.add_argument("--cdf-spec", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--cdf-spec", type=int, default=3, choices=[1, 2, 3])
     ap.add_argument("--no-graphs", action="store_true", help="never replay the block step from a hipGraph (single-stream runs)")
     ap.add_argument("--format", default="reference", choices=["reference", "wave64"],
                     help="reference: the reference's single-state word stream (default, the headline); wave64: the opt-in "

@@ -21,7 +21,7 @@ import torch
 
 from . import container, dist, meta, tiling, workload
 from .bins import discretize, _cache_names as _bins_cache_names
-from .codec import BitSwapCodec, initial_states
+from .codec import BitSwapCodec, initial_states, reference_draws
 from .model import elbo_bits, preset
 
 SCHEME = {1: "Bit-Swap", 0: "BB-ANS"}
@@ -36,6 +36,16 @@ def seed_everything():
     if torch.cuda.is_available():
         torch.cuda.manual_seed(50)
     # cudnn.deterministic / benchmark (:98-99) are scoped to the codec's conv stacks: codec.deterministic_convs()
+
+
+def experiment_draws(ntest, experiments, ndatapoints, nwords=10000):
+    """(randindices, initial states) of a dataset script run: the reference's numpy draw order when its own sequence can
+    serve the shape (codec.reference_draws), else sampling with replacement + codec.initial_states()."""
+    if ntest >= experiments * ndatapoints:
+        return reference_draws(ntest, experiments, ndatapoints, nwords, seed=100)
+    np.random.seed(100)
+    randindices = np.random.choice(ntest, size=(experiments, ndatapoints), replace=True)
+    return randindices, initial_states(experiments, nwords, seed=100)
 
 
 def load_images(dataset, path, synthetic, xs, n):
@@ -79,7 +89,7 @@ def stream_name(scheme, quantbits, nz, c, wave64=False):
 
 def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndatapoints=100, decompress=False,
              synthetic=False, data=None, params=None, outdir=".", backend=None, small=None, verbose=True,
-             save_bins=False, fmt="reference", cdf_spec=2):
+             save_bins=False, fmt="reference", cdf_spec=3):
     """One (dataset, nz, quantbits, scheme) experiment set.  Returns dict of the metric arrays on
     rank 0 (None on other ranks).  fmt "wave64": the opt-in 64-state stream format (pickles then hold 64 sub-state
     lists per experiment and carry the suffix _wave64)."""
@@ -109,21 +119,27 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
     if world > 1 and keep and rank == 0:
         dist.barrier()
 
-    # (experiments, ndatapoints) test images per experiment, without replacement (:133-137)
+    # (experiments, ndatapoints) test images per experiment without replacement, then the initial words of every
+    # experiment -- numpy's generator consumed in the reference's order (:94,133-137,158): seed(100), choice(), randint() per
+    # experiment.  (Round 4 re-seeded before the words; experiment i then started from other "random" words than it does
+    # in the reference script.)  A saved index file selects the images, as it would in the reference if its guard ever hit,
+    # but the draw still happens.  Fewer images than experiments x ndatapoints (small synthetic sets): the reference's
+    # choice(replace=False) would raise; documented fallback = sampling with replacement + initial_states().
     idx_path = os.path.join(outdir, "bitstreams", dataset, "indices.npy")
-    if os.path.exists(idx_path):
-        randindices = np.load(idx_path)
-    else:
-        randindices = np.random.choice(len(images), size=(experiments, ndatapoints),
-                                       replace=len(images) < experiments * ndatapoints)
-        if rank == 0:
-            os.makedirs(os.path.dirname(idx_path), exist_ok=True)
-            np.save(idx_path, randindices)
+    randindices, inits = experiment_draws(len(images), experiments, ndatapoints)
+    have = os.path.exists(idx_path)
+    if world > 1:
+        dist.barrier()       # every rank has looked before rank 0 may write
+    saved = np.load(idx_path) if have else None
+    if saved is not None and saved.shape == randindices.shape:
+        randindices = saved
+    elif rank == 0:
+        os.makedirs(os.path.dirname(idx_path), exist_ok=True)
+        np.save(idx_path, randindices)
     if world > 1:
         dist.barrier()       # nobody may race ahead and find rank 0's half-written indices file on a later call
 
     mine = dist.shard_chains(experiments, world, rank)
-    inits = initial_states(experiments, 10000, seed=100)        # experiment ei gets the ei-th draw (:158)
     codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
                          backend=_format_backend(fmt, backend, dev), cdf_spec=cdf_spec)
     wave64 = hasattr(codec.backend.new_state([inits[0]], 16), "len64") if fmt == "wave64" else False
@@ -195,7 +211,7 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
 
 
 def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=False, data=None, params=None,
-                       outdir=".", backend=None, small=None, verbose=True, cdf_spec=2):
+                       outdir=".", backend=None, small=None, verbose=True, cdf_spec=3):
     """Receiver only (the reference decodes inside compress(), mnist_compress.py:277-358; a real receiver is another
     process): load the experiment pickles and stream_meta.json a sender wrote under `outdir`, REFUSE to decode unless this
     receiver reproduces the recorded format / CDF specification / conv route, decode every experiment, and assert the
@@ -232,7 +248,7 @@ def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=F
     states = [container.load_state(os.path.join(sdir, stream_name(scheme, quantbits, nz, c, wave64)))
               for c in range(experiments)]
     nwords = max((sum(len(x) for x in s) if wave64 else len(s)) for s in states)
-    inits = initial_states(experiments, 10000, seed=100)
+    _, inits = experiment_draws(len(images), experiments, ndatapoints)     # the sender's draw sequence
     if wave64:
         from .hip import split_state
         inits = [split_state(s) for s in inits]
@@ -268,9 +284,10 @@ def dataset_main(dataset, default_nz, nz_loop=None):
                    help="stream format: the reference's single-state stream, or the opt-in 64-state format")
     p.add_argument('--decompress-only', action='store_true',
                    help="receiver only: decode the pickles a previous run wrote under --outdir (checks stream_meta.json first)")
-    p.add_argument('--cdf-spec', default=2, type=int, choices=[1, 2],
-                   help="deterministic CDF specification (include/bitswap_hip.h): 2 = uniform-bin recurrence where the bins "
-                        "allow it (default), 1 = one sigmoid per endpoint everywhere (streams written before round 2)")
+    p.add_argument('--cdf-spec', default=3, type=int, choices=[1, 2, 3],
+                   help="deterministic CDF specification (include/bitswap_hip.h) of the tables whose bins are uniform: 3 = one "
+                        "reciprocal per block of bins (default since round 5), 2 = one per bin (streams of rounds 3-4), "
+                        "1 = one sigmoid per endpoint everywhere (streams written before round 2)")
     p.add_argument('--save-bins', action='store_true',
                    help="write bins fitted on the given test images under the reference's cache names (bins/*.pt)")
     args = p.parse_args()
@@ -341,7 +358,7 @@ class ImageStreams(list):
 
 
 def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_quirk=False, setup=None, backend=None,
-                    trim=True, fmt="reference", cdf_spec=2):
+                    trim=True, fmt="reference", cdf_spec=3):
     """images_blocks: list of [n_i, 32, 32, 3] uint8 block arrays (one per image; every image is a
     chain, imagenetcrop_compress.py:279-300).  Chains of different length run in lock-step and
     drop out as they finish.  Returns per image (state list, min_words, bits/dim); in the 64-state format the state is
@@ -372,7 +389,7 @@ def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_qui
 
 
 def decompress_image(state, nblocks, quantbits=10, nz=4, gpu=0, setup=None, backend=None, hwc_quirk=False,
-                     expect=None, expect_word=None, cdf_spec=2):
+                     expect=None, expect_word=None, cdf_spec=3):
     """demo_decompress.decompress (:69-148): -> [nblocks, 32, 32, 3] uint8 blocks.  A state that is a list of 64
     sub-state lists (container.unpack64) is decoded in the 64-state format.  expect: the sender's fingerprint record
     (the container's sidecar) / expect_word: its CRC-32 (64-state container header): decoding is REFUSED

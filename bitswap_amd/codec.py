@@ -47,6 +47,11 @@ class HipBackend:
     # shorter pop wins (100 chains: 27.9 vs 36.7 ms per step, profiles/r03p).  BITSWAP_PIVOT=0: whole rows always.
     pivot = os.environ.get("BITSWAP_PIVOT", "1") == "1"
     pivot_min_bytes = int(float(os.environ.get("BITSWAP_PIVOT_MIN_BYTES", "2e9")))
+    # CDF specification of tables of uniform-width bins (2 or 3, include/bitswap_hip.h); the codec sets it from its cdf_spec
+    cdf_spec = hip.UNIFORM_CDF_SPEC
+
+    def _sp(self, step):
+        return None if step is None else self.cdf_spec
 
     def table_layout(self, K, uniform=False, D=64, B=1):
         if (uniform and self.pivot and hip.pivot_supported(K, D)
@@ -81,7 +86,8 @@ class HipBackend:
                     layout = hip.LAYOUT_WAVE
                 else:
                     out = None
-        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=layout, step=step, status=status)
+        return hip.logistic_tables(endpoints, mu, scale, bits, quantbits, out=out, layout=layout, step=step, status=status,
+                                   spec=self._sp(step))
 
     def shared_table(self, endpoints, mu, scale, quantbits, bits, step=None):
         """One table row set [D, ld] shared by every chain (the prior)."""
@@ -94,12 +100,12 @@ class HipBackend:
         return hip.rans_pop(state, cdf, K, bits, centres=centres)
 
     def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
-        f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits, step=step)
+        f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits, step=step, spec=self._sp(step))
         hip.rans_push(state, f, c, bits)
 
     # push in two halves, for schedules that evaluate the (f, c) of a layer early and code it later (forked block step)
     def push_prepare(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
-        return hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits, step=step)
+        return hip.logistic_fc(endpoints, mu, scale, sym, state.status, bits, quantbits, step=step, spec=self._sp(step))
 
     def push_commit(self, state, token, bits):
         hip.rans_push(state, token[0], token[1], bits)
@@ -164,20 +170,20 @@ class Hip64Backend(HipBackend):
         return _LazyTable(endpoints, mu[0].contiguous(), scale[0].contiguous(), quantbits, step)
 
     def pop(self, state, t, K, bits, centres=None):
-        return hip.layer_pop64(state, t.endpoints, t.mu, t.scale, bits, t.quantbits, centres=centres, step=t.step)
+        return hip.layer_pop64(state, t.endpoints, t.mu, t.scale, bits, t.quantbits, centres=centres, step=t.step, spec=self._sp(t.step))
 
     def push_params(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
-        hip.layer_push64(state, endpoints, mu, scale, sym, bits, quantbits, step=step)
+        hip.layer_push64(state, endpoints, mu, scale, sym, bits, quantbits, step=step, spec=self._sp(step))
 
     def push_prepare(self, state, endpoints, mu, scale, sym, quantbits, bits, step=None):
         return (endpoints, mu, scale, sym, quantbits, step)      # table + push are ONE launch here: nothing to do early
 
     def push_commit(self, state, token, bits):
         endpoints, mu, scale, sym, quantbits, step = token
-        hip.layer_push64(state, endpoints, mu, scale, sym, bits, quantbits, step=step)
+        hip.layer_push64(state, endpoints, mu, scale, sym, bits, quantbits, step=step, spec=self._sp(step))
 
     def push_table(self, state, t, sym, K, bits):
-        hip.layer_push64(state, t.endpoints, t.mu, t.scale, sym, bits, t.quantbits, step=t.step)
+        hip.layer_push64(state, t.endpoints, t.mu, t.scale, sym, bits, t.quantbits, step=t.step, spec=self._sp(t.step))
 
 
 def initial_states(nchains, nwords=10000, seed=100):
@@ -190,6 +196,25 @@ def initial_states(nchains, nwords=10000, seed=100):
         s[-1] = s[-1] << 32
         out.append(s)
     return out
+
+
+def reference_draws(ntest, experiments, ndatapoints, nwords=10000, seed=100):
+    """What the reference's dataset scripts hold after their numpy draws, IN THEIR ORDER (mnist_compress.py:94,133-137,158
+    and the cifar / imagenet siblings): `np.random.seed(100)`, then `np.random.choice(len(test_set), size=(experiments,
+    ndatapoints), replace=False)` -- always drawn there: the `os.path.exists("bitstreams/<ds>/indices")` guard never hits
+    because `np.save` appends ".npy" -- and only then, experiment after experiment, the 10000 initial words.  The words of
+    experiment i therefore depend on the size of the test set (the permutation behind `choice` consumes the generator):
+    10000 for MNIST / CIFAR-10, 50000 for ImageNet 32x32.  -> (randindices [experiments, ndatapoints], initial states).
+    `initial_states()` (seed, then the words at once) stays the fallback for shapes the reference sequence cannot serve:
+    fewer test images than experiments x ndatapoints, where its `choice(..., replace=False)` raises."""
+    np.random.seed(seed)
+    randindices = np.random.choice(ntest, size=(experiments, ndatapoints), replace=False)
+    out = []
+    for _ in range(experiments):
+        s = list(map(int, np.random.randint(low=1 << 16, high=(1 << 32) - 1, size=nwords, dtype=np.uint32)))
+        s[-1] = s[-1] << 32
+        out.append(s)
+    return randindices, out
 
 
 class Timeline:
@@ -282,7 +307,7 @@ class BitSwapCodec:
     """
 
     def __init__(self, model, zendpoints, zcentres, quantbits=10, bitswap=True, ansbits=31, backend=None,
-                 timeline=None, cdf_spec=2):
+                 timeline=None, cdf_spec=3):
         self.backend = backend if backend is not None else HipBackend(zendpoints.device)
         self.model = model
         self.nz = model.nz
@@ -296,14 +321,16 @@ class BitSwapCodec:
         self.zcen = [zcentres[i].contiguous() for i in range(self.nz)]
         xb = ImageBins(torch.float64, dev, self.X)
         self.xend, self.xcen = xb.endpoints(), xb.centres()   # expanded views, row stride 0
-        # deterministic CDF specification per table (include/bitswap_hip.h): spec 2 on every set of uniform-width
-        # bins (all latent layers but the top one, and the pixels), spec 1 elsewhere.  The choice is a function of
-        # the bins alone, so a receiver built from the same bins makes the same one; cdf_spec=1 forces spec 1
-        # everywhere (streams written before spec 2 existed).
-        assert cdf_spec in (1, 2)
+        # deterministic CDF specification per table (include/bitswap_hip.h): spec `cdf_spec` (3 since round 5: one reciprocal
+        # per block of bins; 2: round 3/4 streams) on every set of uniform-width bins (all latent layers but the top one, and
+        # the pixels), spec 1 elsewhere.  Which tables are uniform is a function of the bins alone, so a receiver built from
+        # the same bins and the same cdf_spec makes the same choice; cdf_spec=1 forces spec 1 everywhere (round 1/2 streams).
+        assert cdf_spec in (1, 2, 3)
         self.cdf_spec = cdf_spec
+        if cdf_spec >= 2:
+            self.backend.cdf_spec = cdf_spec
         none = lambda e: None
-        stepper = getattr(self.backend, "bin_step", none) if cdf_spec == 2 else none
+        stepper = getattr(self.backend, "bin_step", none) if cdf_spec >= 2 else none
         self.zstep = [stepper(e) for e in self.zend]
         self.xstep = stepper(self.xend)
         self.tl = timeline or Timeline(False)
@@ -442,7 +469,8 @@ class BitSwapCodec:
             return
         ts = self._tables_stream((mu, scale, sym))
         with self._on(ts), self.tl.span("fc_" + key):
-            f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, self.bits, quantbits, step=step)
+            f, c = hip.logistic_fc(endpoints, mu, scale, sym, state.status, self.bits, quantbits, step=step,
+                                   spec=None if step is None else self.cdf_spec)
             self._share((f, c), self.serial)
         self._serial_waits_bulk()
         with self._on(self.serial), self.tl.span("push_" + key):

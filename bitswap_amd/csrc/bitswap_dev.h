@@ -87,26 +87,39 @@ __device__ __forceinline__ double recip_1_to_huge(double x) {
     return fma(r, y, y);
 }
 
-// exp(a) for the clamped argument: the exponential half of the deterministic sigmoid
-__device__ __forceinline__ double det_exp(double a) {
-    a = fmin(fmax(a, -700.0), 700.0);
+// fma(a, b, c) with the constant c in a scalar register pair, as ONE three-source instruction.  Left to itself hipcc keeps
+// the eleven polynomial constants of det_exp in VECTOR registers (22 of them, live across the whole row loop of the table
+// kernels) and writes every Horner step as v_mov_b64 + v_fmac_f64 -- 9 extra issue slots per exponential.  Same IEEE
+// operation either way.
+__device__ __forceinline__ double fma_sconst(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
+// exp(a) for the argument clamped to [-700, hi]: the exponential half of the deterministic sigmoid (hi = 700; the anchors
+// of CDF spec 3 clamp at 41)
+__device__ __forceinline__ double det_exp_hi(double a, double hi) {
+    a = fmin(fmax(a, -700.0), hi);
     const double kd = rint(a * 0x1.71547652b82fep+0);
     double r = fma(-kd, 0x1.62e42fee00000p-1, a);
     r = fma(-kd, 0x1.a39ef35793c76p-33, r);
     double p = 0x1.af631e4ea6521p-26;
-    p = fma(p, r, 0x1.28b4068ef93d2p-22);
-    p = fma(p, r, 0x1.71ddf573e8618p-19);
-    p = fma(p, r, 0x1.a01991ab61789p-16);
-    p = fma(p, r, 0x1.a01a01b143bc8p-13);
-    p = fma(p, r, 0x1.6c16c187fc4dep-10);
-    p = fma(p, r, 0x1.111111110f224p-7);
-    p = fma(p, r, 0x1.555555554f0ccp-5);
-    p = fma(p, r, 0x1.555555555555ap-3);
-    p = fma(p, r, 0x1.0000000000011p-1);
+    p = fma_sconst(p, r, 0x1.28b4068ef93d2p-22);
+    p = fma_sconst(p, r, 0x1.71ddf573e8618p-19);
+    p = fma_sconst(p, r, 0x1.a01991ab61789p-16);
+    p = fma_sconst(p, r, 0x1.a01a01b143bc8p-13);
+    p = fma_sconst(p, r, 0x1.6c16c187fc4dep-10);
+    p = fma_sconst(p, r, 0x1.111111110f224p-7);
+    p = fma_sconst(p, r, 0x1.555555554f0ccp-5);
+    p = fma_sconst(p, r, 0x1.555555555555ap-3);
+    p = fma_sconst(p, r, 0x1.0000000000011p-1);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, (int)kd);
 }
+
+__device__ __forceinline__ double det_exp(double a) { return det_exp_hi(a, 700.0); }
 
 __device__ __forceinline__ double det_sigmoid(double t) { return recip_1_to_huge(1.0 + det_exp(-t)); }
 
@@ -225,9 +238,64 @@ __device__ __forceinline__ void uni_bins(const double (&e)[NPL], double rs, doub
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// BS_CDF_SPEC 3: spec 2's denominators x_b = 1 + E_b, inverted per block of N <= 16 bins with ONE correctly rounded
+// reciprocal -- a balanced product tree up, the root inverted, one multiplication per node down (heap order: node k has
+// the children 2k and 2k+1, the leaves are N .. 2N-1).  oracle/bitswap_oracle.c::det3_row_cdf is the C restatement.
+// A quotient costs 3 multiplications + 9/N slots instead of 9: 54 instead of 144 issue slots per 16 bins.
+// ------------------------------------------------------------------------------------------
+#define BS_SPEC3_FAST_HR 8.0      // rows with NPL * |h / scale| below this take the batch inversion, the others spec 2's arithmetic
+#define BS_SPEC3_ANCHOR_HI 41.0   // clamp of the anchor's exponent: x <= 1 + e^41 < 2^59.2, a root of 16 stays below 2^947
+// A node of the product tree over N leaves, walked depth-first so that the quotients come out in bin order and a node's
+// value dies as soon as both of its children have their inverse (the table kernels are register-bound).
+template <int N>
+struct InvTree {
+    InvTree<N / 2> l, r;
+    double t;
+    __device__ __forceinline__ void up(const double* x) {
+        l.up(x);
+        r.up(x + N / 2);
+        t = l.t * r.t;
+    }
+    template <typename F>
+    __device__ __forceinline__ void down(double inv, int i0, F&& leaf) {
+        l.down(inv * r.t, i0, leaf);
+        r.down(inv * l.t, i0 + N / 2, leaf);
+    }
+};
+template <>
+struct InvTree<1> {
+    double t;
+    __device__ __forceinline__ void up(const double* x) { t = x[0]; }
+    template <typename F>
+    __device__ __forceinline__ void down(double inv, int i0, F&& leaf) { leaf(i0, inv); }
+};
+// leaf(i, 1 / x[i]) for i = 0 .. N-1 in order
+template <int N, typename F>
+__device__ __forceinline__ void tree_inverse(const double* x, int i0, F&& leaf) {
+    static_assert(N == 2 || N == 4 || N == 8 || N == 16, "block of a power of two, at most 16 bins");
+    InvTree<N> tr;
+    tr.up(x);
+    tr.down(recip_1_to_huge(tr.t), i0, leaf);
+}
+// fma(-a, b, c) as ONE three-source instruction: left to itself hipcc writes v_mov_b64 + v_fmac_f64 whenever c lives on
+__device__ __forceinline__ double fnma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <int NPL, int I>
+__device__ __forceinline__ void spec3_denoms(const double (&e)[NPL], double Ars, double A, double qb, double (&x)[NPL]) {
+    if constexpr (I < NPL) {
+        x[I] = one_plus_e<NPL, I>(qb, fnma3(Ars, e[I], A));      // e[I]: the residual r_I of the stored endpoint
+        spec3_denoms<NPL, I + 1>(e, Ars, A, qb, x);
+    }
+}
+
 // One (chain, dim) row: bn.t[i] = trunc(pmf * M) of this lane's NPL bins (the reference's f - 1).  `e` holds the
-// lane's endpoints (spec 1) or its anchor + residuals (spec 2, see k_logistic).
-// Returns false when the row leaves the domain of CDF spec 2: NPL * h / scale < 650.  det_exp clamps its argument to +-700.
+// lane's endpoints (spec 1) or its anchor + residuals (specs 2 and 3, see k_logistic; the residual of lane 63's last,
+// virtual endpoint is 0).  SPEC: the CDF specification, 1 = generic bins, 2 / 3 = uniform-width bins.
+// Returns false when the row leaves the domain of CDF specs 2 / 3: NPL * h / scale < 650.  det_exp clamps its argument to +-700.
 // A clamped ANCHOR is harmless on its own: beyond +700 every bin of the lane is exactly 1, beyond -700 the lane's bins
 // come out as e^-(700 - b h/scale) <= e^-50 -- too large, but still truncated to the same f = 1 as the true values, so the
 // table is the exact one.  What must not be clamped is the geometric factor Q_b = exp(-b h/scale): with h/scale in the
@@ -235,20 +303,46 @@ __device__ __forceinline__ void uni_bins(const double (&e)[NPL], double rs, doub
 // 2/255/8, mnist_train.py:411; reachable only through the C ABI) a lane with a clamped anchor would put 0.5 where the
 // cdf is 1e-18, and the cdf would step DOWN into the next lane.  Such rows are not coded: the caller flags
 // BS_ST_BADTABLE (oracle/bitswap_oracle.c::layer_in_domain applies the same test); CDF spec 1 takes any scale.
-template <int NPL, bool UNI>
+template <int NPL, int SPEC>
 __device__ __forceinline__ bool logistic_row(const double (&e)[NPL], double hstep, double m_, double rs, double M, int lane,
                                              Bins<NPL>& bn) {
     double c0, prev;
     bool in_domain = true;
-    if (UNI) {
+    if constexpr (SPEC >= 2) {
         const double hr = hstep * rs;
         const double qb = det_exp(-((double)(lane & (NPL - 1)) * hr));   // lane b < NPL: Q_b
         const double ta = (e[0] - m_) * rs;
-        in_domain = (double)NPL * fabs(hr) < 650.0;
-        const double A = det_exp(-ta);
-        c0 = recip_1_to_huge(1.0 + A);
-        prev = c0;
-        uni_bins<NPL, 1>(e, rs, A, qb, M, lane, prev, bn);
+        const double span = (double)NPL * fabs(hr);
+        in_domain = span < 650.0;
+        bool batch = false;
+        if constexpr (SPEC == 3 && NPL >= 4) batch = span < BS_SPEC3_FAST_HR;      // wave-uniform (mu, scale, h are scalars)
+        if (batch) {
+            if constexpr (SPEC == 3 && NPL >= 4) {
+                const double A = det_exp_hi(-ta, BS_SPEC3_ANCHOR_HI);
+                const double Ars = A * rs;
+                double x[NPL];
+                x[0] = 1.0 + A;
+                spec3_denoms<NPL, 1>(e, Ars, A, qb, x);
+                constexpr int NB = NPL < 16 ? NPL : 16;
+                c0 = prev = 0.0;
+#pragma unroll
+                for (int i0 = 0; i0 < NPL; i0 += NB)
+                    tree_inverse<NB>(x + i0, i0, [&](int i, double ci) {
+                        if (i == 0) {
+                            c0 = ci;
+                        } else {
+                            if (i == NPL - 1 && lane == 63) ci = 1.0;
+                            bn.t[i] = trunc_u32((ci - prev) * M);
+                        }
+                        prev = ci;
+                    });
+            }
+        } else {
+            const double A = det_exp(-ta);
+            c0 = recip_1_to_huge(1.0 + A);
+            prev = c0;
+            uni_bins<NPL, 1>(e, rs, A, qb, M, lane, prev, bn);
+        }
     } else {
         c0 = det_sigmoid((e[0] - m_) * rs);
         if (NPL == 1 && lane == 63) c0 = 1.0;

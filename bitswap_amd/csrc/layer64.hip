@@ -23,7 +23,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int W64_NB = 4;  // chains per wavefront (the endpoint registers are shared between them)
 
-template <int NPL, typename PT, bool UNI, bool PUSH>
+template <int NPL, typename PT, int SPEC, bool PUSH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_layer64(
     const double* __restrict__ endpoints, int64_t e_stride, const double* __restrict__ step, const PT* __restrict__ mu,
     const PT* __restrict__ scale, int64_t p_stride, const int32_t* __restrict__ sym_in, int32_t* __restrict__ sym_out,
@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     uint32_t* __restrict__ stack, int32_t* __restrict__ len, int64_t cap, int B, int D, int bits, int quantbits, int nb,
     int32_t* __restrict__ status) {
     constexpr int K = NPL * 64;
+    constexpr bool UNI = SPEC >= 2;      // CDF specs 2 and 3: rows of uniform-width bins
     const int lane = threadIdx.x & 63;
     const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));  // residue = state index
     if (j >= D) return;
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (UNI) {
 #pragma unroll
             for (int k = 1; k < NPL; ++k) e[k] = e[k] - fma((double)k, hstep, e[0]);
+            if (lane == 63) e[NPL - 1] = 0.0;   // the K-th, virtual endpoint: on the progression (k_logistic does the same)
         }
 #pragma unroll
         for (int c = 0; c < W64_NB; ++c) {
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const double rs = recip_scale(sc_);
             const bool okp = (sc_ > 0.0) && (rs > 0.0) && (fabs(m_) < __builtin_huge_val());
             Bins<NPL> bn;
-            const bool dom = logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
+            const bool dom = logistic_row<NPL, SPEC>(e, hstep, m_, rs, M, lane, bn);
             bool bad;
             uint32_t cstart = bump_and_scan<NPL>(bn, lane, bits, bad);
             if (__ballot(bad || !dom) != 0ull || !okp) { st[c] = BS_ST_BADTABLE; continue; }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 }
 
 template <typename PT, bool PUSH>
-int dispatch_layer64(int K, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
+int dispatch_layer64(int K, int spec, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
                      int64_t p_stride, const int32_t* sym_in, int32_t* sym_out, const double* centres, int64_t c_stride,
                      float* centre_out, uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, int B, int D, int bits,
                      int quantbits, int32_t* status, hipStream_t st) {
@@ -172,13 +174,13 @@ int dispatch_layer64(int K, const double* endpoints, int64_t e_stride, const dou
     dim3 grid(16, (B + nb - 1) / nb), block(256);
     const PT* m = static_cast<const PT*>(mu);
     const PT* s = static_cast<const PT*>(scale);
-#define BS_L64(NPL, UNI)                                                                                          \
-    hipLaunchKernelGGL((k_layer64<NPL, PT, UNI, PUSH>), grid, block, 0, st, endpoints, e_stride, step, m, s, p_stride, \
+#define BS_L64(NPL, SPEC)                                                                                         \
+    hipLaunchKernelGGL((k_layer64<NPL, PT, SPEC, PUSH>), grid, block, 0, st, endpoints, e_stride, step, m, s, p_stride, \
                        sym_in, sym_out, centres, c_stride, centre_out, head, stack, len, cap, B, D, bits, quantbits, nb, status)
     switch (K) {
-        case 256: if (step) BS_L64(4, true); else BS_L64(4, false); break;
-        case 512: if (step) BS_L64(8, true); else BS_L64(8, false); break;
-        case 1024: if (step) BS_L64(16, true); else BS_L64(16, false); break;
+        case 256: if (spec == 3) BS_L64(4, 3); else if (spec == 2) BS_L64(4, 2); else BS_L64(4, 1); break;
+        case 512: if (spec == 3) BS_L64(8, 3); else if (spec == 2) BS_L64(8, 2); else BS_L64(8, 1); break;
+        case 1024: if (spec == 3) BS_L64(16, 3); else if (spec == 2) BS_L64(16, 2); else BS_L64(16, 1); break;
         default: return BS_EUNSUPPORTED;
     }
 #undef BS_L64
@@ -190,9 +192,12 @@ int dispatch_layer64(int K, const double* endpoints, int64_t e_stride, const dou
 extern "C" {
 
 int bs_layer_pop64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t cap, const double* endpoints,
-                   int64_t e_stride, const double* bin_step, const void* mu, const void* scale, int64_t p_stride,
+                   int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu, const void* scale, int64_t p_stride,
                    int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres,
                    int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
+    const int spec = cdf_spec == 1 ? 1 : ((cdf_spec == 2 || cdf_spec == 3) && bin_step) ? cdf_spec : 0;
+    if (!spec) return BS_EINVAL;
+    if (spec == 1) bin_step = nullptr;
     if (!head64 || !stack64 || !len64 || !endpoints || !mu || !scale || !sym_out || !status || B < 0 || D < 0 || cap < 0 ||
         bits < 1 || bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || p_stride < 0 || c_stride < 0 ||
         (centres && !centre_out))
@@ -200,30 +205,33 @@ int bs_layer_pop64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t 
     if (D > 4096) return BS_EUNSUPPORTED;  // one lane per row of a residue
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_layer64<float, false>(K, endpoints, e_stride, bin_step, mu, scale, p_stride, nullptr, sym_out, centres,
+        return dispatch_layer64<float, false>(K, spec, endpoints, e_stride, bin_step, mu, scale, p_stride, nullptr, sym_out, centres,
                                               c_stride, centre_out, head64, stack64, len64, cap, B, D, bits, quantbits,
                                               status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_layer64<double, false>(K, endpoints, e_stride, bin_step, mu, scale, p_stride, nullptr, sym_out, centres,
+        return dispatch_layer64<double, false>(K, spec, endpoints, e_stride, bin_step, mu, scale, p_stride, nullptr, sym_out, centres,
                                                c_stride, centre_out, head64, stack64, len64, cap, B, D, bits, quantbits,
                                                status, S(stream));
     return BS_EINVAL;
 }
 
 int bs_layer_push64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t cap, const double* endpoints,
-                    int64_t e_stride, const double* bin_step, const void* mu, const void* scale, int64_t p_stride,
+                    int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu, const void* scale, int64_t p_stride,
                     int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits, int32_t* status,
                     void* stream) {
+    const int spec = cdf_spec == 1 ? 1 : ((cdf_spec == 2 || cdf_spec == 3) && bin_step) ? cdf_spec : 0;
+    if (!spec) return BS_EINVAL;
+    if (spec == 1) bin_step = nullptr;
     if (!head64 || !stack64 || !len64 || !endpoints || !mu || !scale || !sym || !status || B < 0 || D < 0 || cap < 0 ||
         bits < 1 || bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || p_stride < 0)
         return BS_EINVAL;
     if (D > 4096) return BS_EUNSUPPORTED;
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_layer64<float, true>(K, endpoints, e_stride, bin_step, mu, scale, p_stride, sym, nullptr, nullptr, 0,
+        return dispatch_layer64<float, true>(K, spec, endpoints, e_stride, bin_step, mu, scale, p_stride, sym, nullptr, nullptr, 0,
                                              nullptr, head64, stack64, len64, cap, B, D, bits, quantbits, status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_layer64<double, true>(K, endpoints, e_stride, bin_step, mu, scale, p_stride, sym, nullptr, nullptr, 0,
+        return dispatch_layer64<double, true>(K, spec, endpoints, e_stride, bin_step, mu, scale, p_stride, sym, nullptr, nullptr, 0,
                                               nullptr, head64, stack64, len64, cap, B, D, bits, quantbits, status, S(stream));
     return BS_EINVAL;
 }

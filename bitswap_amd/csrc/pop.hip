@@ -300,12 +300,15 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rans_pop_pivot: BS_LAYOUT_PIVOT rows (uniform-width bins, CDF spec 2), one wavefront per chain.
+// k_rans_pop_pivot: BS_LAYOUT_PIVOT rows (uniform-width bins, CDF spec 2 or 3), one wavefront per chain.
 //
 // The table kernel hands over 64 cumulative values per row (one per group of NPL bins) plus which bin took the remnant
 // and how much.  Per symbol: ballot(pivot <= m) names the group L; lanes 0 .. NPL-1 rebuild the cdf of its NPL bins and
-// lane NPL the last cdf of group L-1, each with exactly the operations logistic_row spends on that bin (own anchor
-// exponential, own geometric factor, residual of the stored endpoint, correctly rounded reciprocal) -- the truncated
+// lanes NPL .. 2 NPL-1 those of group L-1 (whose last cdf is what the first bin of L is differenced against), each with
+// exactly the operations logistic_row spends on that bin (own anchor exponential, own geometric factor, residual of the
+// stored endpoint; spec 2: a correctly rounded reciprocal per bin, spec 3: the block's product tree built by a butterfly
+// exchange over its lanes -- IEEE multiplication commutes, so every lane holds the node values the table kernel computed --
+// ONE reciprocal of the root and one multiplication per level back down) -- the truncated
 // differences are therefore the table's, and a 6-step scan on top of the pivot gives c_s and f_s.  About 2.5x the
 // instructions of k_rans_pop_wave per symbol, but 512 B of HBM traffic per row instead of 4352 B: at 400 chains the
 // row-reading pop kernel ran at the HBM roof (3.57 GB per launch in 0.57 ms) and nothing overlapped with it
@@ -322,7 +325,36 @@ __device__ __forceinline__ double wave_shr1_f64(double v) {
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-template <int NPL, typename PT, int PF>
+// 64-bit lane exchange by DPP (two 32-bit moves; every lane of a row has a source, so `old` never shows)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// 1 / x of every lane by CDF spec 3's product tree over aligned blocks of N <= 16 lanes (bitswap_dev.h::tree_inverse, one bin
+// per lane): level k pairs the node of lanes [2^k j', 2^k (j'+1)) with its sibling -- quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror: any lane of the sibling node holds the sibling's value -- and multiplies; the root is inverted
+// once, and on the way down a lane multiplies by the sibling values it met on the way up.
+template <int N>
+__device__ __forceinline__ double tree_inverse_lanes(double x) {
+    static_assert(N == 4 || N == 8 || N == 16, "one block of 4, 8 or 16 lanes");
+    const double w0 = dpp_f64<0xB1>(x);
+    double v = x * w0;
+    const double w1 = dpp_f64<0x4E>(v);
+    v = v * w1;
+    double w2 = 1.0, w3 = 1.0;
+    if (N >= 8) { w2 = dpp_f64<0x141>(v); v = v * w2; }
+    if (N >= 16) { w3 = dpp_f64<0x140>(v); v = v * w3; }
+    double inv = recip_1_to_huge(v);
+    if (N >= 16) inv = inv * w3;
+    if (N >= 8) inv = inv * w2;
+    inv = inv * w1;
+    return inv * w0;
+}
+
+template <int NPL, typename PT, int PF, int SPEC>
 __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ head, uint32_t* __restrict__ stack,
                                                        int32_t* __restrict__ len, int64_t cap,
                                                        const uint32_t* __restrict__ piv, int64_t ld,
@@ -352,12 +384,12 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
     const double M = (double)((1ll << bits) - (1ll << quantbits));
     int st = BS_ST_OK;
     const int64_t ld2 = ld / 2;
-    // this lane's role in the rebuild.  Lanes 0 .. NPL-1: bin `bi` of the symbol's group; lane NPL: the last bin of the group
-    // below it.  With ONE_EXP the upper half-wave evaluates the geometric factors Q_b = exp(-b h/scale) in the same
-    // instructions in which the lower half evaluates the anchors exp(-t_a); lane 32 + k serves lane k.
+    // this lane's role in the rebuild.  Lanes 0 .. NPL-1: bin `bi` of the symbol's group L; lanes NPL .. 2 NPL-1: bin `bi` of
+    // the group below it (its last cdf closes the first bin of L; spec 3 needs the whole group for that one quotient).
+    // With ONE_EXP the upper half-wave evaluates the geometric factors Q_b = exp(-b h/scale) in the same instructions in
+    // which the lower half evaluates the anchors exp(-t_a); lane 32 + k serves lane k (NPL divides 32: same bin index).
     const bool is_bin = lane < NPL;
-    const int role = ONE_EXP ? (lane & 31) : lane;
-    const int bi = role < NPL ? role : NPL - 1;
+    const int bi = lane & (NPL - 1);
     const bool q_lane = ONE_EXP && lane >= 32;
 
     auto stack_window = [&](int top, int off) -> uint32_t {
@@ -394,6 +426,8 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
         const double mu_l = (double)mu[prm], h_l = step[c64 * 64 + lane];
         const double rs_l = recip_scale((double)scale[prm]);
         const double hr_l = h_l * rs_l;
+        // spec 3: which rows of the chunk take the batch inversion (logistic_row's test, one bit per row)
+        const unsigned long long batch_rows = SPEC == 3 ? __ballot((double)NPL * fabs(hr_l) < BS_SPEC3_FAST_HR) : 0ull;
         int o = 0;
         uint32_t mysym = 0;
         for (int g = 64 / PF - 1; g >= 0; --g) {
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                 const uint32_t m = (uint32_t)h & mask;
                 const int L = __popcll(__ballot(pv[u].x <= m)) - 1;          // group of the symbol: 0..63 (c_0 = 0 <= m)
                 const int Lb = max(L - 1, 0);
-                const int j = (is_bin ? L : Lb) * NPL + bi;                  // this lane's bin (lanes 0 .. NPL)
+                const int j = (is_bin ? L : Lb) * NPL + bi;                  // this lane's bin (lanes 0 .. 2 NPL-1)
                 // its upper endpoint: data dependent, requested first, used last
                 const double e_j = erow[min(j, K - 2)];
                 erow -= d > 0 ? e_stride : 0;
@@ -420,23 +454,33 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                 if (dl > 0) { pp -= ld2; ap -= e_stride; }
                 --dl;
                 // logistic_row, one bin per lane
+                const bool batch = SPEC == 3 && ((batch_rows >> dk) & 1ull);   // wave-uniform
+                const double hi = batch ? BS_SPEC3_ANCHOR_HI : 700.0;
                 double A, Q;
                 if (ONE_EXP) {
-                    const double x = det_exp(q_lane ? -((double)bi * hr) : -((e_a - m_) * rs));
+                    const double x = det_exp_hi(q_lane ? -((double)bi * hr) : -((e_a - m_) * rs), hi);
                     A = x;
                     Q = __shfl(x, lane | 32, 64);                            // lane k < 32 <- lane 32 + k
                 } else {
-                    A = det_exp(-((e_a - m_) * rs));
+                    A = det_exp_hi(-((e_a - m_) * rs), hi);
                     Q = det_exp(-((double)bi * hr));
                 }
-                const double r = e_j - fma((double)bi, hstep, e_a);
-                const double eps = r * rs;
-                const double uu = fma(-A, eps, A);
-                double c = recip_1_to_huge(fma(Q, uu, 1.0));
+                double r = e_j - fma((double)bi, hstep, e_a);
+                double c;
+                if (batch) {
+                    if (j == K - 1) r = 0.0;                                 // the K-th, virtual endpoint: on the progression
+                    const double Ars = A * rs;
+                    const double x = fma(Q, fma(-Ars, r, A), 1.0);           // bi == 0: Q = 1, r = 0 -> 1 + A
+                    c = tree_inverse_lanes<(NPL < 16 ? NPL : 16)>(x);
+                } else {
+                    const double eps = r * rs;
+                    const double uu = fma(-A, eps, A);
+                    c = recip_1_to_huge(fma(Q, uu, 1.0));
+                }
                 if (j == K - 1) c = 1.0;                                     // the last bin has no upper endpoint
-                // cdf of the bin below: lane-1 within the group, lane NPL for bin 0, nothing for the very first bin
+                // cdf of the bin below: lane-1 within the group, the last lane of the group below for bin 0, nothing for the very first bin
                 double below = wave_shr1_f64(c);
-                const double c_grp_below = readlane_f64(c, NPL);
+                const double c_grp_below = readlane_f64(c, 2 * NPL - 1);
                 if (lane == 0) below = L == 0 ? 0.0 : c_grp_below;
                 uint32_t f = trunc_u32((c - below) * M) + 1u;
                 if ((uint32_t)j == bumped) f += rem;
@@ -542,7 +586,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_generic(uint64_t* __restrict__ 
 }  // namespace
 
 template <typename PT>
-int dispatch_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* piv, int64_t ld,
+int dispatch_pop_pivot(int spec, uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* piv, int64_t ld,
                        const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale, int B,
                        int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres, int64_t c_stride,
                        float* centre_out, int32_t* status, hipStream_t st) {
@@ -550,8 +594,14 @@ int dispatch_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t ca
     const PT* m = static_cast<const PT*>(mu);
     const PT* s = static_cast<const PT*>(scale);
 #define BS_POPP(NPL, PF)                                                                                              \
-    hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, endpoints, \
-                       e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status)
+    do {                                                                                                              \
+        if (spec == 3)                                                                                                \
+            hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF, 3>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, \
+                               endpoints, e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF, 2>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, \
+                               endpoints, e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status); \
+    } while (0)
     if (K == 256) BS_POPP(4, BS_POP_PF);
     else if (K == 512) BS_POPP(8, BS_POP_PF);
     else if (K == 1024) BS_POPP(16, BS_POP_PF);
@@ -602,20 +652,20 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, cons
 }
 
 int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* pivots, int64_t ld,
-                      const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu, const void* scale,
-                      int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres,
-                      int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
-    if (!head || !stack || !len || !pivots || !endpoints || !bin_step || !mu || !scale || !sym_out || !status || B < 0 ||
+                      const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
+                      const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out,
+                      const double* centres, int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
+    if ((cdf_spec != 2 && cdf_spec != 3) || !head || !stack || !len || !pivots || !endpoints || !bin_step || !mu || !scale || !sym_out || !status || B < 0 ||
         D < 0 || cap < 0 || bits < 1 || bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || c_stride < 0 ||
         (centres && !centre_out) || ld < 128 || ld % 2 || (reinterpret_cast<uintptr_t>(pivots) & 7u))
         return BS_EINVAL;
     if (D % 64 != 0 || D > 16384) return BS_EUNSUPPORTED;      // whole 64-symbol chunks; a chain's symbols fit in LDS
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_pop_pivot<float>(head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
+        return dispatch_pop_pivot<float>(cdf_spec, head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
                                          bits, quantbits, sym_out, centres, c_stride, centre_out, status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_pop_pivot<double>(head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
+        return dispatch_pop_pivot<double>(cdf_spec, head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,
                                           bits, quantbits, sym_out, centres, c_stride, centre_out, status, S(stream));
     return BS_EINVAL;
 }

@@ -4,8 +4,8 @@
 
 namespace {
 
-template <int NPL, typename PT, int MODE, bool UNI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7, 8))) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
+template <int NPL, typename PT, int MODE, int SPEC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC >= 2 ? 4 : 7, 8))) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
                                                   const double* __restrict__ step,
                                                   const PT* __restrict__ mu, const PT* __restrict__ scale,
                                                   const int32_t* __restrict__ sym, int B, int D, int bits,
@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
                                                   uint32_t* __restrict__ out1, int64_t ld,
                                                   int32_t* __restrict__ status) {
     constexpr int K = NPL * 64;
+    constexpr bool UNI = SPEC >= 2;      // CDF specs 2 and 3: rows of uniform-width bins
     __shared__ uint32_t stage[MODE == M_WAVE ? 4 * 64 * (NPL + 1) : 1];   // (M_PIVOT needs no transpose)
     const int lane = threadIdx.x & 63;
     const int d = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
     if (UNI) {
 #pragma unroll
         for (int i = 1; i < NPL; ++i) e[i] = e[i] - fma((double)i, hstep, e[0]);   // residuals r_i; e[0] stays the anchor
+        if (NPL > 1 && lane == 63) e[NPL - 1] = 0.0;   // the K-th, virtual endpoint (its cdf is 1 by definition): on the progression
     }
     // (mu, scale) of the next chain are fetched while the current one is computed: the row is
     // wave-uniform, so these are scalar loads whose latency would otherwise sit in front of every row
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UNI ? 4 : 7
         if (MODE == M_ENCODE) sym_n = sym[nrow];
 
         Bins<NPL> bn;
-        const bool dom = logistic_row<NPL, UNI>(e, hstep, m_, rs, M, lane, bn);
+        const bool dom = logistic_row<NPL, SPEC>(e, hstep, m_, rs, M, lane, bn);
 
         bool bad;
         uint32_t bumped = 0, rem = 0;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void k_table_rows_generic(const double* __rest
 }
 
 template <int NPL, typename PT>
-int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
+int launch_logistic(int mode, int spec, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
                     const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0, uint32_t* out1,
                     int64_t ld, int32_t* status, hipStream_t st) {
     // chains per wavefront: amortise the endpoint fetch (8 KB of L2 reads per row at K = 1024: with one chain per wavefront the
@@ -236,37 +238,46 @@ int launch_logistic(int mode, const double* endpoints, int64_t e_stride, const d
     // wavefront make the launch's tail too coarse when it shares the chip.
     int nb = 8;
     while (nb > 1 && (int64_t)((D + 3) / 4) * ((B + nb - 1) / nb) < 2048) nb >>= 1;
-    static const int nb_env = [] { const char* e = getenv("BITSWAP_TABLE_NB"); return e ? atoi(e) : 0; }();   // tuning only
-    if (nb_env > 0) nb = nb_env;
+    const char* nb_env = getenv("BITSWAP_TABLE_NB");   // tuning only; read per launch (tools flip it between launches)
+    if (nb_env && atoi(nb_env) > 0) nb = atoi(nb_env);
     dim3 grid((D + 3) / 4, (B + nb - 1) / nb), block(256);
     const PT* m = static_cast<const PT*>(mu);
     const PT* s = static_cast<const PT*>(scale);
-#define BS_LAUNCH(MODE, UNI)                                                                                     \
-    hipLaunchKernelGGL((k_logistic<NPL, PT, MODE, UNI>), grid, block, 0, st, endpoints, e_stride, step, m, s, sym, B, D, \
+#define BS_LAUNCH(MODE, SPEC)                                                                                     \
+    hipLaunchKernelGGL((k_logistic<NPL, PT, MODE, SPEC>), grid, block, 0, st, endpoints, e_stride, step, m, s, sym, B, D, \
                        bits, quantbits, nb, out0, out1, ld, status)
-    if (step) {  // CDF spec 2 (uniform bins); host dispatch guarantees NPL >= 4
-        if (mode == M_PIVOT) BS_LAUNCH((NPL >= 4 ? M_PIVOT : M_LINEAR), (NPL >= 4));
-        else if (mode == M_WAVE) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR), (NPL >= 4));
-        else if (mode == M_LINEAR_VEC) BS_LAUNCH((NPL >= 4 ? M_LINEAR_VEC : M_LINEAR), (NPL >= 4));
-        else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, (NPL >= 4));
-        else BS_LAUNCH(M_LINEAR, (NPL >= 4));
-    } else if (mode == M_WAVE && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_WAVE : M_LINEAR), false);
-    else if (mode == M_LINEAR_VEC && NPL >= 4) BS_LAUNCH((NPL >= 4 ? M_LINEAR_VEC : M_LINEAR), false);
-    else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, false);
-    else BS_LAUNCH(M_LINEAR, false);
+    // specs 2 / 3 (uniform bins): host dispatch guarantees NPL >= 4; the layouts of the pop kernels need NPL >= 4 as well
+    constexpr int S2 = NPL >= 4 ? 2 : 1, S3 = NPL >= 4 ? 3 : 1;
+    constexpr int MP = NPL >= 4 ? M_PIVOT : M_LINEAR, MW = NPL >= 4 ? M_WAVE : M_LINEAR, MV = NPL >= 4 ? M_LINEAR_VEC : M_LINEAR;
+#define BS_BY_MODE(SPEC)                                   \
+    do {                                                   \
+        if (mode == M_PIVOT) BS_LAUNCH(MP, SPEC);          \
+        else if (mode == M_WAVE) BS_LAUNCH(MW, SPEC);      \
+        else if (mode == M_LINEAR_VEC) BS_LAUNCH(MV, SPEC); \
+        else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, SPEC); \
+        else BS_LAUNCH(M_LINEAR, SPEC);                    \
+    } while (0)
+    if (spec == 3) BS_BY_MODE(S3);
+    else if (spec == 2) BS_BY_MODE(S2);
+    else if (mode == M_WAVE && NPL >= 4) BS_LAUNCH(MW, 1);
+    else if (mode == M_LINEAR_VEC && NPL >= 4) BS_LAUNCH(MV, 1);
+    else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, 1);
+    else BS_LAUNCH(M_LINEAR, 1);
+#undef BS_BY_MODE
 #undef BS_LAUNCH
     return launch_rc();
 }
 
+// spec: the CDF specification (1: any bins, step ignored; 2 / 3: uniform-width bins, step required, K >= 256)
 template <typename PT>
-int dispatch_logistic(int K, int mode, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
+int dispatch_logistic(int K, int mode, int spec, const double* endpoints, int64_t e_stride, const double* step, const void* mu, const void* scale,
                       const int32_t* sym, int B, int D, int bits, int quantbits, uint32_t* out0, uint32_t* out1,
                       int64_t ld, int32_t* status, hipStream_t st) {
 #define BS_CASE(NPL)                                                                                             \
     case 64 * NPL:                                                                                               \
-        return launch_logistic<NPL, PT>(mode, endpoints, e_stride, step, mu, scale, sym, B, D, bits, quantbits, out0, \
+        return launch_logistic<NPL, PT>(mode, spec, endpoints, e_stride, step, mu, scale, sym, B, D, bits, quantbits, out0, \
                                         out1, ld, status, st)
-    if (step && K < 256) return BS_EUNSUPPORTED;  // CDF spec 2 is defined for K >= 256 (groups of K/64 >= 4 bins)
+    if (spec != 1 && K < 256) return BS_EUNSUPPORTED;  // CDF specs 2 / 3 are defined for K >= 256 (groups of K/64 >= 4 bins)
     switch (K) {
         BS_CASE(1);
         BS_CASE(2);
@@ -278,6 +289,13 @@ int dispatch_logistic(int K, int mode, const double* endpoints, int64_t e_stride
             return BS_EUNSUPPORTED;
     }
 #undef BS_CASE
+}
+
+// cdf_spec argument of the C ABI -> 1 / 2 / 3, or 0 when it contradicts bin_step
+inline int checked_spec(int cdf_spec, const double* bin_step) {
+    if (cdf_spec == 1) return 1;                                  // bin_step is ignored
+    if ((cdf_spec == 2 || cdf_spec == 3) && bin_step) return cdf_spec;
+    return 0;
 }
 
 }  // namespace
@@ -306,12 +324,14 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
     return launch_rc();
 }
 
-int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
                        const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits,
                        uint32_t* cdf_out, int64_t ld, int layout, int32_t* status, void* stream) {
+    const int spec = checked_spec(cdf_spec, bin_step);
     if (!endpoints || !mu || !scale || !cdf_out || B < 0 || D < 0 || bits < 1 || bits > 31 || quantbits < 0 ||
-        quantbits >= bits || e_stride < 0)
+        quantbits >= bits || e_stride < 0 || !spec)
         return BS_EINVAL;
+    if (spec == 1) bin_step = nullptr;
     int mode;
     if (layout == BS_LAYOUT_LINEAR) {
         if (ld < K + 1) return BS_EINVAL;
@@ -319,7 +339,7 @@ int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* 
     } else if (layout == BS_LAYOUT_WAVE) {
         if (ld < K + 64 || K < 256) return BS_EINVAL;
         mode = M_WAVE;
-    } else if (layout == BS_LAYOUT_PIVOT) {      // 64 x (cumulative value, aux) per row: uniform bins (spec 2) only
+    } else if (layout == BS_LAYOUT_PIVOT) {      // 64 x (cumulative value, aux) per row: uniform bins (specs 2 / 3) only
         if (ld < 128 || ld % 2 || K < 256 || !bin_step || (reinterpret_cast<uintptr_t>(cdf_out) & 7u)) return BS_EINVAL;
         mode = M_PIVOT;
     } else {
@@ -327,26 +347,28 @@ int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* 
     }
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_logistic<float>(K, mode, endpoints, e_stride, bin_step, mu, scale, nullptr, B, D, bits, quantbits,
+        return dispatch_logistic<float>(K, mode, spec, endpoints, e_stride, bin_step, mu, scale, nullptr, B, D, bits, quantbits,
                                         cdf_out, nullptr, ld, status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_logistic<double>(K, mode, endpoints, e_stride, bin_step, mu, scale, nullptr, B, D, bits, quantbits,
+        return dispatch_logistic<double>(K, mode, spec, endpoints, e_stride, bin_step, mu, scale, nullptr, B, D, bits, quantbits,
                                          cdf_out, nullptr, ld, status, S(stream));
     return BS_EINVAL;
 }
 
-int bs_logistic_fc(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu, const void* scale,
-                   int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits, uint32_t* f_out,
-                   uint32_t* c_out, int32_t* status, void* stream) {
+int bs_logistic_fc(const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
+                   const void* scale, int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits,
+                   uint32_t* f_out, uint32_t* c_out, int32_t* status, void* stream) {
+    const int spec = checked_spec(cdf_spec, bin_step);
     if (!endpoints || !mu || !scale || !sym || !f_out || !c_out || !status || B < 0 || D < 0 || bits < 1 ||
-        bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0)
+        bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || !spec)
         return BS_EINVAL;
+    if (spec == 1) bin_step = nullptr;
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
-        return dispatch_logistic<float>(K, M_ENCODE, endpoints, e_stride, bin_step, mu, scale, sym, B, D, bits, quantbits,
+        return dispatch_logistic<float>(K, M_ENCODE, spec, endpoints, e_stride, bin_step, mu, scale, sym, B, D, bits, quantbits,
                                         f_out, c_out, 0, status, S(stream));
     if (param_dtype == BS_PARAM_F64)
-        return dispatch_logistic<double>(K, M_ENCODE, endpoints, e_stride, bin_step, mu, scale, sym, B, D, bits, quantbits,
+        return dispatch_logistic<double>(K, M_ENCODE, spec, endpoints, e_stride, bin_step, mu, scale, sym, B, D, bits, quantbits,
                                          f_out, c_out, 0, status, S(stream));
     return BS_EINVAL;
 }

@@ -10,7 +10,7 @@ import torch
 
 from . import build as _build
 
-ABI_VERSION = 5   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
+ABI_VERSION = 6   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
 PARAM_F32, PARAM_F64 = 0, 1
@@ -55,15 +55,15 @@ def load():
     L.bs_strerror.restype = C.c_char_p
     L.bs_strerror.argtypes = [i32]
     L.bs_table_rows_f64.argtypes = [p, i64, i32, i32, i32, p, p, i64, p, p]
-    L.bs_logistic_tables.argtypes = [p, i64, p, p, p, i32, i32, i32, i32, i32, i32, p, i64, i32, p, p]
-    L.bs_logistic_fc.argtypes = [p, i64, p, p, p, i32, p, i32, i32, i32, i32, i32, p, p, p, p]
+    L.bs_logistic_tables.argtypes = [p, i64, p, i32, p, p, i32, i32, i32, i32, i32, i32, p, i64, i32, p, p]
+    L.bs_logistic_fc.argtypes = [p, i64, p, i32, p, p, i32, p, i32, i32, i32, i32, i32, p, p, p, p]
     L.bs_rans_push.argtypes = [p, p, p, i64, p, p, i32, i32, i32, p, p]
     L.bs_rans_push_table.argtypes = [p, p, p, i64, p, i64, i64, i32, p, i32, i32, i32, i32, p, p]
     L.bs_rans_pop.argtypes = [p, p, p, i64, p, i64, i64, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
-    L.bs_rans_pop_pivot.argtypes = [p, p, p, i64, p, i64, p, i64, p, p, p, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
+    L.bs_rans_pop_pivot.argtypes = [p, p, p, i64, p, i64, p, i64, p, i32, p, p, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
     L.bs_gather_centres.argtypes = [p, i64, p, i32, i32, i32, p, p]
-    L.bs_layer_pop64.argtypes = [p, p, p, i64, p, i64, p, p, p, i64, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
-    L.bs_layer_push64.argtypes = [p, p, p, i64, p, i64, p, p, p, i64, i32, p, i32, i32, i32, i32, i32, p, p]
+    L.bs_layer_pop64.argtypes = [p, p, p, i64, p, i64, p, i32, p, p, i64, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
+    L.bs_layer_push64.argtypes = [p, p, p, i64, p, i64, p, i32, p, p, i64, i32, p, i32, i32, i32, i32, i32, p, p]
     L.bs_selftest.argtypes = [C.POINTER(C.c_int64), p]
     L.bs_sigmoid_f64.argtypes = [p, i64, p, p]
     L.bs_bias_residual_elu_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
@@ -195,39 +195,58 @@ def _step(step, D):
     return step
 
 
+UNIFORM_CDF_SPEC = 3     # CDF spec of rows of uniform-width bins when the caller names none (include/bitswap_hip.h BS_CDF_SPEC)
+
+
+def _spec(step, spec):
+    """The `cdf_spec` argument of the C ABI: 1 without bin widths; with them 2 or 3 as asked (default UNIFORM_CDF_SPEC).
+    Sender and receiver must make the same choice: the codec records it in the stream fingerprint (meta.py)."""
+    if step is None:
+        if spec not in (None, 1):
+            raise BitswapHipError(f"CDF spec {spec} needs the bin widths (step)")
+        return 1
+    spec = UNIFORM_CDF_SPEC if spec is None else int(spec)
+    if spec not in (2, 3):
+        raise BitswapHipError(f"CDF spec {spec} is not one of the uniform-bin specifications (2, 3)")
+    return spec
+
+
 def logistic_tables(endpoints, mu, scale, bits=31, quantbits=10, ld=None, out=None, layout=LAYOUT_LINEAR, step=None,
-                    status=None):
+                    status=None, spec=None):
     """Fused CDF -> integer cdf rows.  endpoints [D,K-1] f64, mu/scale [B,D] -> cdf [B,D,ld] int32.
     layout=LAYOUT_WAVE writes the wave-native hand-off format (ld = K+64) that rans_pop searches
     with two ballots; the returned tensor remembers its layout (`bs_layout`).  step [D] f64 (bins.uniform_step)
-    selects CDF spec 2 for uniform-width bins; status [B] int32 receives BS_ST_BADTABLE for degenerate parameters."""
+    selects the CDF specs of uniform-width bins (`spec` 2 or 3, default UNIFORM_CDF_SPEC); status [B] int32 receives
+    BS_ST_BADTABLE for degenerate parameters."""
     _need_cuda(endpoints, mu, scale, step, status)
     B, D = mu.shape
     K = endpoints.shape[1] + 1
     endpoints, es = _row_stride(endpoints, K - 1)
     step = _step(step, D)
+    spec = _spec(step, spec)
     mu, scale = mu.contiguous(), scale.contiguous()
     if out is not None:
         ld = out.shape[-1]
     ld = ld or (wave_ld(K) if layout == LAYOUT_WAVE else PIVOT_LD if layout == LAYOUT_PIVOT else aligned_ld(K))
     if out is None:
         out = torch.empty((B, D, ld), dtype=torch.int32, device=mu.device)
-    _check(load().bs_logistic_tables(_ptr(endpoints), es, _ptr(step), _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K,
+    _check(load().bs_logistic_tables(_ptr(endpoints), es, _ptr(step), spec, _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K,
                                      bits, quantbits, _ptr(out), ld, layout, _ptr(status), _stream()),
            "bs_logistic_tables")
     out.bs_layout = layout
     if layout == LAYOUT_PIVOT:      # the pop kernel rebuilds rows from what the table kernel saw: keep it with the hand-off
-        out.bs_pivot_args = (endpoints, es, step, mu, scale, quantbits)
+        out.bs_pivot_args = (endpoints, es, step, spec, mu, scale, quantbits)
     return out
 
 
-def logistic_fc(endpoints, mu, scale, sym, status, bits=31, quantbits=10, out=None, step=None):
+def logistic_fc(endpoints, mu, scale, sym, status, bits=31, quantbits=10, out=None, step=None, spec=None):
     """Fused CDF -> (f, c) of the given symbols.  sym [B,D] int32 -> f, c [B,D] int32."""
     _need_cuda(endpoints, mu, scale, sym, status, step)
     B, D = mu.shape
     K = endpoints.shape[1] + 1
     endpoints, es = _row_stride(endpoints, K - 1)
     step = _step(step, D)
+    spec = _spec(step, spec)
     mu, scale = mu.contiguous(), scale.contiguous()
     sym = sym.contiguous()
     if sym.dtype != torch.int32:
@@ -237,7 +256,7 @@ def logistic_fc(endpoints, mu, scale, sym, status, bits=31, quantbits=10, out=No
         c = torch.empty((B, D), dtype=torch.int32, device=mu.device)
     else:
         f, c = out
-    _check(load().bs_logistic_fc(_ptr(endpoints), es, _ptr(step), _ptr(mu), _ptr(scale), _param_dtype(mu), _ptr(sym), B,
+    _check(load().bs_logistic_fc(_ptr(endpoints), es, _ptr(step), spec, _ptr(mu), _ptr(scale), _param_dtype(mu), _ptr(sym), B,
                                  D, K, bits, quantbits, _ptr(f), _ptr(c), _ptr(status), _stream()), "bs_logistic_fc")
     return f, c
 
@@ -365,7 +384,7 @@ def rans_pop_pivot(state, piv, K, bits=31, centres=None):
     """Pop D symbols per chain from BS_LAYOUT_PIVOT rows made by logistic_tables(layout=LAYOUT_PIVOT): the kernel rebuilds
     the symbol's group of bins from the (endpoints, step, mu, scale) the table kernel used (remembered on `piv`).
     Returns (sym [B,D] int32, z [B,D] float32 | None)."""
-    endpoints, es, step, mu, scale, quantbits = piv.bs_pivot_args
+    endpoints, es, step, spec, mu, scale, quantbits = piv.bs_pivot_args
     _need_cuda(piv, centres, endpoints, step, mu, scale)
     assert piv.is_contiguous() and piv.dim() == 3
     B, D, ld = piv.shape
@@ -375,7 +394,7 @@ def rans_pop_pivot(state, piv, K, bits=31, centres=None):
         centres, cs = _row_stride(centres, K)
         z = torch.empty((B, D), dtype=torch.float32, device=piv.device)
     _check(load().bs_rans_pop_pivot(_ptr(state.head), _ptr(state.stack), _ptr(state.len), state.cap, _ptr(piv), ld,
-                                    _ptr(endpoints), es, _ptr(step), _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K, bits,
+                                    _ptr(endpoints), es, _ptr(step), spec, _ptr(mu), _ptr(scale), _param_dtype(mu), B, D, K, bits,
                                     quantbits, _ptr(sym), _ptr(centres), cs, _ptr(z), _ptr(state.status), _stream()),
            "bs_rans_pop_pivot")
     return sym, z
@@ -480,7 +499,7 @@ def _layer64_args(state, endpoints, mu, scale, step):
     return B, D, K, endpoints, es, step, mu, scale, ps
 
 
-def layer_pop64(state, endpoints, mu, scale, bits=31, quantbits=10, centres=None, step=None):
+def layer_pop64(state, endpoints, mu, scale, bits=31, quantbits=10, centres=None, step=None, spec=None):
     """64-state format: logistic CDF -> integer table -> pop, one launch; mu/scale [B,D] or [D] / [1,D] (one row set
     shared by all chains: the prior).  -> (sym [B,D] int32, z [B,D] float32 | None)."""
     _need_cuda(endpoints, mu, scale, centres, step, state.head)
@@ -491,12 +510,12 @@ def layer_pop64(state, endpoints, mu, scale, bits=31, quantbits=10, centres=None
         centres, cs = _row_stride(centres, K)
         z = torch.empty((B, D), dtype=torch.float32, device=mu.device)
     _check(load().bs_layer_pop64(_ptr(state.head), _ptr(state.stack), _ptr(state.len64), state.cap, _ptr(endpoints), es,
-                                 _ptr(step), _ptr(mu), _ptr(scale), ps, _param_dtype(mu), B, D, K, bits, quantbits,
+                                 _ptr(step), _spec(step, spec), _ptr(mu), _ptr(scale), ps, _param_dtype(mu), B, D, K, bits, quantbits,
                                  _ptr(sym), _ptr(centres), cs, _ptr(z), _ptr(state.status), _stream()), "bs_layer_pop64")
     return sym, z
 
 
-def layer_push64(state, endpoints, mu, scale, sym, bits=31, quantbits=10, step=None):
+def layer_push64(state, endpoints, mu, scale, sym, bits=31, quantbits=10, step=None, spec=None):
     _need_cuda(endpoints, mu, scale, sym, step, state.head)
     B, D, K, endpoints, es, step, mu, scale, ps = _layer64_args(state, endpoints, mu, scale, step)
     sym = sym.contiguous()
@@ -505,7 +524,7 @@ def layer_push64(state, endpoints, mu, scale, sym, bits=31, quantbits=10, step=N
     if tuple(sym.shape) != (B, D):
         raise BitswapHipError(f"sym must be [{B},{D}]")
     _check(load().bs_layer_push64(_ptr(state.head), _ptr(state.stack), _ptr(state.len64), state.cap, _ptr(endpoints), es,
-                                  _ptr(step), _ptr(mu), _ptr(scale), ps, _param_dtype(mu), _ptr(sym), B, D, K, bits,
+                                  _ptr(step), _spec(step, spec), _ptr(mu), _ptr(scale), ps, _param_dtype(mu), _ptr(sym), B, D, K, bits,
                                   quantbits, _ptr(state.status), _stream()), "bs_layer_push64")
 
 

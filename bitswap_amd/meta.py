@@ -45,7 +45,8 @@ def fingerprint(codec, chains_per_call=None):
     m = codec.model
     fp = {"stream_format": "wave64" if getattr(codec.backend, "name", "").endswith("wave64") else "reference",
           "ansbits": int(codec.bits), "quantbits": int(codec.q), "bitswap": bool(codec.bitswap),
-          "cdf_spec": {"z": [2 if s is not None else 1 for s in codec.zstep], "x": 2 if codec.xstep is not None else 1},
+          "cdf_spec": {"z": [int(codec.cdf_spec) if s is not None else 1 for s in codec.zstep],
+                       "x": int(codec.cdf_spec) if codec.xstep is not None else 1},
           "library_abi": int(hip.ABI_VERSION), "backend": getattr(codec.backend, "name", "?"), "conv_route": route(m)}
     if not batch_invariant(fp) and chains_per_call is not None:
         # (a list: chains per call of every rank of an unevenly sharded multi-process run -- 5 experiments on 3 ranks code 2, 2

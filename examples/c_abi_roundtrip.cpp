@@ -84,12 +84,12 @@ int main() {
     HIP_OK(hipMalloc(&d_sym, (size_t)B * D * 4));
     HIP_OK(hipMalloc(&d_z, (size_t)B * D * 4));
 
-    BS_OKAY(bs_logistic_tables(d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, B, D, K, bits, q, d_cdf, ld, BS_LAYOUT_WAVE,
+    BS_OKAY(bs_logistic_tables(d_e, K - 1, d_step, BS_CDF_SPEC, d_mu, d_sc, BS_PARAM_F32, B, D, K, bits, q, d_cdf, ld, BS_LAYOUT_WAVE,
                                d_status, stream));
     BS_OKAY(bs_rans_pop(d_head, d_stack, d_len, cap, d_cdf, (int64_t)D * ld, ld, BS_LAYOUT_WAVE, B, D, K, bits, d_sym, d_cen, K,
                         d_z, d_status, stream));
     auto len_after_pop = to_host(d_len, B);
-    BS_OKAY(bs_logistic_fc(d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, d_sym, B, D, K, bits, q, d_f, d_c, d_status, stream));
+    BS_OKAY(bs_logistic_fc(d_e, K - 1, d_step, BS_CDF_SPEC, d_mu, d_sc, BS_PARAM_F32, d_sym, B, D, K, bits, q, d_f, d_c, d_status, stream));
     BS_OKAY(bs_rans_push(d_head, d_stack, d_len, cap, d_f, d_c, B, D, bits, d_status, stream));
     HIP_OK(hipStreamSynchronize(stream));
     int bad = 0;
@@ -113,11 +113,11 @@ int main() {
         int32_t* d_sym2;
         HIP_OK(hipMalloc(&d_piv, (size_t)B * D * ldp * 4));
         HIP_OK(hipMalloc(&d_sym2, (size_t)B * D * 4));
-        BS_OKAY(bs_logistic_tables(d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, B, D, K, bits, q, d_piv, ldp, BS_LAYOUT_PIVOT,
+        BS_OKAY(bs_logistic_tables(d_e, K - 1, d_step, BS_CDF_SPEC, d_mu, d_sc, BS_PARAM_F32, B, D, K, bits, q, d_piv, ldp, BS_LAYOUT_PIVOT,
                                    d_status, stream));
-        BS_OKAY(bs_rans_pop_pivot(d_head, d_stack, d_len, cap, d_piv, ldp, d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, B, D, K,
+        BS_OKAY(bs_rans_pop_pivot(d_head, d_stack, d_len, cap, d_piv, ldp, d_e, K - 1, d_step, BS_CDF_SPEC, d_mu, d_sc, BS_PARAM_F32, B, D, K,
                                   bits, q, d_sym2, d_cen, K, d_z, d_status, stream));
-        BS_OKAY(bs_logistic_fc(d_e, K - 1, d_step, d_mu, d_sc, BS_PARAM_F32, d_sym2, B, D, K, bits, q, d_f, d_c, d_status, stream));
+        BS_OKAY(bs_logistic_fc(d_e, K - 1, d_step, BS_CDF_SPEC, d_mu, d_sc, BS_PARAM_F32, d_sym2, B, D, K, bits, q, d_f, d_c, d_status, stream));
         BS_OKAY(bs_rans_push(d_head, d_stack, d_len, cap, d_f, d_c, B, D, bits, d_status, stream));
         HIP_OK(hipStreamSynchronize(stream));
         auto sym2 = to_host(d_sym2, (size_t)B * D);
@@ -141,9 +141,9 @@ int main() {
     uint32_t* d_stack64 = to_device(stack64);
     int32_t* d_len64 = to_device(len64);
     HIP_OK(hipMemset(d_status, 0, B * 4));
-    BS_OKAY(bs_layer_pop64(d_head64, d_stack64, d_len64, cap64, d_e, K - 1, d_step, d_mu, d_sc, D, BS_PARAM_F32, B, D, K, bits, q,
+    BS_OKAY(bs_layer_pop64(d_head64, d_stack64, d_len64, cap64, d_e, K - 1, d_step, BS_CDF_SPEC, d_mu, d_sc, D, BS_PARAM_F32, B, D, K, bits, q,
                            d_sym, d_cen, K, d_z, d_status, stream));
-    BS_OKAY(bs_layer_push64(d_head64, d_stack64, d_len64, cap64, d_e, K - 1, d_step, d_mu, d_sc, D, BS_PARAM_F32, d_sym, B, D, K,
+    BS_OKAY(bs_layer_push64(d_head64, d_stack64, d_len64, cap64, d_e, K - 1, d_step, BS_CDF_SPEC, d_mu, d_sc, D, BS_PARAM_F32, d_sym, B, D, K,
                             bits, q, d_status, stream));
     HIP_OK(hipStreamSynchronize(stream));
     auto h64 = to_host(d_head64, (size_t)B * 64);

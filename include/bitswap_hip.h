@@ -40,16 +40,23 @@ extern "C" {
 
 /* 2: layout argument, BS_LAYOUT_WAVE pivot words, conv-stack epilogue entry points
  * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop64 / _push64
- * 4: BS_LAYOUT_PIVOT and bs_rans_pop_pivot (64 cumulative values per row instead of the whole row) */
-#define BS_ABI_VERSION 5
+ * 4: BS_LAYOUT_PIVOT and bs_rans_pop_pivot (64 cumulative values per row instead of the whole row)
+ * 6: explicit cdf_spec argument (after bin_step) of bs_logistic_tables / _fc, bs_rans_pop_pivot, bs_layer_pop64 / _push64;
+ *    CDF spec 3 */
+#define BS_ABI_VERSION 6
 /* highest version of the deterministic logistic-CDF specification this library implements;
  * a stream written with one CDF spec can only be decoded with the same one.
- *   spec 1: one float64 sigmoid per bin endpoint (bin_step == NULL); any bins.
- *   spec 2: rows of UNIFORM-width bins (bin_step != NULL, K >= 256): one exponential per group of K/64 bins
+ *   spec 1: one float64 sigmoid per bin endpoint; any bins.
+ *   spec 2: rows of UNIFORM-width bins (bin_step required, K >= 256): one exponential per group of K/64 bins
  *           and a geometric factor per bin; same endpoints, agrees with spec 1 to a few ulp of the cdf.  Defined for
  *           rows with (K/64) * bin_step / scale < 650 (the geometric factors must stay clear of the exponential's clamp:
- *           scale > 5e-5 for the pixel bins, 20x under the reference's floor); a row outside flags BS_ST_BADTABLE. */
-#define BS_CDF_SPEC 2
+ *           scale > 5e-5 for the pixel bins, 20x under the reference's floor); a row outside flags BS_ST_BADTABLE.
+ *   spec 3: spec 2's denominators 1 + E, inverted per block of min(K/64, 16) bins through a balanced product tree with ONE
+ *           correctly rounded reciprocal (54 instead of 144 issue slots per 16 bins); rows with (K/64) * bin_step / scale
+ *           >= 8 (peaked pixel rows) are spec 2's bit for bit.  Same domain as spec 2; the default of the codec since round 5.
+ * Every table-building entry point takes `cdf_spec` (1, 2 or 3) next to `bin_step`: 1 ignores bin_step; 2 and 3 need it
+ * (BS_EINVAL otherwise).  The oracle's C restatements: oracle/bitswap_oracle.c::orc_det_sigmoid / det2_row_cdf / det3_row_cdf. */
+#define BS_CDF_SPEC 3
 
 #define BS_OK 0
 #define BS_EINVAL (-1)       /* bad argument (null pointer, negative size, ld < K+1 ...)   */
@@ -75,7 +82,7 @@ extern "C" {
  *                     + (j/64)%4), followed at [K, K+64) by the pivot words: word r = c_{64r} for
  *                     r < K/64, word K/64 = c_K = 2^bits, the remaining words 0xffffffff.
  *   BS_LAYOUT_PIVOT   internal hand-off format between bs_logistic_tables and bs_rans_pop_pivot for rows of
- *                     uniform-width bins (CDF spec 2, bin_step != NULL, K = 256*n; ld >= 128 even, 8-byte aligned rows):
+ *                     uniform-width bins (CDF spec 2 or 3, bin_step != NULL, K = 256*n; ld >= 128 even, 8-byte aligned rows):
  *                     64 pairs of words; pair l = (c_{l K/64}, aux_l) -- the cumulative value at the first bin of group
  *                     l -- with aux_0 = the bin that took the remnant 2^bits - sum f (mnist_compress.py:36) and aux_1 =
  *                     that remnant.  512 bytes per row cross HBM instead of 4 (K + 64): the popping wavefront rebuilds
@@ -107,10 +114,10 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
  *              all equal, may pass e_stride = 0).
  *   mu, scale [B,D] of param_dtype (the reference's Model emits float32 and casts up,
  *              model/mnist_train.py:375-376; both are converted to f64 exactly).
- *   bin_step:  NULL selects CDF spec 1.  Otherwise [D] doubles, the bin width h_d = (e[d][K-2] - e[d][0]) / (K-2)
- *              of rows whose endpoints are an arithmetic progression up to rounding (every latent layer but
- *              the top one: discretization.py:81-83,105-118) and selects CDF spec 2 (K >= 256).  The caller
- *              decides from the bins alone, so sender and receiver agree.
+ *   bin_step:  [D] doubles, the bin width h_d = (e[d][K-2] - e[d][0]) / (K-2) of rows whose endpoints are an arithmetic
+ *              progression up to rounding (every latent layer but the top one: discretization.py:81-83,105-118);
+ *              required by CDF specs 2 and 3 (K >= 256), ignored (may be NULL) by spec 1.
+ *   cdf_spec:  1, 2 or 3 (BS_CDF_SPEC above).  The caller decides from the bins alone, so sender and receiver agree.
  *   cdf_out [B,D,ld] in `layout` (BS_LAYOUT_LINEAR, BS_LAYOUT_WAVE or BS_LAYOUT_PIVOT).
  *   status [B] (nullable) receives BS_ST_BADTABLE for a chain with a non-finite mu, a scale that is not a
  *              positive finite number, or a row whose remnant drives a frequency below 1 (mnist_compress.py:46-47).
@@ -118,7 +125,7 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
  * it agrees with torch.sigmoid to a few ulp, everything after it is exact integer work.
  * K must be 64*n, n in {1,2,4,8,16,32}.
  */
-int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
                        const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits,
                        uint32_t* cdf_out, int64_t ld, int layout, int32_t* status, void* stream);
 
@@ -127,9 +134,9 @@ int bs_logistic_tables(const double* endpoints, int64_t e_stride, const double* 
  * (chain, dim) emit only its frequency f and cumulative start c (what ANS.encode reads at
  * mnist_compress.py:51,55); no table is written.
  *   sym [B,D] int32; f_out, c_out [B,D] uint32; status [B] receives BS_ST_BADSYMBOL / BS_ST_BADTABLE.
- *   bin_step as in bs_logistic_tables (must be the same choice on both sides of a stream).
+ *   bin_step, cdf_spec as in bs_logistic_tables (must be the same choice on both sides of a stream).
  */
-int bs_logistic_fc(const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+int bs_logistic_fc(const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
                    const void* scale, int param_dtype, const int32_t* sym, int B, int D, int K, int bits,
                    int quantbits, uint32_t* f_out, uint32_t* c_out, int32_t* status, void* stream);
 
@@ -170,11 +177,11 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
  * bs_rans_pop_pivot -- bs_rans_pop on BS_LAYOUT_PIVOT rows (the production pair of the batched codec for every table
  * of uniform-width bins): the same ANS.decode (mnist_compress.py:58-68), the same symbols and words; the integer row of
  * a symbol's group is rebuilt inside the kernel with the operations bs_logistic_tables spent on it (the SAME endpoints,
- * bin_step, mu, scale, bits, quantbits must be passed), so only 64 cumulative values per row travel through HBM.
+ * bin_step, cdf_spec (2 or 3), mu, scale, bits, quantbits must be passed), so only 64 cumulative values per row travel through HBM.
  * pivots [B,D,ld] as written by bs_logistic_tables(layout = BS_LAYOUT_PIVOT); D % 64 == 0, D <= 16384.
  */
 int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* pivots, int64_t ld,
-                      const double* endpoints, int64_t e_stride, const double* bin_step, const void* mu,
+                      const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
                       const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits,
                       int32_t* sym_out, const double* centres, int64_t c_stride, float* centre_out, int32_t* status,
                       void* stream);
@@ -195,11 +202,11 @@ int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap
  * status [B]: BS_ST_UNDERFLOW / OVERFLOW / BADTABLE / BADSYMBOL, sticky, whichever state of the chain reports first.
  */
 int bs_layer_pop64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t cap, const double* endpoints,
-                   int64_t e_stride, const double* bin_step, const void* mu, const void* scale, int64_t p_stride,
+                   int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu, const void* scale, int64_t p_stride,
                    int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres,
                    int64_t c_stride, float* centre_out, int32_t* status, void* stream);
 int bs_layer_push64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t cap, const double* endpoints,
-                    int64_t e_stride, const double* bin_step, const void* mu, const void* scale, int64_t p_stride,
+                    int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu, const void* scale, int64_t p_stride,
                     int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits, int32_t* status,
                     void* stream);
 

@@ -91,14 +91,19 @@ class OracleBackend:
         return np.ascontiguousarray(h) if np.all(dev <= lim[:, None]) else None
 
     def bin_step(self, endpoints):
-        """Same decision as HipBackend.bin_step; only the deterministic mode has a spec 2 -- the libm / torch modes
-        restate the reference formula and ignore it."""
+        """Same decision as HipBackend.bin_step; only the deterministic mode has the uniform-bin specs 2 / 3 -- the libm /
+        torch modes restate the reference formula and ignore them."""
         if self.mode != O.MODE_DET or endpoints.shape[1] + 1 < 256:
             return None
         return self.uniform_step(endpoints)
 
+    # CDF specification of tables of uniform-width bins (2 or 3); the codec sets it from its cdf_spec, like HipBackend's
+    cdf_spec = 3
+
     def _mode(self, step):
-        return O.MODE_DET2 if (step is not None and self.mode == O.MODE_DET) else self.mode
+        if step is not None and self.mode == O.MODE_DET:
+            return O.MODE_DET3 if self.cdf_spec == 3 else O.MODE_DET2
+        return self.mode
 
     @staticmethod
     def _torch_cdf_rows(e, mu, scale, bits, q):

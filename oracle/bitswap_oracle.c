@@ -119,6 +119,78 @@ static int det2_row_cdf(const double* e, double h, double mu, double scale, int 
     return ok;
 }
 
+/* det_exp with the upper clamp of CDF spec 3's anchors: exp(min(max(a, -700), hi)) */
+static double det_exp_hi(double a, double hi) {
+    a = fmin(fmax(a, -700.0), hi);
+    double kd = rint(a * DET_LOG2E);
+    double r = fma(-kd, DET_LN2_HI, a);
+    r = fma(-kd, DET_LN2_LO, r);
+    double p = DET_C[11];
+    for (int i = 10; i >= 0; --i) p = fma(p, r, DET_C[i]);
+    return p * det_pow2((int)kd);
+}
+
+/*
+ * BS_CDF_SPEC 3 (mode 3) -- spec 2 with ONE reciprocal per block of up to 16 bins instead of one per bin (batch
+ * inversion over a balanced product tree): the denominators x_b = 1 + E_b of a block are multiplied up pairwise, the
+ * root is inverted once (correctly rounded) and the quotients come back down the tree, one multiplication per node.
+ * Same endpoints and the same formula as utils/torch/rand.py:67-68; every operation below is ONE IEEE-754 binary64
+ * operation:
+ *   rs = 1/scale;  hr = h * rs;  N = K/64 bins per group
+ *   rows with N |hr| >= 8 (a scale tiny against the bin width: peaked pixel rows only): the row is spec 2's, bit for bit
+ *   Q_b = exp(-(b * hr)),  b = 1..N-1
+ *   group g (bins j0 = g N .. j0 + N - 1):
+ *     t_a = (e[j0] - mu) * rs;  A = exp(min(-t_a, 41));  Ars = A * rs            (the anchor, clamped: see below)
+ *     x_0 = 1 + A;   x_b = fma(Q_b, fma(-Ars, r_b, A), 1),  r_b = e[j0+b] - fma(b, h, e[j0])   (r_b = 0 for the K-th,
+ *                                                             virtual endpoint that closes the last group)
+ *     blocks of n = min(N, 16) consecutive bins (K = 2048: two per group), per block a balanced binary tree:
+ *       level 0: T_0[i] = x_i;   level k: T_k[j] = T_{k-1}[2j] * T_{k-1}[2j+1];   root T_{log2 n}[0]
+ *       I_root = 1 / root;       I_{k-1}[2j] = I_k[j] * T_{k-1}[2j+1];   I_{k-1}[2j+1] = I_k[j] * T_{k-1}[2j]
+ *       cdf_i = I_0[i]
+ * (IEEE multiplication commutes, so a node's value does not depend on who computes it: a wavefront that holds one bin
+ * per lane builds the same tree with a butterfly exchange, k_rans_pop_pivot; one that holds the block in registers walks
+ * it in any order, k_logistic.)  The clamp keeps the root below 2^947 (x <= 1 + e^41 < 2^59.2).  With N |hr| < 8 a
+ * clamped group has E_b >= e^33 in every bin, i.e. cdf <= 2^-47: its bins -- and the first bin of the group behind it --
+ * truncate to f = 1 exactly as with the unclamped anchor.  Rounding: a quotient carries 2 log2 n + 1 roundings instead
+ * of one; against torch.sigmoid the integer tables differ in ~0.1 ppm of the entries, |df| = 1 (tests/test_oracle.py),
+ * the same level as specs 1 and 2.
+ */
+static int det3_row_cdf(const double* e, double h, double mu, double scale, int K, double* cdf /* K-1 */) {
+    const int N = K >= 64 ? K / 64 : 1;
+    const double rs = 1.0 / scale;
+    const double hr = h * rs;
+    if (N < 4 || !((double)N * fabs(hr) < 8.0)) return det2_row_cdf(e, h, mu, scale, K, cdf);
+    double Q[64], x[64], T[5][16], I[5][16];
+    for (int b = 1; b < N && b < 64; ++b) Q[b] = det_exp(-((double)b * hr));
+    const int n = N < 16 ? N : 16;
+    int levels = 0;
+    while ((1 << levels) < n) ++levels;
+    for (int j0 = 0; j0 < K - 1; j0 += N) {
+        const double ta = (e[j0] - mu) * rs;
+        const double A = det_exp_hi(-ta, 41.0);
+        const double Ars = A * rs;
+        x[0] = 1.0 + A;
+        for (int b = 1; b < N; ++b) {
+            const double r = (j0 + b < K - 1) ? e[j0 + b] - fma((double)b, h, e[j0]) : 0.0;
+            x[b] = fma(Q[b], fma(-Ars, r, A), 1.0);
+        }
+        for (int i0 = 0; i0 < N; i0 += n) {
+            for (int i = 0; i < n; ++i) T[0][i] = x[i0 + i];
+            for (int k = 1; k <= levels; ++k)
+                for (int j = 0; j < (n >> k); ++j) T[k][j] = T[k - 1][2 * j] * T[k - 1][2 * j + 1];
+            I[levels][0] = 1.0 / T[levels][0];
+            for (int k = levels; k >= 1; --k)
+                for (int j = 0; j < (n >> k); ++j) {
+                    I[k - 1][2 * j] = I[k][j] * T[k - 1][2 * j + 1];
+                    I[k - 1][2 * j + 1] = I[k][j] * T[k - 1][2 * j];
+                }
+            for (int i = 0; i < n; ++i)
+                if (j0 + i0 + i < K - 1) cdf[j0 + i0 + i] = I[0][i];
+        }
+    }
+    return 1;
+}
+
 /* reference formula: torch.sigmoid((x - mu) / scale), utils/torch/rand.py:67-68 */
 static double ref_sigmoid(double x, double mu, double scale) {
     double t = (x - mu) / scale;
@@ -135,12 +207,16 @@ static double ref_sigmoid(double x, double mu, double scale) {
  *   mode 1: the deterministic spec of the HIP kernels:
  *           rs = 1/scale (correctly rounded), t = (e - mu) * rs, det sigmoid.
  */
-void orc_logistic_pmf2(const double* endpoints, const double* step, const double* mu, const double* scale,
-                       int64_t D, int K, double* pmf) {
+static int detN_row_cdf(int spec, const double* e, double h, double mu, double scale, int K, double* cdf) {
+    return spec == 3 ? det3_row_cdf(e, h, mu, scale, K, cdf) : det2_row_cdf(e, h, mu, scale, K, cdf);
+}
+
+void orc_logistic_pmf_uniform(const double* endpoints, const double* step, const double* mu, const double* scale,
+                              int64_t D, int K, int spec, double* pmf) {
     double* c = (double*)malloc(sizeof(double) * (size_t)K);
     for (int64_t d = 0; d < D; ++d) {
         double* p = pmf + d * (int64_t)K;
-        det2_row_cdf(endpoints + d * (int64_t)(K - 1), step[d], mu[d], scale[d], K, c);
+        detN_row_cdf(spec, endpoints + d * (int64_t)(K - 1), step[d], mu[d], scale[d], K, c);
         for (int j = 0; j < K - 1; ++j) p[j] = (j == 0) ? c[0] : c[j] - c[j - 1];
         p[K - 1] = 1.0 - c[K - 2];
     }
@@ -298,9 +374,9 @@ static int row_table(const double* e, double mu, double scale, int K, int bits, 
                      int mode, double h, double* p, int64_t* f, uint32_t* c) {
     double prev = 0.0, rs = 1.0 / scale;
     int ok = 1;
-    if (mode == 2) {   /* CDF spec 2: uniform bins of width h */
+    if (mode == 2 || mode == 3) {   /* CDF spec 2 / 3: uniform bins of width h */
         double* cd = (double*)malloc(sizeof(double) * (size_t)K);
-        ok = det2_row_cdf(e, h, mu, scale, K, cd);
+        ok = detN_row_cdf(mode, e, h, mu, scale, K, cd);
         for (int j = 0; j < K - 1; ++j) p[j] = (j == 0) ? cd[0] : cd[j] - cd[j - 1];
         prev = cd[K - 2];
         free(cd);
@@ -327,10 +403,10 @@ static int row_table(const double* e, double mu, double scale, int K, int bits, 
     return ok;
 }
 
-/* Spec 2 only: every row of the layer inside the domain of det2_row_cdf?  Checked BEFORE anything is coded, like the HIP
+/* Specs 2 and 3: every row of the layer inside the domain of det2_row_cdf?  Checked BEFORE anything is coded, like the HIP
  * table kernels, which flag the chain and leave its state untouched. */
 static int layer_in_domain(const double* scale, int64_t D, int K, int mode, const double* step) {
-    if (mode != 2 || !step) return 1;
+    if ((mode != 2 && mode != 3) || !step) return 1;
     const int N = K >= 64 ? K / 64 : 1;
     for (int64_t i = 0; i < D; ++i) {
         const double rs = 1.0 / scale[i], hr = step[i] * rs;
@@ -370,4 +446,4 @@ int orc_layer_push(uint64_t* head, uint32_t* stack, int64_t* len, int64_t cap,
     return rc;
 }
 
-int orc_version(void) { return 2; }
+int orc_version(void) { return 3; }

@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 OK, UNDERFLOW, OVERFLOW, BAD_TABLE = 0, 1, 2, 3
-MODE_LIBM, MODE_DET, MODE_DET2 = 0, 1, 2   # reference formula / CDF spec 1 / CDF spec 2 (uniform bins)
-MODE_TORCH = 3   # backend.py only: the reference formula evaluated by torch.sigmoid itself (utils/torch/rand.py:67-68)
+MODE_LIBM, MODE_DET, MODE_DET2, MODE_DET3 = 0, 1, 2, 3   # reference formula / CDF spec 1 / CDF specs 2, 3 (uniform bins)
+MODE_TORCH = 9   # backend.py only: the reference formula evaluated by torch.sigmoid itself (utils/torch/rand.py:67-68)
 
 
 def build(force=False):
@@ -55,8 +55,8 @@ def lib():
         L.orc_layer_pop.argtypes = [p, p, p, p, p, p, i64, i32, i32, i32, i32, p, p]
         L.orc_layer_push.restype = i32
         L.orc_layer_push.argtypes = [p, p, p, i64, p, p, p, i64, i32, i32, i32, i32, p, p]
-        L.orc_logistic_pmf2.restype = None
-        L.orc_logistic_pmf2.argtypes = [p, p, p, p, i64, i32, p]
+        L.orc_logistic_pmf_uniform.restype = None
+        L.orc_logistic_pmf_uniform.argtypes = [p, p, p, p, i64, i32, i32, p]
         _lib = L
     return _lib
 
@@ -87,13 +87,13 @@ def bin_step(endpoints):
 
 
 def logistic_pmf(endpoints, mu, scale, mode=MODE_LIBM, step=None):
-    """endpoints [D,K-1], mu/scale [D] -> pmf [D,K] float64.  mode MODE_DET2 needs step [D] (bin_step())."""
+    """endpoints [D,K-1], mu/scale [D] -> pmf [D,K] float64.  modes MODE_DET2 / MODE_DET3 need step [D] (bin_step())."""
     e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
     D, Km1 = e.shape
     pmf = np.empty((D, Km1 + 1), dtype=np.float64)
-    if mode == MODE_DET2:
+    if mode in (MODE_DET2, MODE_DET3):
         step = _f64(bin_step(e) if step is None else step)
-        lib().orc_logistic_pmf2(_ptr(e), _ptr(step), _ptr(mu), _ptr(scale), D, Km1 + 1, _ptr(pmf))
+        lib().orc_logistic_pmf_uniform(_ptr(e), _ptr(step), _ptr(mu), _ptr(scale), D, Km1 + 1, mode, _ptr(pmf))
     else:
         lib().orc_logistic_pmf(_ptr(e), _ptr(mu), _ptr(scale), D, Km1 + 1, mode, _ptr(pmf))
     return pmf
@@ -161,7 +161,7 @@ def pop(st, cdf, bits=31):
 
 
 def _step_ptr(e, mode, step):
-    if mode != MODE_DET2:
+    if mode not in (MODE_DET2, MODE_DET3):
         return None, C.c_void_p(0)
     step = _f64(bin_step(e) if step is None else step)
     return step, _ptr(step)

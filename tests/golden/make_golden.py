@@ -667,7 +667,90 @@ def make_discretize_fixture():
     print("discretize_small.npz: mins", np.array(mins).min(), "maxs", np.array(maxs).max())
 
 
+def make_mnist_full_chain(nblocks=100):
+    """BASELINE configs[0] at its REAL width (mnist_compress.py:85-86,107: nz 2, reswidth 63, resdepth 8, nprocessing 4), ONE
+    chain of `nblocks` = 100 blocks (one "experiment", :102-103), Bit-Swap and BB-ANS, the reference's sender and receiver
+    on CPU.  What it is for: the HIP path evaluates the CDF with its own deterministic routine, torch.sigmoid differs from it
+    in ~0.1 ppm of table entries -- this chain measures how far a teacher-forced HIP stream follows the reference's own words
+    before such an entry forks it.  Stored compactly: per op (mu, scale) float32 as the reference's net emitted
+    them, the symbols, the word count and the head after the op; the pixel scale is a parameter (mnist_train.py:411), stored
+    once; the prior ops carry no arrays (mu 0, scale 1)."""
+    torch.manual_seed(55)
+    rng = np.random.RandomState(15)
+    nz, quantbits = 2, 10
+    xs, zch = (1, 32, 32), 1
+    cfg = [xs[0], nz, zch, 4, 3, 8, 63]
+    model = RefModel(xs=xs, nz=nz, zchannels=zch, nprocessing=4, kernel_size=3, resdepth=8, reswidth=63, root_process=False)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(".b") or n.endswith("gen_std"):
+                p.add_(torch.randn_like(p) * 0.3)
+            if n.endswith(".gain"):
+                p.add_(torch.randn_like(p) * 0.2)
+    model.eval()
+    xdim, zdim = int(np.prod(xs)), zch * 16 * 16
+    images = synth_images(rng, 128, xs)
+    zend, zcen, mins, maxs = synth_bins(model, nz, zdim, quantbits, images, rng)
+    for bitswap in (1, 0):
+        ops, sent, restbits, nets, cma = replay_chain(model, zend, zcen, images[:nblocks], nz, bitswap, quantbits, xdim, zdim,
+                                                      cap=0)
+        prior = np.array([p["kind"] == 1 and p["table"] == nz - 1 for p in ops])
+        zops = [p for p, pr in zip(ops, prior) if p["table"] >= 0 and not pr]
+        xops = [p for p in ops if p["table"] < 0]
+        assert all(np.array_equal(p["scale"], xops[0]["scale"]) for p in xops)
+        o = {
+            "cfg": np.array(cfg + [quantbits, bitswap, nblocks], dtype=np.int64),
+            "images": images[:nblocks],
+            "z_top_endpoints": zend[nz - 1][0], "z_top_centres": zcen[nz - 1][0], "z_mins": mins, "z_maxs": maxs,
+            "sent_words": words(sent), "restbits_len": np.int64(len(restbits)), "nets": np.array(nets), "cma": np.array(cma),
+            "op_kind": np.array([p["kind"] for p in ops], dtype=np.int8),
+            "op_table": np.array([p["table"] for p in ops], dtype=np.int8),
+            "op_prior": prior,
+            "op_q": np.array([p["q"] for p in ops], dtype=np.int8),
+            "op_nwords": np.array([p["nwords"] for p in ops], dtype=np.int64),
+            "op_head": np.array([p["head"] for p in ops], dtype=np.uint64),
+            "z_mu": np.stack([p["mu"] for p in zops]), "z_scale": np.stack([p["scale"] for p in zops]),
+            "z_sym": np.stack([p["sym"] for p in zops]).astype(np.int16),
+            "prior_sym": np.stack([p["sym"] for p, pr in zip(ops, prior) if pr]).astype(np.int16),
+            "x_mu": np.stack([p["mu"] for p in xops]), "x_scale": xops[0]["scale"],
+            "x_sym": np.stack([p["sym"] for p in xops]).astype(np.uint8),
+        }
+        name = f"chain_mnist_full_{'bitswap' if bitswap else 'bbans'}.npz"
+        np.savez_compressed(os.path.join(OUT, name), **o)
+        print(name, "ops", len(ops), "words", len(sent), "cma", cma[-1])
+
+
+def make_draws_fixture():
+    """The numpy draws of the dataset scripts in the reference's order (mnist_compress.py:94,133-137,158; imagenet_compress.py:
+    94,134,158): seed(100), choice(len(test_set), (100, 100), replace=False) -- the exists() guard at :133 never hits, np.save
+    appends .npy -- then per experiment the 10000 initial words.  len(test_set) = 10000 (MNIST / CIFAR-10 test sets) and 50000
+    (ImageNet 32x32 validation set).  Stored: the first indices and the first / last words of experiments 0-2."""
+    import random
+    out = {}
+    for ntest in (10000, 50000):
+        np.random.seed(100)
+        random.seed(50)
+        torch.manual_seed(50)
+        experiments, ndatapoints = 100, 100
+        randindices = np.random.choice(ntest, size=(experiments, ndatapoints), replace=False)
+        out[f"n{ntest}_indices"] = randindices[:3, :8].astype(np.int64)
+        for ei in range(3):
+            state = list(map(int, np.random.randint(low=1 << 16, high=(1 << 32) - 1, size=10000, dtype=np.uint32)))
+            state[-1] = state[-1] << 32
+            initialstate = state.copy()
+            out[f"n{ntest}_e{ei}_first4"] = np.array(initialstate[:4], dtype=np.uint64)
+            out[f"n{ntest}_e{ei}_last2"] = np.array(initialstate[-2:], dtype=np.uint64)
+    np.savez_compressed(os.path.join(OUT, "draws.npz"), **out)
+    print("draws.npz", out["n10000_e0_first4"], out["n50000_e0_first4"])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mnist_full":
+        make_mnist_full_chain()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "draws":
+        make_draws_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "surface":
         make_surface_fixture()
         sys.exit(0)
@@ -687,3 +770,5 @@ if __name__ == "__main__":
     make_bits_fixture()
     make_surface_fixture()
     make_discretize_fixture()
+    make_draws_fixture()
+    make_mnist_full_chain()

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.bs_abi_version.restype = ctypes.c_int
     from bitswap_amd import hip
-    assert lib.bs_abi_version() == hip.ABI_VERSION == 5
+    assert lib.bs_abi_version() == hip.ABI_VERSION == 6
     lib.bs_strerror.restype = ctypes.c_char_p
     assert b"underflow" in lib.bs_strerror(1)
 
@@ -39,11 +39,17 @@ def test_argument_validation_needs_no_gpu():
     # null pointers / bad sizes are rejected on the host before any launch
     assert L.bs_rans_push(None, None, None, 0, None, None, 1, 1, 31, None, None) == hip.EINVAL
     assert L.bs_table_rows_f64(None, 1, 16, 31, 4, None, None, 17, None, None) == hip.EINVAL
-    assert L.bs_logistic_tables(None, 0, None, None, None, 0, 1, 1, 256, 31, 8, None, 260, 0, None, None) == hip.EINVAL
-    assert L.bs_layer_pop64(None, None, None, 0, None, 0, None, None, None, 0, 0, 1, 64, 256, 31, 8, None, None, 0, None,
+    assert L.bs_logistic_tables(None, 0, None, 1, None, None, 0, 1, 1, 256, 31, 8, None, 260, 0, None, None) == hip.EINVAL
+    assert L.bs_layer_pop64(None, None, None, 0, None, 0, None, 1, None, None, 0, 0, 1, 64, 256, 31, 8, None, None, 0, None,
                             None, None) == hip.EINVAL
-    assert L.bs_layer_push64(None, None, None, 0, None, 0, None, None, None, 0, 0, None, 1, 64, 256, 31, 8, None,
+    assert L.bs_layer_push64(None, None, None, 0, None, 0, None, 1, None, None, 0, 0, None, 1, 64, 256, 31, 8, None,
                              None) == hip.EINVAL
+    # the uniform-bin CDF specs need the bin widths; a spec that does not exist is refused
+    buf8 = (ctypes.c_char * 64)()
+    q = ctypes.c_void_p((ctypes.addressof(buf8) + 15) & ~15)
+    for spec in (2, 3, 0, 4):
+        assert L.bs_logistic_tables(q, 0, None, spec, q, q, 0, 1, 1, 256, 31, 8, q, 260, 0, None, None) == hip.EINVAL
+        assert L.bs_logistic_fc(q, 0, None, spec, q, q, 0, q, 1, 1, 256, 31, 8, q, q, q, None) == hip.EINVAL
     # the conv-stack products: null operands, a limb-product count that does not exist, a K that is not a multiple of 16
     assert L.bs_wino_gemm_f32(None, None, None, 36, 256, 256, 128, None) == hip.EINVAL
     assert L.bs_wino_gemm_bf16x3(None, None, None, 36, 256, 256, 128, 6, None) == hip.EINVAL
@@ -53,7 +59,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.bs_wino_gemm_bf16x3(p, p, p, 36, 256, 256, 128, 7, None) == hip.EINVAL
     assert L.bs_wino_gemm_bf16x3(p, p, p, 36, 256, 250, 128, 6, None) == hip.EUNSUPPORTED
     assert L.bs_wino_gemm_bf16x3(p, p, p, 0, 256, 256, 128, 6, None) == hip.OK          # nothing to do: no launch
-    assert L.bs_cdf_spec() == 2
+    assert L.bs_cdf_spec() == 3
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -191,10 +191,44 @@ def test_cli_experiment_artefacts(tmp_path):
         assert isinstance(st, list) and st[-1] >= 1 << 32
     import json
     meta = json.load(open(tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap" / "stream_meta.json"))
-    assert meta["stream_format"] == "reference" and meta["cdf_spec"] == {"z": [1, 1], "x": 2}   # latents K = 64: no spec 2; pixels K = 256: spec 2
+    assert meta["stream_format"] == "reference" and meta["cdf_spec"] == {"z": [1, 1], "x": 3}   # latents K = 64: spec 1; pixels K = 256: the uniform-bin spec (3)
     assert meta["conv_route"]["chains_per_call"] == 3 and meta["world_size"] == 1
     # net bit rate formula (:254,258): cumulative nets * xdim * ndatapoints = words added * 32
     assert np.all(r["total"] > 0) and np.isfinite(r["elbos"]).all()
+
+
+def test_initial_words_follow_the_reference_draw_order(golden, tmp_path):
+    """mnist_compress.py:94,133-137,158: numpy is seeded once, `choice(len(test_set), (100, 100), replace=False)`
+    consumes the generator (the exists() guard never hits: np.save appends .npy), THEN experiment i draws its 10000 initial
+    words.  draws.npz holds what that sequence yields for test sets of 10000 (MNIST / CIFAR-10) and 50000 (ImageNet32)
+    images; codec.reference_draws must hold the same indices and words, and cli.compress must start its experiments there."""
+    from bitswap_amd.codec import reference_draws
+    g = golden("draws.npz")
+    for ntest in (10000, 50000):
+        idx, inits = reference_draws(ntest, 100, 100)
+        assert np.array_equal(idx[:3, :8], g[f"n{ntest}_indices"])
+        for ei in range(3):
+            assert inits[ei][:4] == [int(v) for v in g[f"n{ntest}_e{ei}_first4"]]
+            assert inits[ei][-2:] == [int(v) for v in g[f"n{ntest}_e{ei}_last2"]]
+    assert initial_states(3)[0][:4] != inits[0][:4]          # the fallback (seed, then the words at once) is NOT that sequence
+    # the CLI: 3 experiments x 2 datapoints out of >= 512 synthetic images -> the reference sequence for that shape
+    seen = {}
+    orig = BitSwapCodec.new_states
+
+    def spy(self, B, n, **kw):
+        seen["states"] = [list(s) for s in kw["states"]]
+        return orig(self, B, n, **kw)
+    BitSwapCodec.new_states = spy
+    try:
+        cli.compress(6, 2, 1, 0, dataset="mnist", experiments=3, ndatapoints=2, decompress=True, outdir=str(tmp_path),
+                     backend=OracleBackend(O.MODE_DET), small=8, verbose=False)
+    finally:
+        BitSwapCodec.new_states = orig
+    idx, want = reference_draws(512, 3, 2)
+    assert seen["states"] == want
+    assert np.array_equal(np.load(tmp_path / "bitstreams" / "mnist" / "indices.npy"), idx)
+    cli.decompress_streams(6, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=OracleBackend(O.MODE_DET), small=8,
+                           verbose=False)                  # the receiver finds the same initial words (:358)
 
 
 def test_tiling_and_container_round_trip():
