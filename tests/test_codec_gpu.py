@@ -344,15 +344,16 @@ class _Count:
         setattr(self.hip, self.name, self.orig)
 
 
-@pytest.mark.parametrize("name,bitswap,n,regime", [("cifar8", 1, 1, None), ("imagenet4", 1, 2, None), ("imagenet4", 0, 1, None),
-                                                   ("cifar8", 1, 2, "lowrate"), ("mnist2", 1, 2, None), ("cifar8", 0, 1, None)])
-def test_full_width_oracle_word_parity(name, bitswap, n, regime):
+@pytest.mark.parametrize("name,bitswap,n,regime,cdf_spec", [("cifar8", 1, 1, None, 3), ("imagenet4", 1, 2, None, 3), ("imagenet4", 0, 1, None, 3),
+                                                            ("cifar8", 1, 2, "lowrate", 3), ("mnist2", 1, 2, None, 3), ("cifar8", 0, 1, None, 3),
+                                                            ("cifar8", 1, 1, None, 2), ("cifar8", 1, 1, "lowrate", 2)])
+def test_full_width_oracle_word_parity(name, bitswap, n, regime, cdf_spec):
     """BASELINE configs 1 (MNIST nz = 2 at its real width: reswidth 63 padded to 64, Z = 256, X = 1024,
     mnist_compress.py:85-86,107), 2, 3 and 5, and the 8-layer BB-ANS schedule (cifar_compress.py --bitswap 0: the deepest
     dip into the initial stack, :206-243), at FULL model width (reswidth 252 / 254, Z = 2048, X = 3072, K = 1024 / 256) on the
     route the bench takes: 32 chains per call, every convolution of the stacks in the Winograd domain on OUR fp32 MFMA
     GEMM (asserted: bs_wino_gemm_f32 is called, the BLAS library is not), and the production kernel pair (k_logistic wave
-    layout, CDF spec 2 + k_rans_pop_wave + systolic push).  The oracle replays the schedule on the CPU with the GPU's conv
+    layout, CDF spec 3 -- and spec 2, the streams of rounds 3-4 -- + k_rans_pop_wave + systolic push).  The oracle replays the schedule on the CPU with the GPU's conv
     outputs and must produce the very same words (mnist_compress.py:176-251); then the GPU receiver returns the blocks
     and unwinds every chain.  The imagenet4 Bit-Swap case is TWO blocks deep: the second block renormalises into the
     words the first one pushed above the initial 10,000.  regime "lowrate": the calibrated synthetic
@@ -365,8 +366,9 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime):
         images = workload.lowrate_blocks(model, B * n, seed=17).view(B, n, -1).to(torch.int32)
     else:
         images = workload.synthetic_blocks(B * n, model.xs, seed=17).view(B, n, -1).to(torch.int32)
-    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap))
-    assert codec.cdf_spec == 2 and all(s is not None for s in codec.zstep[:-1]) and codec.zstep[-1] is None
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap), cdf_spec=cdf_spec)
+    assert BitSwapCodec(model, zend, zcen, quantbits=10).cdf_spec == 3       # the default since round 5
+    assert codec.cdf_spec == cdf_spec and all(s is not None for s in codec.zstep[:-1]) and codec.zstep[-1] is None
     from bitswap_amd import hip
     # the hand-off of the bench's batch size (>= 2 GB of rows per launch: 64 cumulative values per row, the pop kernel
     # rebuilds its group of bins) forced on at 32 chains; the top layer / prior (CDF spec 1) keeps whole rows
@@ -388,7 +390,7 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime):
         print(f"lowrate {name}: net {met['nets'].mean():.3f} bits/dim")
 
     oc = BitSwapCodec(model, zend.cpu(), zcen.cpu(), quantbits=10, bitswap=bool(bitswap),
-                      backend=OracleBackend(O.MODE_DET, threads=16))
+                      backend=OracleBackend(O.MODE_DET, threads=16), cdf_spec=cdf_spec)
     oc._net = rec.replay
     ostate, omet = oc.compress(images)
     assert ostate.to_lists() == sent

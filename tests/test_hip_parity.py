@@ -382,7 +382,7 @@ def test_ans_class_drop_in(golden):
 @pytest.mark.parametrize("chain", ["chain_mnist_small_bitswap", "chain_mnist_small_bbans", "chain_rgb4_small_bitswap",
                                    "chain_rgb4_small_bbans"])
 @pytest.mark.parametrize("layout", ["linear", "wave"])
-@pytest.mark.parametrize("spec", [1, 2])
+@pytest.mark.parametrize("spec", [1, 2, 3])
 def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
     """Teacher-forced replay of the reference sender through the HIP kernels: same popped symbols,
     same per-operation state, same final word stream as the reference's Python run -- for the production kernel
@@ -396,11 +396,12 @@ def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
     xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)
     steps = {}
     for tab, e in list(enumerate(zend)) + [(-1, xend)]:
-        hs = uniform_step(e) if (spec == 2 and e.shape[1] + 1 >= 256) else None
+        hs = uniform_step(e) if (spec >= 2 and e.shape[1] + 1 >= 256) else None
         steps[tab] = None if hs is None else dev(hs)
-    if spec == 2:
+    if spec >= 2:
         assert steps[-1] is not None and steps[0] is not None and steps[len(zend) - 1] is None
     lay = h.LAYOUT_WAVE if layout == "wave" else h.LAYOUT_LINEAR
+    sp = lambda stp: None if stp is None else spec
     B = 2
     s0 = reference_init_state()
     st = h.RansState.from_lists([s0] * B, cap=40000, device=DEV)
@@ -410,14 +411,14 @@ def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
         mu = dev(np.tile(g[f"op{i}_mu"], (B, 1)))
         sc = dev(np.tile(g[f"op{i}_scale"], (B, 1)))
         if kind == 0:
-            cdf = h.logistic_tables(e, mu, sc, 31, int(q), layout=lay, step=steps[int(tab)], status=st.status)
+            cdf = h.logistic_tables(e, mu, sc, 31, int(q), layout=lay, step=steps[int(tab)], status=st.status, spec=sp(steps[int(tab)]))
             sym, z = h.rans_pop(st, cdf, K, centres=dev(zcen[tab]))
             assert np.array_equal(sym[1].cpu().numpy(), g[f"op{i}_sym"])
             want_z = zcen[tab][np.arange(zcen.shape[1]), g[f"op{i}_sym"]].astype(np.float32)
             assert np.array_equal(z[0].cpu().numpy(), want_z)
         else:
             sym = dev(np.tile(g[f"op{i}_sym"].astype(np.int32), (B, 1)))
-            f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, int(q), step=steps[int(tab)])
+            f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, int(q), step=steps[int(tab)], spec=sp(steps[int(tab)]))
             h.rans_push(st, f, c)
         assert (st.len.cpu() + 1).tolist() == [int(g["op_nwords"][i])] * B
         assert int(st.head[0].cpu().numpy().view(np.uint64)) == int(g["op_head"][i])
@@ -425,8 +426,57 @@ def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
     assert st.to_lists() == [words_to_state(g["sent_words"])] * B
 
 
+@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
+@pytest.mark.parametrize("spec", [1, 2, 3])
+def test_divergence_horizon_on_the_gpu(golden, sched, spec):
+    """How far the HIP kernels follow the reference's OWN word stream: BASELINE configs[0] at its real width,
+    one chain of 100 blocks written by the reference's sender on CPU (tests/golden/chain_mnist_full_*.npz; torch.sigmoid
+    tables), replayed teacher-forced -- the reference's (mu, scale) and pushed symbols in, every popped symbol, word count
+    and head compared -- through k_logistic + k_rans_pop_wave / the systolic push.  The first operation whose state differs
+    must be the one the oracle predicts (tests/test_oracle.py::HORIZON): None for CDF specs 1 and 2 (all 500 operations,
+    51,416 / 56,624 words reproduced), operation 165 = block 33 for spec 3, whose tables differ from torch's in 0.2 ppm of
+    the entries instead of 0.03 ppm.  Two chains side by side: both see the same thing."""
+    from bitswap_amd.bins import uniform_step
+    from test_oracle import HORIZON, full_chain_ops
+    h = hip()
+    g = golden(f"chain_mnist_full_{sched}.npz")
+    zend, xend, zcen = chain_tables(g)
+    zend_d = [dev(z) for z in zend]
+    xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)
+    steps = {}
+    for tab, e in list(enumerate(zend)) + [(-1, xend)]:
+        hs = uniform_step(e) if (spec >= 2 and e.shape[1] + 1 >= 256) else None
+        steps[tab] = None if hs is None else dev(hs)
+    B = 2
+    st = h.RansState.from_lists([reference_init_state()] * B, cap=80000, device=DEV)
+    first = None
+    for i, (kind, tab, q, mu, sc, sym) in enumerate(full_chain_ops(g)):
+        e = xend_d if tab < 0 else zend_d[tab]
+        K = e.shape[1] + 1
+        mu_d, sc_d = dev(np.tile(mu, (B, 1))), dev(np.tile(sc, (B, 1)))
+        sp = None if steps[tab] is None else spec
+        if kind == 0:
+            cdf = h.logistic_tables(e, mu_d, sc_d, 31, q, layout=h.LAYOUT_WAVE, step=steps[tab], status=st.status, spec=sp)
+            got, _ = h.rans_pop(st, cdf, K)
+        else:
+            f, c = h.logistic_fc(e, mu_d, sc_d, dev(np.tile(sym, (B, 1))), st.status, 31, q, step=steps[tab], spec=sp)
+            h.rans_push(st, f, c)
+        if i % 5 == 4 or i >= 160:          # a device -> host read per block is enough to find the operation
+            nw = (st.len.cpu() + 1).tolist()
+            hd = [int(x) for x in st.head.cpu().numpy().view(np.uint64)]
+            if nw != [int(g["op_nwords"][i])] * B or hd != [int(g["op_head"][i])] * B:
+                first = i
+                break
+    st.check()
+    want = HORIZON[(sched, spec)]
+    if want is None:
+        assert first is None and st.to_lists() == [words_to_state(g["sent_words"])] * B
+    else:
+        assert first is not None and (first == want or (first // 5 == want // 5 and first % 5 == 4 and want < 160))
+
+
 @pytest.mark.parametrize("layout", ["linear", "wave"])
-@pytest.mark.parametrize("spec", [1, 2])
+@pytest.mark.parametrize("spec", [1, 2, 3])
 def test_full_size_round_trip_property(layout, spec):
     """BASELINE config sizes (D=2048, K=1024 latents; D=3072, K=256 pixels), 64 chains: bits-back
     pop followed by push of the same symbols restores every state exactly; pushing then popping
@@ -441,19 +491,20 @@ def test_full_size_round_trip_property(layout, spec):
         lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
         e_np = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
         e = dev(e_np)
-        step = dev(uniform_step(e_np)) if spec == 2 else None
+        step = dev(uniform_step(e_np)) if spec >= 2 else None
+        sp = None if step is None else spec
         mu = dev(rng.randn(B, D).astype(np.float32))
         sc = dev(rng.uniform(0.1, 1.0, (B, D)).astype(np.float32))
         states = [reference_init_state(3000, seed=100 + b) for b in range(B)]
         st = h.RansState.from_lists(states, cap=3000 + D + 64, device=DEV)
-        cdf = h.logistic_tables(e, mu, sc, 31, q, layout=lay, step=step, status=st.status)
+        cdf = h.logistic_tables(e, mu, sc, 31, q, layout=lay, step=step, status=st.status, spec=sp)
         sym, _ = h.rans_pop(st, cdf, K)
-        f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, q, step=step)
+        f, c = h.logistic_fc(e, mu, sc, sym, st.status, 31, q, step=step, spec=sp)
         h.rans_push(st, f, c)
         st.check()
         assert st.to_lists() == states
         data = dev(rng.randint(0, K, (B, D)).astype(np.int32))
-        f, c = h.logistic_fc(e, mu, sc, data, st.status, 31, q, step=step)
+        f, c = h.logistic_fc(e, mu, sc, data, st.status, 31, q, step=step, spec=sp)
         h.rans_push(st, f, c)
         back, _ = h.rans_pop(st, cdf, K)
         st.check()
@@ -517,9 +568,11 @@ def test_wave_layout_tables_and_pop(K):
 
 @pytest.mark.parametrize("K", [256, 512, 1024, 2048])
 @pytest.mark.parametrize("ptype", [torch.float32, torch.float64])
-def test_logistic_spec2_bit_exact_vs_oracle(K, ptype):
-    """CDF spec 2 (uniform bins) on the GPU -- decode flavour in both layouts and encode flavour -- against the
-    oracle's C restatement (oracle/bitswap_oracle.c::det2_row_cdf), bit for bit; 6 chains so that a wavefront
+@pytest.mark.parametrize("spec", [2, 3])
+def test_logistic_spec2_bit_exact_vs_oracle(K, ptype, spec):
+    """CDF specs 2 and 3 (uniform bins) on the GPU -- decode flavour in both layouts and encode flavour -- against the
+    oracle's C restatements (oracle/bitswap_oracle.c::det2_row_cdf / det3_row_cdf), bit for bit; spec 3 on rows that take
+    the batch inversion AND on peaked rows that fall back to spec 2's arithmetic ((K/64) h / scale >= 8); 6 chains so that a wavefront
     walks several chains with the same residual registers, scales down to the model's minimum and saturated rows."""
     from bitswap_amd.bins import uniform_step
     h = hip()
@@ -535,19 +588,21 @@ def test_logistic_spec2_bit_exact_vs_oracle(K, ptype):
     sc = rng.uniform(0.1, 1.0, (B, D)).astype(np.float32)
     sc[0, :8] = 0.1
     mu[1, 0], mu[1, 1] = 30.0, -30.0
+    sc[2, :6] = (np.float32(K // 64) * step[:6] / np.array([7.0, 7.9, 8.1, 9.0, 40.0, 600.0])).astype(np.float32)   # either side of spec 3's switch
+    mu[3, :6], sc[3, :6] = 12.0, 0.1                                        # lower groups beyond the anchor clamp at 41
     sym = rng.randint(0, K, (B, D)).astype(np.int32)
     sym[0, :4] = [0, K - 1, 1, K - 2]
     status = torch.zeros(B, dtype=torch.int32, device=DEV)
-    lin = u32(h.logistic_tables(dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, step=dev(step), status=status))
+    lin = u32(h.logistic_tables(dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, step=dev(step), status=status, spec=spec))
     wav = u32(h.logistic_tables(dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, layout=h.LAYOUT_WAVE, step=dev(step),
-                                status=status))
-    f, c = h.logistic_fc(dev(e), dev(mu, ptype), dev(sc, ptype), dev(sym), status, 31, q, step=dev(step))
+                                status=status, spec=spec))
+    f, c = h.logistic_fc(dev(e), dev(mu, ptype), dev(sc, ptype), dev(sym), status, 31, q, step=dev(step), spec=spec)
     f, c = u32(f), u32(c)
     assert int(status.abs().max()) == 0
     cw, piv = unpermute_wave(wav, K)
     rows = np.arange(D)
     for b in range(B):
-        pmf = O.logistic_pmf(e, mu[b].astype(np.float64), sc[b].astype(np.float64), O.MODE_DET2, step)
+        pmf = O.logistic_pmf(e, mu[b].astype(np.float64), sc[b].astype(np.float64), {2: O.MODE_DET2, 3: O.MODE_DET3}[spec], step)
         _, want, rc = O.tables(pmf, 31, q)
         assert rc == O.OK
         assert np.array_equal(lin[b][:, : K + 1], want), b
@@ -558,10 +613,10 @@ def test_logistic_spec2_bit_exact_vs_oracle(K, ptype):
     # K below 256 has no spec 2
     e64 = np.stack([np.linspace(-4, 4, 65)[1:-1]] * 3)
     with pytest.raises(h.BitswapHipError):
-        h.logistic_tables(dev(e64), dev(mu[:, :3]), dev(sc[:, :3]), 31, 6, step=dev(uniform_step(e64)))
+        h.logistic_tables(dev(e64), dev(mu[:, :3]), dev(sc[:, :3]), 31, 6, step=dev(uniform_step(e64)), spec=spec)
 
 
-@pytest.mark.parametrize("spec", [1, 2])
+@pytest.mark.parametrize("spec", [1, 2, 3])
 def test_degenerate_parameters_are_flagged(spec):
     """NaN / Inf / non-positive (mu, scale) from a broken checkpoint: the table kernels set BS_ST_BADTABLE for the
     chain (the reference would trip over its assert at mnist_compress.py:47 or code garbage), later kernels skip it,
@@ -570,7 +625,8 @@ def test_degenerate_parameters_are_flagged(spec):
     h = hip()
     K, D, B = 256, 64, 5
     e = np.stack([np.linspace(-4, 4, K + 1)[1:-1]] * D)
-    step = dev(uniform_step(e)) if spec == 2 else None
+    step = dev(uniform_step(e)) if spec >= 2 else None
+    sp = None if step is None else spec
     mu = np.zeros((B, D), dtype=np.float32)
     sc = np.full((B, D), 0.5, dtype=np.float32)
     mu[1, 3] = np.nan
@@ -578,20 +634,21 @@ def test_degenerate_parameters_are_flagged(spec):
     sc[3, 7] = np.inf
     states = [reference_init_state(800, seed=b) for b in range(B)]
     st = h.RansState.from_lists(states, cap=2000, device=DEV)
-    cdf = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, step=step, status=st.status)
+    cdf = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, step=step, status=st.status, spec=sp)
     assert st.status.cpu().tolist() == [0, h.ST_BADTABLE, h.ST_BADTABLE, h.ST_BADTABLE, 0]
     sym, _ = h.rans_pop(st, cdf, K)
     got = st.to_lists()
     assert got[1:4] == states[1:4] and got[0] != states[0] and got[4] != states[4]
     st2 = h.RansState.from_lists(states, cap=2000, device=DEV)
-    h.logistic_fc(dev(e), dev(mu), dev(sc), sym, st2.status, 31, 8, step=step)
+    h.logistic_fc(dev(e), dev(mu), dev(sc), sym, st2.status, 31, 8, step=step, spec=sp)
     assert st2.status.cpu().tolist() == [0, h.ST_BADTABLE, h.ST_BADTABLE, h.ST_BADTABLE, 0]
 
 
 @pytest.mark.parametrize("K,D,ptype,shared_row", [(1024, 192, np.float32, False), (256, 128, np.float32, True),
                                                    (512, 64, np.float64, False), (2048, 64, np.float32, False),
                                                    (1024, 2048, np.float32, False)])
-def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_row):
+@pytest.mark.parametrize("spec", [2, 3])
+def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_row, spec):
     """BS_LAYOUT_PIVOT (64 cumulative values per row; bs_rans_pop_pivot rebuilds the symbol's group of bins with the table
     kernel's arithmetic) against BS_LAYOUT_WAVE (the whole integer row in HBM) and against the oracle: same symbols, same
     words, same centres -- peaked and flat rows, remnant bumps inside and outside the popped group, the first and the last
@@ -615,13 +672,15 @@ def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_r
     sc[0, :] = 0.004 if shared_row else 0.02            # a chain of peaked rows: most bins f = 1
     mu[1, :] = -50.0                                    # all mass in the first bin
     mu[2, :] = 50.0                                     # ... in the last one
+    hh = uniform_step(e)
+    sc[3, :8] = ((K // 64) * hh[:8] / np.array([7.0, 7.9, 8.1, 9.0, 20.0, 40.0, 100.0, 300.0])).astype(ptype)   # either side of spec 3's switch to spec 2's arithmetic
     e_d = dev(e[:1]).expand(D, -1) if shared_row else dev(e)
     c_d = dev(cen)
     states = [reference_init_state(3000 + 12 * D // 10, seed=b) for b in range(B)]
     res = {}
     for layout in (h.LAYOUT_WAVE, h.LAYOUT_PIVOT):
         st = h.RansState.from_lists(states, cap=8000 + 2 * D, device=DEV)
-        tab = h.logistic_tables(e_d, dev(mu), dev(sc), 31, q, layout=layout, step=step, status=st.status)
+        tab = h.logistic_tables(e_d, dev(mu), dev(sc), 31, q, layout=layout, step=step, status=st.status, spec=spec)
         assert tab.shape[-1] == (h.PIVOT_LD if layout == h.LAYOUT_PIVOT else K + 64)
         sym, z = h.rans_pop(st, tab, K, 31, centres=c_d)
         st.check()
@@ -629,22 +688,23 @@ def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_r
     a, b = res[h.LAYOUT_WAVE], res[h.LAYOUT_PIVOT]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
     assert (a[0][1] == 0).all() and (a[0][2] >= K - 2).mean() > 0.9      # the mass sits where the mean is
-    # ... and the oracle (CDF spec 2) agrees
+    # ... and the oracle (the same CDF spec) agrees
     for bb in (0, 2, 3):
         ost = O.Stack(states[bb], cap=8000 + 2 * D)
-        osym, rc = O.layer_pop(ost, e, mu[bb].astype(np.float64), sc[bb].astype(np.float64), 31, q, O.MODE_DET2)
+        osym, rc = O.layer_pop(ost, e, mu[bb].astype(np.float64), sc[bb].astype(np.float64), 31, q, {2: O.MODE_DET2, 3: O.MODE_DET3}[spec])
         assert rc == O.OK and np.array_equal(osym, b[0][bb]) and ost.tolist() == b[2][bb]
     # a degenerate chain: flagged by the table kernel, skipped by the pop, the others untouched by it
     sc2 = sc.copy()
     sc2[4, 7] = 0.0
     st = h.RansState.from_lists(states, cap=8000 + 2 * D, device=DEV)
-    tab = h.logistic_tables(e_d, dev(mu), dev(sc2), 31, q, layout=h.LAYOUT_PIVOT, step=step, status=st.status)
+    tab = h.logistic_tables(e_d, dev(mu), dev(sc2), 31, q, layout=h.LAYOUT_PIVOT, step=step, status=st.status, spec=spec)
     sym, _ = h.rans_pop(st, tab, K, 31)
     assert st.status.cpu().tolist() == [0, 0, 0, 0, h.ST_BADTABLE, 0] and st.to_lists()[4] == states[4]
     assert np.array_equal(sym.cpu().numpy()[[0, 1, 2, 3, 5]], b[0][[0, 1, 2, 3, 5]])
 
 
-def test_cdf_spec2_domain_is_flagged():
+@pytest.mark.parametrize("spec", [2, 3])
+def test_cdf_spec2_domain_is_flagged(spec):
     """a row whose anchors leave the +-700 domain of det_exp (scale tiny against the bin width -- reachable
     through the C ABI, never by the reference's models) is outside CDF spec 2: every flavour flags BS_ST_BADTABLE for the
     chain and leaves its state alone, as the oracle does (tests/test_oracle.py::test_cdf_spec2_domain_is_enforced); the
@@ -660,13 +720,13 @@ def test_cdf_spec2_domain_is_flagged():
     sc[1, 5] = 1e-4
     states = [reference_init_state(800, seed=b) for b in range(B)]
     st = h.RansState.from_lists(states, cap=2000, device=DEV)
-    cdf = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, step=step, status=st.status)
+    cdf = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, step=step, status=st.status, spec=spec)
     assert st.status.cpu().tolist() == [0, h.ST_BADTABLE, 0]
     sym, _ = h.rans_pop(st, cdf, K)
     got = st.to_lists()
     assert got[1] == states[1] and got[0] != states[0] and got[2] != states[2]
     st2 = h.RansState.from_lists(states, cap=2000, device=DEV)
-    h.logistic_fc(dev(e), dev(mu), dev(sc), sym, st2.status, 31, 8, step=step)
+    h.logistic_fc(dev(e), dev(mu), dev(sc), sym, st2.status, 31, 8, step=step, spec=spec)
     assert st2.status.cpu().tolist() == [0, h.ST_BADTABLE, 0]
     st3 = h.RansState.from_lists(states, cap=2000, device=DEV)                       # spec 1: a well-formed table
     cdf1 = h.logistic_tables(dev(e), dev(mu), dev(sc), 31, 8, layout=h.LAYOUT_WAVE, status=st3.status)
@@ -675,12 +735,12 @@ def test_cdf_spec2_domain_is_flagged():
     st3.check()
     assert 0 <= int(s1.min()) and int(s1.max()) < K
     s64 = h.RansState64.from_lists(states, cap=64, device=DEV)                      # the fused 64-state kernels too
-    h.layer_pop64(s64, dev(e), dev(mu), dev(sc), 31, 8, step=step)
+    h.layer_pop64(s64, dev(e), dev(mu), dev(sc), 31, 8, step=step, spec=spec)
     assert s64.status.cpu().tolist() == [0, h.ST_BADTABLE, 0]
 
 
 @pytest.mark.parametrize("K", [256, 512, 1024])
-@pytest.mark.parametrize("spec", [1, 2])
+@pytest.mark.parametrize("spec", [1, 2, 3])
 def test_layer64_kernels_vs_oracle(K, spec):
     """bs_layer_pop64 / bs_layer_push64 (64 states per chain, table row + rANS step in one launch) against the
     oracle: state j of a chain codes dims j, j + 64, ... with the single-state arithmetic (ANS.decode / ANS.encode,
@@ -694,9 +754,10 @@ def test_layer64_kernels_vs_oracle(K, spec):
     D, B = 200, 7
     lo, hi = rng.uniform(-8, -2, D), rng.uniform(2, 8, D)
     e = np.stack([np.linspace(a, b, K + 1)[1:-1] for a, b in zip(lo, hi)])
-    step_np = uniform_step(e) if spec == 2 else None
+    step_np = uniform_step(e) if spec >= 2 else None
     step = None if step_np is None else dev(step_np)
-    mode = O.MODE_DET2 if spec == 2 else O.MODE_DET
+    sp = None if step is None else spec
+    mode = {1: O.MODE_DET, 2: O.MODE_DET2, 3: O.MODE_DET3}[spec]
     mu = (rng.randn(B, D) * 0.6).astype(np.float32)
     sc = rng.uniform(0.1, 1.0, (B, D)).astype(np.float32)
     cen = rng.randn(D, K)
@@ -715,7 +776,7 @@ def test_layer64_kernels_vs_oracle(K, spec):
     for ptype in (torch.float32, torch.float64):
         st = h.RansState64.from_lists(states, cap=400, device=DEV)
         assert st.to_lists() == [split_state(s) for s in states]
-        sym, z = h.layer_pop64(st, dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, centres=dev(cen), step=step)
+        sym, z = h.layer_pop64(st, dev(e), dev(mu, ptype), dev(sc, ptype), 31, q, centres=dev(cen), step=step, spec=sp)
         st.check()
         got = st.to_lists()
         for b in range(B):
@@ -724,13 +785,13 @@ def test_layer64_kernels_vs_oracle(K, spec):
             assert np.array_equal(sym[b].cpu().numpy(), want), b
             assert got[b] == [s_.tolist() for s_ in stacks], b
             assert np.array_equal(z[b].cpu().numpy(), cen[np.arange(D), want].astype(np.float32))
-        h.layer_push64(st, dev(e), dev(mu, ptype), dev(sc, ptype), sym, 31, q, step=step)   # bits back: restores every state
+        h.layer_push64(st, dev(e), dev(mu, ptype), dev(sc, ptype), sym, 31, q, step=step, spec=sp)   # bits back: restores every state
         st.check()
         assert st.to_lists() == [split_state(s) for s in states]
     # fresh symbols: push, compare with the oracle, pop them back
     data = rng.randint(0, K, (B, D)).astype(np.int32)
     st = h.RansState64.from_lists(states, cap=400, device=DEV)
-    h.layer_push64(st, dev(e), dev(mu), dev(sc), dev(data), 31, q, step=step)
+    h.layer_push64(st, dev(e), dev(mu), dev(sc), dev(data), 31, q, step=step, spec=sp)
     st.check()
     got = st.to_lists()
     for b in range(B):
@@ -740,14 +801,14 @@ def test_layer64_kernels_vs_oracle(K, spec):
             assert O.layer_push(stacks[j], e[sl], mu[b][sl].astype(np.float64), sc[b][sl].astype(np.float64),
                                 np.ascontiguousarray(data[b][sl]), 31, q, mode, None if step_np is None else step_np[sl]) == O.OK
         assert got[b] == [s_.tolist() for s_ in stacks], b
-    back, _ = h.layer_pop64(st, dev(e), dev(mu), dev(sc), 31, q, step=step)
+    back, _ = h.layer_pop64(st, dev(e), dev(mu), dev(sc), 31, q, step=step, spec=sp)
     st.check()
     assert torch.equal(back.cpu(), torch.from_numpy(data)) and st.to_lists() == [split_state(s) for s in states]
     # one row set shared by all chains (the prior): same as expanding it
     st_a = h.RansState64.from_lists(states, cap=400, device=DEV)
     st_b = h.RansState64.from_lists(states, cap=400, device=DEV)
-    sa, _ = h.layer_pop64(st_a, dev(e), dev(mu[0]), dev(sc[0]), 31, q, step=step)
-    sb, _ = h.layer_pop64(st_b, dev(e), dev(np.tile(mu[:1], (B, 1))), dev(np.tile(sc[:1], (B, 1))), 31, q, step=step)
+    sa, _ = h.layer_pop64(st_a, dev(e), dev(mu[0]), dev(sc[0]), 31, q, step=step, spec=sp)
+    sb, _ = h.layer_pop64(st_b, dev(e), dev(np.tile(mu[:1], (B, 1))), dev(np.tile(sc[:1], (B, 1))), 31, q, step=step, spec=sp)
     assert torch.equal(sa, sb) and st_a.to_lists() == st_b.to_lists()
 
 

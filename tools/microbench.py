@@ -59,12 +59,13 @@ def main():
         wcdf = torch.empty((B, D, hip.wave_ld(K)), dtype=torch.int32, device=dev)
         fo = (torch.empty((B, D), dtype=torch.int32, device=dev), torch.empty((B, D), dtype=torch.int32, device=dev))
         r = dict(B=B, D=D, K=K)
-        for spec, stp in ((1, None), (2, step)):
+        for spec, stp in ((1, None), (2, step), (3, step)):
+            sp = None if stp is None else spec
             t_tab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=wcdf, layout=hip.LAYOUT_WAVE, step=stp,
-                                                       status=st.status), args.iters)
+                                                       status=st.status, spec=sp), args.iters)
             wcdf.bs_layout = hip.LAYOUT_WAVE
             sym, _ = hip.rans_pop(st, wcdf, K)
-            t_fc = timeit(lambda: hip.logistic_fc(e, mu, sc, sym, st.status, 31, q, out=fo, step=stp), args.iters)
+            t_fc = timeit(lambda: hip.logistic_fc(e, mu, sc, sym, st.status, 31, q, out=fo, step=stp, spec=sp), args.iters)
             hip.rans_push(st, fo[0], fo[1])
             tp, tq = [], []
             for _ in range(args.iters):
@@ -79,8 +80,8 @@ def main():
             if stp is not None:      # the production hand-off for uniform bins: 64 cumulative values per row
                 pcdf = torch.empty((B, D, hip.PIVOT_LD), dtype=torch.int32, device=dev)
                 t_ptab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=pcdf, layout=hip.LAYOUT_PIVOT, step=stp,
-                                                            status=st.status), args.iters)
-                tables = hip.logistic_tables(e, mu, sc, 31, q, out=pcdf, layout=hip.LAYOUT_PIVOT, step=stp, status=st.status)
+                                                            status=st.status, spec=sp), args.iters)
+                tables = hip.logistic_tables(e, mu, sc, 31, q, out=pcdf, layout=hip.LAYOUT_PIVOT, step=stp, status=st.status, spec=sp)
                 tpp = []
                 for _ in range(args.iters):
                     tpp.append(timeit(lambda: hip.rans_pop(st, tables, K), 1, 0))
@@ -99,9 +100,9 @@ def main():
             tp64, tq64 = [], []
             for _ in range(args.iters):
                 box = []
-                tp64.append(timeit(lambda: box.append(hip.layer_pop64(s64, e, mu, sc, 31, q, centres=cen, step=stp)), 1, 0))
+                tp64.append(timeit(lambda: box.append(hip.layer_pop64(s64, e, mu, sc, 31, q, centres=cen, step=stp, spec=sp)), 1, 0))
                 sy = box[0][0]
-                tq64.append(timeit(lambda: hip.layer_push64(s64, e, mu, sc, sy, 31, q, step=stp), 1, 0))
+                tq64.append(timeit(lambda: hip.layer_push64(s64, e, mu, sc, sy, 31, q, step=stp, spec=sp), 1, 0))
             s64.check()
             r[f"spec{spec}"].update(layer_pop64_s=float(np.median(tp64)), layer_push64_s=float(np.median(tq64)))
         res[name] = r
