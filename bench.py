@@ -52,10 +52,12 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # the shipped code object: VALU instructions of the per-row loop + 3 extra slots per quarter-rate v_rcp_f64.  Under
 # sustained float64 load the chip runs at about 4/4.9 of the nominal clock (tools/probes/instr_rate.hip), so 0.82 here is the
 # practical ceiling
-VALU_SLOTS_PER_ROW = {2: 381, 1: 648}   # CDF spec 2 (uniform bins, BS_LAYOUT_PIVOT hand-off; 403 with whole rows) / spec 1
+# (round 5: tools/isa_count.py --blocks, the blocks one row executes -- spec 3's loop holds two arms, a row takes one)
+VALU_SLOTS_PER_ROW = {3: 268, 2: 371, 1: 643}   # CDF spec 3 / 2 (uniform bins, BS_LAYOUT_PIVOT hand-off; +29 with whole rows) / spec 1
+WHOLE_ROW_EXTRA_SLOTS = 29
 # float64 flops of one row (64 lanes x [2 per fma + 1 per add/mul/rcp] in that loop): SURVEY 8(d) asks for the FP64
 # utilisation next to the HBM figure.  Vector FP64 peak 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
-FP64_FLOPS_PER_ROW = {2: 353 * 64, 1: 699 * 64}
+FP64_FLOPS_PER_ROW = {3: 229 * 64, 2: 362 * 64, 1: 763 * 64}
 FP64_PEAK_TFLOPS = 78.6
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, MI355X_MICROARCH.md (155 measured)
 
@@ -402,14 +404,14 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
         spec = args.cdf_spec if any(s is not None for s in codec.codecs[0].zstep) else 1
         from bitswap_amd import hip as _hip
         be = codec.codecs[0].backend
-        pivot = bool(spec == 2 and args.format == "reference" and hasattr(be, "table_layout")
+        pivot = bool(spec >= 2 and args.format == "reference" and hasattr(be, "table_layout")
                      and be.table_layout(Kb, True, Z, int(rows // Z)) == _hip.LAYOUT_PIVOT)
         slots = VALU_SLOTS_PER_ROW[spec] if (Kb == 1024 and args.format == "reference") else None
-        if slots is not None and spec == 2 and not pivot:
-            slots = 403                                   # whole-row hand-off (BITSWAP_PIVOT=0)
-        kname = (f"k_layer64<16,float,{'uniform' if spec == 2 else 'generic'},pop> (logistic CDF -> integer table -> rANS pop in "
+        if slots is not None and spec >= 2 and not pivot:
+            slots += WHOLE_ROW_EXTRA_SLOTS                # whole-row hand-off (BITSWAP_PIVOT=0)
+        kname = (f"k_layer64<16,float,{'uniform' if spec >= 2 else 'generic'},pop> (logistic CDF -> integer table -> rANS pop in "
                  f"one launch, rows in registers, CDF spec {spec})" if args.format == "wave64" else
-                 f"k_logistic<16,float,{'pivot' if pivot else 'decode'},{'uniform' if spec == 2 else 'generic'}> (fused logistic CDF -> "
+                 f"k_logistic<16,float,{'pivot' if pivot else 'decode'},spec{spec}> (fused logistic CDF -> "
                  f"integer table -> {'64 cumulative values per row for bs_rans_pop_pivot' if pivot else 'cdf rows'}, CDF spec {spec})")
         # --- HBM side, on bytes that move.  SURVEY 8(d) prices a z-row at (K-1)*8 + 12 B because it counts the [Z, K-1]
         # float64 endpoint table once per BLOCK; a launch over `chains` blocks reads that table from HBM once (the rest are
@@ -425,7 +427,7 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                 tj = json.load(open(tp)).get(name, {})
                 per_row = tj.get("k_logistic_pivot_bytes_per_row" if pivot else "k_logistic_decode_bytes_per_row")
                 traffic = None if per_row is None else int(per_row * rows)   # PMC bytes/row x rows of one launch
-                traffic_src = ["profiles/" + f for f in tj.get("source", [])]
+                traffic_src = [f if f.startswith("profiles/") else "profiles/" + f for f in tj.get("source", [])]
             except Exception:
                 traffic = None
         a_block = algorithmic_bytes_per_block(codec)
@@ -442,7 +444,7 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                        + ("" if pivot else ", 98 % of it the cdf-row hand-off to k_rans_pop_wave")
                        + f"; SURVEY 8(d)'s per-block count would be {survey_alg} B per launch, of which all but the first table "
                          "pass are L2 hits"}
-        kkey = f"k_logistic<16,float,{'pivot' if pivot else 'decode'},{'uniform' if spec == 2 else 'generic'}>"
+        kkey = f"k_logistic<16,float,{'pivot' if pivot else 'decode'},spec{spec}>"
         # the SURVEY 8(d)-literal figure for this kernel, kept visible: (K-1)*8 + 12 B per row x rows / launch time against the
         # HBM peak.  Above 1 whenever more than one chain shares a launch: all but the first pass over the [Z, K-1] endpoint
         # table are L2 hits, so it is not an HBM figure -- which is why `frac` is quoted on the bound the kernel sits on
@@ -450,19 +452,24 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
                   "hbm_survey_frac": round(survey_alg / avg / 1e9 / HBM_PEAK_GBPS, 4),
                   "hbm_survey_note": "SURVEY 8(d) literal: 8196 B/row x rows_per_launch / avg_launch_ms / 8 TB/s; > 1 = L2 hits "
                                      "(the endpoint table is re-read from L2 by every chain of a launch), not HBM traffic"}
+        # The record's headline (`bound`, `achieved`, `peak`, `frac`) is the WHOLE-PATH figure SURVEY 8(d) / BASELINE.md 2.3 define
+        # -- 2 x A_block x blocks / (t_sender + t_receiver) against the HBM peak -- the one 8(d) number that stays <= 1 whatever
+        # the batch.  The dominant kernel's own figures sit under "kernel_*": it is bound by VALU issue (`valu_issue_frac`), and
+        # the 8(d)-literal per-launch byte count over its time exceeds the HBM peak because all but the first pass over the
+        # endpoint table are L2 hits (`hbm_survey_frac`, annotated).
+        roof = {"bound": "hbm", "achieved": round(path / world, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(path / world / HBM_PEAK_GBPS, 4),
+                "definition": "whole path, SURVEY 8(d): 2 x algorithmic bytes per block x blocks / (t_sender + t_receiver) / 8 TB/s",
+                "path_frac": round(path / world / HBM_PEAK_GBPS, 4), "kernel": kname, **survey}
         if slots is not None:
             ach = rows * slots / avg / 1e9
-            roof = {"kernel": kname, "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINSTR, 1),
-                    "unit": "Ginstr/s", "frac": round(ach / VALU_PEAK_GINSTR, 4),
-                    "path_frac": round(path / world / HBM_PEAK_GBPS, 4), **survey, "slots_per_row": slots,
-                    # measured by SQ counters (profiles/valu_busy.json, tools/pmc_valu.sh): share of the SIMD cycles the
-                    # VALU pipe is busy while THIS flavour of the kernel runs; None: no counter run of it on file
-                    "valu_busy_pmc": _valu_busy(kkey)}
-        else:       # no issue model for this kernel shape: the counter-side HBM figure is the headline
-            roof = {"kernel": kname, "bound": "hbm", "achieved": hbm["traffic_achieved"] or hbm["achieved"],
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": hbm["traffic_frac"] if hbm["traffic_frac"] is not None else hbm["frac"],
-                    "path_frac": round(path / world / HBM_PEAK_GBPS, 4), **survey}
+            roof.update({"kernel_bound": "valu_issue", "kernel_achieved_Ginstr": round(ach, 1), "kernel_peak_Ginstr": round(VALU_PEAK_GINSTR, 1),
+                         "valu_issue_frac": round(ach / VALU_PEAK_GINSTR, 4), "slots_per_row": slots,
+                         # measured by SQ counters (profiles/valu_busy.json, tools/pmc_valu.sh): share of the SIMD cycles the
+                         # VALU pipe is busy while THIS flavour of the kernel runs; None: no counter run of it on file
+                         "valu_busy_pmc": _valu_busy(kkey)})
+        else:       # no issue model for this kernel shape: the counter-side HBM figure stands for the kernel
+            roof.update({"kernel_bound": "hbm", "kernel_hbm_frac": hbm["traffic_frac"] if hbm["traffic_frac"] is not None else hbm["frac"]})
         roof.update({"traffic": traffic, "launches": cnt, "avg_launch_ms": round(avg * 1e3, 4),
                      "timing": ("exclusive: HIP events on the launch stream, single-stream pass of one chain group after the "
                                 "timed region" if excl else "time-shared: HIP events inside the timed region"),

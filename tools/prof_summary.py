@@ -177,7 +177,7 @@ def traffic(fetch_json, write_json, workload, out, rows_per_launch):
     rows = float(rows_per_launch)
     entry = res.get(workload, {})
     entry.update({"rows_per_launch": int(rows), "fetch_correction": 2.0, "source": [os.path.basename(fetch_json), os.path.basename(write_json)]})
-    for tag, prefix in (("decode", "void k_logistic<16, float, 3, true"), ("pivot", "void k_logistic<16, float, 4, true"),
+    for tag, prefix in (("decode", "void k_logistic<16, float, 3, 3"), ("pivot", "void k_logistic<16, float, 4, 3"),
                         ("pop_wave", "void k_rans_pop_wave<16"), ("pop_pivot", "void k_rans_pop_pivot<16")):
         f, nf = per(fetch_json, "FETCH_SIZE", prefix)
         w, nw = per(write_json, "WRITE_SIZE", prefix)

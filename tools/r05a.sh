@@ -19,6 +19,6 @@ for sp in 3 2 3 2; do
 import json
 d=json.loads([l for l in open("$OUT/${TAG}_bench_spec${sp}.json") if l.startswith("{")][-1])
 r=d["roofline"]
-print("spec $sp", round(d["value"]/1e6,3), "Mpx/s", d["ms_per_step"], "ms lossless", d["lossless"], "tables excl ms", r["avg_launch_ms"], "in pipeline", r["avg_launch_ms_in_pipeline"], "frac", r["frac"])
+print("spec $sp", round(d["value"]/1e6,3), "Mpx/s", d["ms_per_step"], "ms lossless", d["lossless"], "tables excl ms", r["avg_launch_ms"], "in pipeline", r["avg_launch_ms_in_pipeline"], "valu_issue_frac", r.get("valu_issue_frac"), "path_frac", r["frac"])
 PY
 done

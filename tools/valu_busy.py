@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/valu_busy.json from the SQ-counter passes of tools/pmc_valu.sh (three separate --pmc runs of tools/microbench.py,
 per-dispatch means per kernel):  VALU busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).
-Keys name the kernel FLAVOUR (pivot / decode / encode x uniform / generic), which is what bench.py looks up for the kernel
+Keys name the kernel FLAVOUR (pivot / decode / encode x CDF spec), which is what bench.py looks up for the kernel
 it actually timed.     python tools/valu_busy.py gpurun_out/r04Z profiles/valu_busy.json"""
 import glob
 import json
@@ -12,12 +12,12 @@ MODES = {"0": "encode", "1": "linear", "2": "linear_vec", "3": "decode", "4": "p
 
 
 def flavour(name):
-    m = re.search(r"k_logistic<(\d+), (\w+), (\d), (true|false)>", name)
+    m = re.search(r"k_logistic<(\d+), (\w+), (\d), (\d)>", name)      # <NPL, param type, mode, CDF spec> since round 5
     if m:
-        return f"k_logistic<{m.group(1)},{m.group(2)},{MODES.get(m.group(3), m.group(3))},{'uniform' if m.group(4) == 'true' else 'generic'}>"
-    m = re.search(r"k_layer64<(\d+), (\w+), (true|false), (true|false)>", name)
+        return f"k_logistic<{m.group(1)},{m.group(2)},{MODES.get(m.group(3), m.group(3))},spec{m.group(4)}>"
+    m = re.search(r"k_layer64<(\d+), (\w+), (\d), (true|false)>", name)
     if m:
-        return f"k_layer64<{m.group(1)},{m.group(2)},{'uniform' if m.group(3) == 'true' else 'generic'},{'push' if m.group(4) == 'true' else 'pop'}>"
+        return f"k_layer64<{m.group(1)},{m.group(2)},spec{m.group(3)},{'push' if m.group(4) == 'true' else 'pop'}>"
     return None
 
 
