@@ -576,7 +576,8 @@ def extra_in_child(args, spec, steps, warmup):
                       + (", calibrated low-rate regime (workload.calibrate_lowrate: latent scales at the 0.1 clamp, pixel scale "
                          "0.0035, blocks drawn from the model's own generative path)" if spec.get("regime") == "lowrate" else "")
                       + (", opt-in 64-state stream format (not the reference's word stream)" if spec.get("format") == "wave64" else ""),
-            "why": spec.get("why"), "workload": spec["workload"], "chains_per_gpu": d["config"]["chains_per_gpu"],
+            "why": spec.get("why"), "workload": spec["workload"], "bitswap": int(spec.get("bitswap", args.bitswap)),
+            "chains_per_gpu": d["config"]["chains_per_gpu"],
             "chain_groups": d["config"]["chain_groups"], "scaling": d["scaling"], "steps": d["steps"], "warmup": d["warmup"],
             "value": round(d["value"], 1), "ms_per_step": round(d["ms_per_step"], 3), "lossless": d["lossless"],
             "bits_per_dim": round(d["bits_per_dim"], 4), "stream_format": spec.get("format", "reference"),
@@ -597,6 +598,14 @@ EXTRAS = (
     dict(workload="cifar8", chains=13, groups=1, why="one GPU's share of 100 chains on 8 GPUs"),
     dict(workload="imagenet4", chains=13, groups=1, bitswap=0, why="configs[4]: one GPU's share (13 of 100 chains) on 8 GPUs"),
     dict(workload="imagenetcrop4", chains=13, scaling="strong", steps=16, why="configs[3]: one GPU's share (13 of 100 images) on 8 GPUs"),
+    # the 2- and 4-GPU shares of the same 100 chains: with the 100- and 13-chain lines they give the predicted
+    # 1 / 2 / 4 / 8-GPU strong-scaling curve of configs[1], [3], [4] (predicted_scaling below)
+    dict(workload="cifar8", chains=50, groups=1, share_of=2, why="one GPU's share of 100 chains on 2 GPUs"),
+    dict(workload="cifar8", chains=25, groups=1, share_of=4, why="one GPU's share of 100 chains on 4 GPUs"),
+    dict(workload="imagenet4", chains=50, groups=1, bitswap=0, share_of=2, why="configs[4]: one GPU's share on 2 GPUs"),
+    dict(workload="imagenet4", chains=25, groups=1, bitswap=0, share_of=4, why="configs[4]: one GPU's share on 4 GPUs"),
+    dict(workload="imagenetcrop4", chains=50, scaling="strong", steps=16, share_of=2, why="configs[3]: one GPU's share (50 of 100 images) on 2 GPUs"),
+    dict(workload="imagenetcrop4", chains=25, scaling="strong", steps=16, share_of=4, why="configs[3]: one GPU's share (25 of 100 images) on 4 GPUs"),
     dict(workload="cifar8", chains=1000, groups=2, regime="lowrate", why="peaked tables: a trained model's rate"),
     dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_GEMM_ARITH": "bf16x3"},
          why="OPT-IN conv arithmetic, not the headline: the ResNet products as three bf16 limbs per float32 operand, 6 limb products "
@@ -689,6 +698,31 @@ def main(args):
             dist.destroy_process_group()
         return
 
+    # ---- the other shapes in compact form, and the strong-scaling curve they predict -----------------------------------
+    # predicted N-GPU rate of a fixed 100-chain job = N x the rate ONE GPU reaches on its share of the chains (ceil(100 / N)
+    # chains, measured above in a process of its own); the ranks never talk while coding (bitswap_amd/dist.py) and the gather
+    # of the finished streams is outside the timed region, so what the prediction leaves out is box-to-box spread only.
+    shapes, predicted = None, None
+    if extra:
+        def label(e):
+            return (f"{e['workload']}{'' if e.get('bitswap', 1) else '_bbans'}_{e['chains_per_gpu']}"
+                    + ("_wave64" if e.get("stream_format") == "wave64" else "")
+                    + ("_lowrate" if e.get("regime") == "lowrate" else "")
+                    + ("_" + e["conv_dtype"] if e.get("conv_dtype") not in (None, "f32") else ""))
+        shapes = {label(e): [round(e["value"] / 1e6, 3), e["ms_per_step"], e["lossless"]] for e in extra if "value" in e}
+        predicted = {}
+        for cfg, wl, bs in (("configs[1] cifar8 Bit-Swap", "cifar8", 1), ("configs[4] imagenet4 BB-ANS", "imagenet4", 0),
+                            ("configs[3] imagenetcrop4 ragged", "imagenetcrop4", 1)):
+            pick = lambda n: next((e["value"] for e in extra if e.get("workload") == wl and e.get("bitswap", 1) == bs and "value" in e
+                                   and e.get("chains_per_gpu") == n and e.get("stream_format", "reference") == "reference"
+                                   and e.get("conv_dtype", "f32") == "f32" and e.get("regime") != "lowrate"), None)
+            v = {1: pick(100), 2: pick(50), 4: pick(25), 8: pick(13)}
+            if v[1]:
+                predicted[cfg] = {"Mpixel_per_s": {str(n): (None if x is None else round(n * x / 1e6, 2)) for n, x in v.items()},
+                                  "speedup": {str(n): (None if x is None else round(n * x / v[1], 2)) for n, x in v.items()}}
+        predicted["how"] = ("N x the measured 1-GPU rate of one rank's share (100, 50, 25, 13 chains) of the same 100-chain job; no "
+                            "collective while coding; reference stream format: the serial rANS chain bounds few-chain steps (DESIGN 5)")
+
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
         try:
@@ -706,11 +740,20 @@ def main(args):
                    "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32" if arith == "fp32" else arith, "conv_path": conv_path,
                    "forked_block_step": forked,
                    "weights": "seeded random init (no checkpoints offline)"
-                              + (", calibrated to the low-rate regime (workload.calibrate_lowrate)" if args.regime else "")},
+                              + (", calibrated to the low-rate regime (workload.calibrate_lowrate)" if args.regime else ""),
+                   # the other shapes measured by this run, each in a process of its own like the headline (full records:
+                   # `extra`): label -> [Mpixel/s enc+dec, ms per step, lossless]; and the strong-scaling curve they predict
+                   "measured_shapes": shapes, "predicted_scaling": predicted},
         "rccl_ranks": (world if (world > 1 and (os.environ.get("BENCH_DIST_BACKEND") or "nccl") == "nccl") else 0),
         "lossless": r["lossless"], "bits_per_dim": round(r["bits_per_dim"], 4),
         "stream_time_fraction": r["stream_time_fraction"],
         "roofline": r["roofline"], "cpu_baseline": cpu, "stream_gather": r["stream_gather"], "extra": extra,
+        # last on the line so that a reader of the line's tail sees them: the shapes and the curve again, compact
+        "summary": {"headline_Mpixel_per_s": round(r["value"] / 1e6, 3), "ms_per_step": round(r["ms_per_step"], 3),
+                    "lossless": r["lossless"], "path_frac": (r["roofline"] or {}).get("frac"),
+                    "valu_issue_frac": (r["roofline"] or {}).get("valu_issue_frac"),
+                    "measured_shapes": shapes, "predicted_scaling": {k: v.get("Mpixel_per_s") for k, v in (predicted or {}).items()
+                                                                     if isinstance(v, dict)} or None},
     }
     if strong:
         out["config"].update({"total_chains": args.total_chains, "chains_per_rank": [len(p[0]) for p in plan],

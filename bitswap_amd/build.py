@@ -13,12 +13,24 @@ SRCS = [os.path.join(HERE, "csrc", f) for f in ("bitswap_hip.hip", "tables.hip",
 HDR = os.path.join(HERE, "..", "include", "bitswap_hip.h")
 DEV_HDR = os.path.join(HERE, "csrc", "bitswap_dev.h")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-LIB = os.environ.get("BITSWAP_HIP_LIB") or os.path.join(HERE, "csrc", "libbitswap_hip.so")
+PRODUCT_LIB = os.path.join(HERE, "csrc", "libbitswap_hip.so")
 
 # -ffp-contract=off: the deterministic CDF spec forbids any fusion the source does not spell out
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-pass-failed"]   # K = 2048 rows cannot reach the occupancy hint of k_logistic; that is expected
 EXTRA_FLAGS = [f for f in os.environ.get("BITSWAP_HIPCC_EXTRA", "").split() if f]   # e.g. -DBS_GEMM_LAB (tools/gemm_probe.py)
+
+
+def _flag_hash():
+    import hashlib
+    return hashlib.md5(" ".join([f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS).encode()).hexdigest()[:8]
+
+
+# A build with extra flags (lab kernels that give WRONG results, selectable by environment) never lands on the product's
+# path: its library carries the flag hash in its name, like its object directory -- so a later default-flag process cannot
+# pick it up as "fresh", and a lab run never reuses the product library (round 4: both shared libbitswap_hip.so).
+LIB = os.environ.get("BITSWAP_HIP_LIB") or (os.path.join(HERE, "csrc", f"libbitswap_hip_{_flag_hash()}.so") if EXTRA_FLAGS
+                                             else PRODUCT_LIB)
 
 
 def hipcc_path():
@@ -60,10 +72,9 @@ def build_hip(force=False, verbose=False):
     if not (force or is_stale()):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
-    import hashlib
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS
     # objects of another flag set (tools/gemm_probe.py --lab appends -DBS_GEMM_LAB) never mix with the product's
-    objdir = OBJ_DIR + "_" + hashlib.md5(" ".join(cflags).encode()).hexdigest()[:8]
+    objdir = OBJ_DIR + "_" + _flag_hash()
     os.makedirs(objdir, exist_ok=True)
     deps = max(os.path.getmtime(p) for p in (HDR, DEV_HDR, os.path.abspath(__file__)))
 

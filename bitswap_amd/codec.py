@@ -940,6 +940,8 @@ class GroupedCodec:
         self.bulk = None
         self.group_streams = None
         gs = os.environ.get("BITSWAP_GROUP_STREAMS", "auto")
+        if int(os.environ.get("BITSWAP_SERIAL_CUS", "0")):
+            gs = "0"
         be = self.codecs[0].backend
         one_stream = gs == "1" or (gs == "auto" and (isinstance(be, Hip64Backend) or getattr(be, "pivot", False)))
         if groups > 1 and one_stream:
@@ -949,11 +951,25 @@ class GroupedCodec:
             # split (800 chains: 152.5 vs 157.9 ms per step, profiles/r03r; round 2, with the row-reading pop: 164.8 vs 164.2)
             self.group_streams = [torch.cuda.Stream(device=self.device) for _ in self.codecs]
         elif groups > 1:
-            self.bulk = torch.cuda.Stream(device=self.device)
+            # BITSWAP_SERIAL_CUS=n (round 5 experiment, VERDICT r4 #1c; scheduling only): the serial streams -- the pop / push
+            # kernels, one wavefront per chain -- restricted to n compute units (mask bits 0 .. n-1: n / 8 per XCD) and the bulk
+            # streams to the others, so that the coder wavefronts do not sit on the SIMDs of the GEMMs and table kernels.
+            # Takes the bulk + serial arrangement (BITSWAP_GROUP_STREAMS=0); set BITSWAP_GEMM_CUS to the bulk CU count as well.
+            ncu = int(os.environ.get("BITSWAP_SERIAL_CUS", "0"))
+            total_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            self._masked = []
+
+            def stream(first, n):
+                if not ncu:
+                    return torch.cuda.Stream(device=self.device)
+                m = hip.MaskedStream(first, n, self.device)
+                self._masked.append(m)
+                return m.stream
+            self.bulk = stream(ncu, total_cus - ncu)
             own = os.environ.get("BITSWAP_BULK_PER_GROUP", "1") == "1"
             for c in self.codecs:
-                c.bulk = torch.cuda.Stream(device=self.device) if own else self.bulk
-                c.serial = torch.cuda.Stream(device=self.device)
+                c.bulk = stream(ncu, total_cus - ncu) if own else self.bulk
+                c.serial = stream(0, ncu)
 
     def split(self, n):
         g = len(self.codecs)

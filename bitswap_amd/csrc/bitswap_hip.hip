@@ -111,6 +111,41 @@ const char* bs_strerror(int code) {
     }
 }
 
+int bs_stream_create_cu_mask(int first_cu, int n_cus, void** stream_out) {
+    // mask bit b = compute unit b / nxcd of XCD b % nxcd (the driver deals the bits of a queue's mask round the XCDs), so a run
+    // of n_cus = 8 m consecutive bits is m compute units on each of the 8 XCDs
+    if (!stream_out || first_cu < 0 || n_cus < 1 || first_cu + n_cus > 1024) return BS_EINVAL;
+    uint32_t mask[32] = {};
+    for (int b = first_cu; b < first_cu + n_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)((first_cu + n_cus + 31) / 32), mask) != hipSuccess) {
+        (void)hipGetLastError();
+        return BS_ELAUNCH;
+    }
+    *stream_out = st;
+    return BS_OK;
+}
+
+int bs_stream_destroy(void* stream) {
+    if (!stream) return BS_EINVAL;
+    return hipStreamDestroy(S(stream)) == hipSuccess ? BS_OK : BS_ELAUNCH;
+}
+
+// where the wavefronts of a launch on `stream` land: ids_out[i] = HW_ID of workgroup i's first wavefront (bits 8..11 CU,
+// 12 SH, 13..15 SE) | XCC_ID << 16, n workgroups of one wavefront that spin ~spin_cycles so that the launch spreads
+__global__ void k_where(uint32_t* ids, int spin) {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_ID
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));       // XCC_ID
+    const uint64_t t0 = __builtin_readcyclecounter();
+    while ((int64_t)(__builtin_readcyclecounter() - t0) < spin) {}
+    if (threadIdx.x == 0) ids[blockIdx.x] = (hw & 0xffffu) | ((xcc & 0xfu) << 16);
+}
+int bs_debug_where(uint32_t* ids_out, int n, int spin_cycles, void* stream) {
+    if (!ids_out || n < 1) return BS_EINVAL;
+    hipLaunchKernelGGL(k_where, dim3((unsigned)n), dim3(64), 0, S(stream), ids_out, spin_cycles);
+    return launch_rc();
+}
+
 int bs_gather_centres(const double* centres, int64_t c_stride, const int32_t* sym, int B, int D, int K,
                       float* centre_out, void* stream) {
     if (!centres || !sym || !centre_out || B < 0 || D < 0 || K < 1 || c_stride < 0) return BS_EINVAL;

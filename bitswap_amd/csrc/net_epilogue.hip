@@ -691,7 +691,7 @@ int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act
     if (N == 0) return BS_OK;
     const int64_t groups = (N + IMG - 1) / IMG;
     // channels per block: as many as leave the launch a few blocks per CU slot (2 blocks fit a CU at 77 KB each)
-    static const int forced = [] { const char* e = getenv("BITSWAP_CONV3_CPB"); return e ? atoi(e) : 0; }();
+    const int forced = [] { const char* e = getenv("BITSWAP_CONV3_CPB"); return e ? atoi(e) : 0; }();
     int cpb = 64;
     while (cpb > 8 && groups * ((C + cpb - 1) / cpb) < 1536) cpb /= 2;
     if (forced >= 8 && forced % 8 == 0) cpb = forced;

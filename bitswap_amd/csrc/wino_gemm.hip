@@ -438,6 +438,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restric
 }
 
 int cu_count() {
+    // BITSWAP_GEMM_CUS: the compute units the launch stream may use when it is a CU-masked one (bitswap_amd.hip.MaskedStream:
+    // the persistent grid is sized by the CUs it can reach, not by the chip)
+    if (const char* e = getenv("BITSWAP_GEMM_CUS")) {
+        const int v = atoi(e);
+        if (v > 0) return v;
+    }
     // multiprocessor count of the current device (a device attribute, not library state)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess
@@ -456,7 +462,7 @@ int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int C
     // at most BITSWAP_GEMM_NS3_UNITS units (default: four per resident workgroup slot of the two-stage shape); results are
     // bitwise the same either way
     const int per_cu2 = BM >= 128 ? 2 : BM == 64 ? 4 : 6;
-    static const long ns3_units = [] { const char* e = getenv("BITSWAP_GEMM_NS3_UNITS"); return e ? atol(e) : -1L; }();
+    const long ns3_units = [] { const char* e = getenv("BITSWAP_GEMM_NS3_UNITS"); return e ? atol(e) : -1L; }();
     const int64_t small = ns3_units >= 0 ? ns3_units : (int64_t)cu_count() * per_cu2 * 4;
     const bool ns3 = Cin >= 2 * G_BK && units <= small;
     const size_t shm = (ns3 ? 3 : 2) * (size_t)(BM * G_LDA + G_BK * G_LDB) * sizeof(float);
@@ -464,16 +470,16 @@ int launch_gemm(const float* U, const float* V, float* M, int T, int Cout, int C
     // lane); the one-wave shape of the head convolutions is bounded by its 20 / 30 KB of LDS
     const int per_cu = ns3 ? (BM >= 128 ? 2 : BM == 64 ? 4 : 5) : per_cu2;
     int64_t G = (int64_t)cu_count() * per_cu;
-    static const int wgs_env = [] { const char* e = getenv("BITSWAP_GEMM_WGS_PER_CU"); return e ? atoi(e) : 0; }();   // tuning only
+    const int wgs_env = [] { const char* e = getenv("BITSWAP_GEMM_WGS_PER_CU"); return e ? atoi(e) : 0; }();   // tuning only
     if (wgs_env > 0) G = (int64_t)cu_count() * wgs_env;
     // few units per workgroup slot: fewer workgroups with whole four-block chunks (an A tile fetched per 128 columns instead of
     // per 32 or 64, the hand-pipelined chunk code) beat one or two units on every slot -- BITSWAP_GEMM_MIN_UNITS per workgroup
-    static const int min_units = [] { const char* e = getenv("BITSWAP_GEMM_MIN_UNITS"); return e ? atoi(e) : 1; }();
+    const int min_units = [] { const char* e = getenv("BITSWAP_GEMM_MIN_UNITS"); return e ? atoi(e) : 1; }();
     if (min_units > 1 && G * min_units > units) G = (units + min_units - 1) / min_units;
     if (G > units) G = units;
     if (G < 1) G = 1;
-    static const int variant = [] { const char* e = getenv("BITSWAP_GEMM_VARIANT"); return e ? atoi(e) : 2; }();     // tuning only
-    static const int even = getenv("BITSWAP_GEMM_EVEN_RANGES") ? 1 : 0;
+    const int variant = [] { const char* e = getenv("BITSWAP_GEMM_VARIANT"); return e ? atoi(e) : 2; }();     // tuning only
+    const int even = getenv("BITSWAP_GEMM_EVEN_RANGES") ? 1 : 0;
     auto go = [&](auto kern) {
         if (shm > 48 * 1024) {                 // more than the default dynamic LDS limit: raise it once per kernel and device
             static bool raised[16] = {};

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -52,7 +53,10 @@ union Pack8 {
 // limb products of one k block in the order they are added (i = limb of a, j = limb of b): small terms first
 __device__ constexpr int X_ORDER9[9][2] = {{2, 2}, {1, 2}, {2, 1}, {0, 2}, {1, 1}, {2, 0}, {0, 1}, {1, 0}, {0, 0}};
 
-template <int NPROD, int LAB = 0>     // LAB != 0: timing experiments with WRONG results (-DBS_GEMM_LAB builds only)
+// CLAIM / STRICT: diagnostics of the co-residency failure (BITSWAP_BF16X3_DIAG, tests/test_codec_gpu.py::test_bf16x3_gemm_beside_a_small_kernel):
+// CLAIM = false leaves the register share as the compiler sized it (a small wavefront of another kernel then fits beside this
+// one on the SIMD); STRICT = true replaces every counted wait by vmcnt(0).
+template <int NPROD, int LAB = 0, bool CLAIM = true, bool STRICT = false>     // LAB != 0: timing experiments with WRONG results (-DBS_GEMM_LAB builds only)
 __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
                                                               float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                               int ncc, int nrt) {
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
     // (tools/bf16x3_stress.py), with one hardware queue, or with 448 registers (NPROD = 9) was bit-exact every time.  With
     // nothing beside it: lossless 6 / 6.  Cause not established (LABNOTES.md); occupancy is one by design, so this costs
     // nothing but the co-residency of small wavefronts on these SIMDs.
-    asm volatile("" ::: "v255");
+    if constexpr (CLAIM) asm volatile("" ::: "v255");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;
     // chunk of this workgroup: (t, row tile, 256-column chunk).  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8),
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
         interleave();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (decltype(dma)::value) {
-            __builtin_amdgcn_s_waitcnt(0x007A);                           // vmcnt(10), lgkmcnt(0): stage kt + 1 has landed
+            if constexpr (STRICT) __builtin_amdgcn_s_waitcnt(0x0070);
+            else __builtin_amdgcn_s_waitcnt(0x007A);                      // vmcnt(10), lgkmcnt(0): stage kt + 1 has landed
             __builtin_amdgcn_s_barrier();                                 // ... in every wavefront; stage kt is in registers everywhere
             if (!(LAB & 4)) load_stage((kt + 3) * X_BK, kt % 3);          // into the buffer stage kt lived in
         } else {
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
         interleave();
         __builtin_amdgcn_sched_barrier(0);
         read_b(nx, 1);
-        if constexpr (decltype(dma)::value) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): the fragments of step kt + 1 are here
+        if constexpr (decltype(dma)::value && !STRICT) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): the fragments of step kt + 1 are here
         else __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
         if (!(LAB & 4)) {
             landed(an);
@@ -300,12 +305,12 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
 // split of two column tiles) with a burst of 4 NPROD back-to-back MFMAs, and while one splits the other multiplies.
 constexpr int Y_BN = 128, Y_STAGE = X_BK * Y_BN * 4;      // 8 KB per stage, three stages per workgroup
 
-template <int NPROD>
+template <int NPROD, bool CLAIM = true, bool STRICT = false>
 __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
                                                                  float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                                  int ncc, int nrt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [3][Y_STAGE]
-    asm volatile("" ::: "v255");                                 // the whole 256-register share of the SIMD (see k_wino_gemm_bf16x3)
+    if constexpr (CLAIM) asm volatile("" ::: "v255");            // the whole 256-register share of the SIMD (see k_wino_gemm_bf16x3)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;
     const int nwg = gridDim.x;
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
     read_b(lds);
     auto step = [&](int kt, auto dma) {
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (decltype(dma)::value) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): this step's fragments are here
+        if constexpr (decltype(dma)::value && !STRICT) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): this step's fragments are here
         else __builtin_amdgcn_s_waitcnt(0x0F70);
         landed_a();
         split_pair(0);
@@ -432,7 +437,8 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
         __builtin_amdgcn_sched_barrier(0);
         load_a_async(min(kt + 1, nk - 1));
         if constexpr (decltype(dma)::value) {
-            __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8), lgkmcnt(0): stage kt + 1 has landed
+            if constexpr (STRICT) __builtin_amdgcn_s_waitcnt(0x0070);
+            else __builtin_amdgcn_s_waitcnt(0x0078);                      // vmcnt(8), lgkmcnt(0): stage kt + 1 has landed
             __builtin_amdgcn_s_barrier();
             load_stage((kt + 3) * X_BK, kt % 3);
         } else {
@@ -483,7 +489,7 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     if (wgs > 0x7fffffff || (int64_t)Cin * cols > 0x7fffffff) return BS_EUNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     size_t shm = 3 * (size_t)X_STAGE;
-    static const long lds_pad = [] { const char* e = getenv("BITSWAP_BF16X3_LDS_PAD"); return e ? atol(e) : 0L; }();   // diagnostics
+    const long lds_pad = [] { const char* e = getenv("BITSWAP_BF16X3_LDS_PAD"); return e ? atol(e) : 0L; }();   // diagnostics
     shm += (size_t)lds_pad;
     if (shm > 48 * 1024) {
         static bool raised = false;
@@ -504,15 +510,35 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
     }
 #endif
-    static const int shape = [] { const char* e = getenv("BITSWAP_BF16X3_SHAPE"); return e ? atoi(e) : 2; }();   // tuning only: same bits
+    // BITSWAP_BF16X3_SHAPE=1 (the one-workgroup-per-CU shape) and BITSWAP_BF16X3_DIAG (noclaim | noclaim_strict: the kernels
+    // WITHOUT the whole-register-share claim, with counted or with vmcnt(0) waits) exist for the co-residency diagnostics
+    // only: the unclaimed shape-1 kernel gave wrong products beside a small wavefront of another kernel (LABNOTES r04/r05)
+    const char* shape_env = getenv("BITSWAP_BF16X3_SHAPE");
+    const char* diag = getenv("BITSWAP_BF16X3_DIAG");
+    const int shape = shape_env ? atoi(shape_env) : 2;
+    const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : -1;
+    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6)) return BS_EINVAL;
+#define BS_X3_O2(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<NP, CL, ST>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt)
+#define BS_X3_O1(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3<NP, 0, CL, ST>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt)
     if (shape == 2) {                     // two workgroups of 256 x 128 per CU (default)
         const int64_t ncc2 = (cols + Y_BN - 1) / Y_BN, wgs2 = (int64_t)T * nrt * ncc2;
         if (wgs2 > 0x7fffffff) return BS_EUNSUPPORTED;
         const size_t shm2 = 3 * (size_t)Y_STAGE;
-        if (nprod == 9)
-            hipLaunchKernelGGL(k_wino_gemm_bf16x3_o2<9>, dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
-        else
-            hipLaunchKernelGGL(k_wino_gemm_bf16x3_o2<6>, dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
+        if (dg == 1) BS_X3_O2(6, false, false);
+        else if (dg == 2) BS_X3_O2(6, false, true);
+        else if (nprod == 9) BS_X3_O2(9, true, false);
+        else BS_X3_O2(6, true, false);
+        return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
+    }
+    if (dg) {
+        static bool raised_d = false;
+        if (!raised_d) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3<6, 0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3<6, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised_d = true;
+        }
+        if (dg == 1) BS_X3_O1(6, false, false);
+        else BS_X3_O1(6, false, true);
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
     }
     if (nprod == 9)

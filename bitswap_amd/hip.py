@@ -6,6 +6,8 @@ raises.  torch is used only for device memory and the current HIP stream.
 import ctypes as C
 import os
 
+import numpy as np
+
 import torch
 
 from . import build as _build
@@ -19,7 +21,7 @@ LAYOUT_LINEAR, LAYOUT_WAVE, LAYOUT_PIVOT = 0, 1, 2
 SYMBOLS = [
     "bs_abi_version", "bs_cdf_spec", "bs_strerror", "bs_table_rows_f64", "bs_logistic_tables",
     "bs_logistic_fc", "bs_rans_push", "bs_rans_push_table", "bs_rans_pop", "bs_rans_pop_pivot", "bs_gather_centres", "bs_layer_pop64",
-    "bs_layer_push64",
+    "bs_layer_push64", "bs_stream_create_cu_mask", "bs_stream_destroy", "bs_debug_where",
     "bs_selftest", "bs_sigmoid_f64", "bs_bias_residual_elu_f32", "bs_head_params_f32", "bs_expand_rows5_f32", "bs_wino_in_f32", "bs_wino_out_f32", "bs_wino_fused_f32",
     "bs_small_k_gemm_f32", "bs_conv3_wino_f32", "bs_wino_gemm_f32", "bs_wino_gemm_bf16x3",
 ]
@@ -63,6 +65,9 @@ def load():
     L.bs_rans_pop_pivot.argtypes = [p, p, p, i64, p, i64, p, i64, p, i32, p, p, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
     L.bs_gather_centres.argtypes = [p, i64, p, i32, i32, i32, p, p]
     L.bs_layer_pop64.argtypes = [p, p, p, i64, p, i64, p, i32, p, p, i64, i32, i32, i32, i32, i32, i32, p, p, i64, p, p, p]
+    L.bs_stream_create_cu_mask.argtypes = [i32, i32, p]
+    L.bs_stream_destroy.argtypes = [p]
+    L.bs_debug_where.argtypes = [p, i32, i32, p]
     L.bs_layer_push64.argtypes = [p, p, p, i64, p, i64, p, i32, p, p, i64, i32, p, i32, i32, i32, i32, i32, p, p]
     L.bs_selftest.argtypes = [C.POINTER(C.c_int64), p]
     L.bs_sigmoid_f64.argtypes = [p, i64, p, p]
@@ -528,6 +533,39 @@ def layer_push64(state, endpoints, mu, scale, sym, bits=31, quantbits=10, step=N
                                   quantbits, _ptr(state.status), _stream()), "bs_layer_push64")
 
 
+class MaskedStream:
+    """A HIP stream whose kernels run on the compute units of mask bits [first_cu, first_cu + n_cus) only
+    (bs_stream_create_cu_mask: 8 m consecutive bits = m CUs on each of the 8 XCDs), wrapped for `torch.cuda.stream()`.
+    Scheduling only: results do not depend on where a kernel runs."""
+
+    def __init__(self, first_cu, n_cus, device=None):
+        h = C.c_void_p()
+        _check(load().bs_stream_create_cu_mask(int(first_cu), int(n_cus), C.byref(h)), "bs_stream_create_cu_mask")
+        self.handle, self.first_cu, self.n_cus = h.value, int(first_cu), int(n_cus)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.ExternalStream(self.handle, device=dev)
+
+    def close(self):
+        if self.handle:
+            self.stream.synchronize()
+            load().bs_stream_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+
+def where(n, spin_cycles=20000, stream=None):
+    """Diagnostics: launch n one-wavefront workgroups on `stream` (torch stream; default: the current one) and return where
+    each ran as (xcc, se, sh, cu) tuples (bs_debug_where)."""
+    ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+    if stream is None:
+        _check(load().bs_debug_where(_ptr(ids), n, spin_cycles, _stream()), "bs_debug_where")
+    else:
+        with torch.cuda.stream(stream):
+            _check(load().bs_debug_where(_ptr(ids), n, spin_cycles, _stream()), "bs_debug_where")
+    torch.cuda.synchronize()
+    v = ids.cpu().numpy().view(np.uint32)
+    return [(int(x >> 16) & 15, int(x >> 13) & 7, int(x >> 12) & 1, int(x >> 8) & 15) for x in v]
+
+
 def gather_centres(centres, sym):
     """z[b,d] = float32(centres[d, sym[b,d]])  (mnist_compress.py:181,196 + Model's .float())."""
     _need_cuda(centres, sym)
@@ -670,10 +708,27 @@ def split_bf16x3(U):
     return torch.stack([x0, x1, x2], 0).contiguous()
 
 
+class FragsBf16x3:
+    """The weight operand of bs_wino_gemm_bf16x3: the pre-tiled limb fragments together with the logical shape they were cut
+    from (round 4 hung the shape on the tensor as an ad-hoc attribute, which any .to() / .clone() silently dropped)."""
+
+    __slots__ = ("frags", "T", "Cout", "Cin")
+
+    def __init__(self, frags, T, Cout, Cin):
+        want = (T, (Cout + 31) // 32, Cin // 16, 3, 64, 8)
+        if frags.dtype != torch.bfloat16 or not frags.is_contiguous() or tuple(frags.shape) != want:
+            raise BitswapHipError(f"bf16x3 fragments must be a contiguous bfloat16 tensor of shape {want}, got {tuple(frags.shape)}")
+        self.frags, self.T, self.Cout, self.Cin = frags, int(T), int(Cout), int(Cin)
+
+    def to(self, *a, **k):
+        return FragsBf16x3(self.frags.to(*a, **k).contiguous(), self.T, self.Cout, self.Cin)
+
+
 def frags_bf16x3(U):
     """The weight operand bs_wino_gemm_bf16x3 takes: U [T, Cout, Cin] float32 split into its three bfloat16 limbs and
     pre-tiled as MFMA A fragments, [T, ceil(Cout/32), Cin/16, 3, 64, 8] -- lane l = 32 (k // 8) + row of a 32-row tile holds 8
-    consecutive k of a 16-deep block (include/bitswap_hip.h).  Rows beyond Cout are zero.  Done once per model (Model.fuse())."""
+    consecutive k of a 16-deep block (include/bitswap_hip.h).  Rows beyond Cout are zero.  Done once per model (Model.fuse()).
+    -> FragsBf16x3 (fragments + the shape they stand for)."""
     assert U.dtype == torch.float32 and U.dim() == 3 and U.shape[2] % 16 == 0
     T, Cout, Cin = U.shape
     pad = (-Cout) % 32
@@ -683,24 +738,24 @@ def frags_bf16x3(U):
     R = Cout + pad
     L = L.view(3, T, R // 32, 32, Cin // 16, 2, 8)                  # limb, t, row tile, row, k block, k half, k
     L = L.permute(1, 2, 4, 0, 5, 3, 6).contiguous()                 # t, row tile, k block, limb, k half, row, k
-    out = L.view(T, R // 32, Cin // 16, 3, 64, 8)
-    out.bs_shape = (T, Cout, Cin)
-    return out
+    return FragsBf16x3(L.view(T, R // 32, Cin // 16, 3, 64, 8), T, Cout, Cin)
 
 
 def wino_gemm_bf16x3(Uf, V, nprod=6, out=None):
     """M [T, Cout, cols] = U x V with U given as frags_bf16x3(U) and V [T, Cin, cols] float32 split in the kernel: nprod limb
     products per k block on the bf16 matrix cores, float32 accumulation, one fixed order per output
     (include/bitswap_hip.h, bs_wino_gemm_bf16x3).  Opt-in arithmetic."""
-    _need_cuda(Uf, V, out)
-    T, Cout, Cin = Uf.bs_shape
-    assert Uf.dtype == torch.bfloat16 and Uf.is_contiguous() and tuple(Uf.shape) == (T, (Cout + 31) // 32, Cin // 16, 3, 64, 8)
+    if not isinstance(Uf, FragsBf16x3):
+        raise BitswapHipError("wino_gemm_bf16x3 takes the FragsBf16x3 that frags_bf16x3() returns")
+    _need_cuda(Uf.frags, V, out)
+    T, Cout, Cin = Uf.T, Uf.Cout, Uf.Cin
     assert V.dtype == torch.float32 and V.dim() == 3 and V.is_contiguous()
-    assert V.shape[0] == T and V.shape[1] == Cin and V.shape[2] % 4 == 0
+    if V.shape[0] != T or V.shape[1] != Cin or V.shape[2] % 4:
+        raise BitswapHipError(f"V {tuple(V.shape)} does not go with fragments of a [{T}, {Cout}, {Cin}] operand (columns: multiple of 4)")
     cols = V.shape[2]
     M = out if out is not None else torch.empty((T, Cout, cols), dtype=torch.float32, device=V.device)
     assert M.is_contiguous() and tuple(M.shape) == (T, Cout, cols) and M.dtype == torch.float32
-    _check(load().bs_wino_gemm_bf16x3(_ptr(Uf), _ptr(V), _ptr(M), T, Cout, Cin, cols, int(nprod), _stream()), "bs_wino_gemm_bf16x3")
+    _check(load().bs_wino_gemm_bf16x3(_ptr(Uf.frags), _ptr(V), _ptr(M), T, Cout, Cin, cols, int(nprod), _stream()), "bs_wino_gemm_bf16x3")
     return M
 
 

@@ -218,6 +218,19 @@ int bs_gather_centres(const double* centres, int64_t c_stride, const int32_t* sy
                       float* centre_out, void* stream);
 
 /*
+ * Scheduling helpers (no reference counterpart; round 5, VERDICT r4 #1c): a HIP stream whose kernels run on a subset of the
+ * compute units, so that the one-wavefront-per-chain coder kernels can be kept off the CUs the bulk kernels fill.
+ * bs_stream_create_cu_mask -- *stream_out = a stream restricted to the n_cus mask bits [first_cu, first_cu + n_cus); the driver
+ *   deals the mask bits round the 8 XCDs (bit b = XCD b % 8), so 8 m consecutive bits are m CUs on every XCD.  HOST pointers.
+ * bs_stream_destroy -- destroys it.
+ * bs_debug_where -- diagnostics: n one-wavefront workgroups that spin spin_cycles and record where they ran
+ *   (ids_out[i] = HW_ID[15:0] | XCC_ID << 16, device pointer): how the tests check what a mask really does.
+ */
+int bs_stream_create_cu_mask(int first_cu, int n_cus, void** stream_out);
+int bs_stream_destroy(void* stream);
+int bs_debug_where(uint32_t* ids_out, int n, int spin_cycles, void* stream);
+
+/*
  * bs_selftest -- runs the wave-level primitives (DPP scan / reductions) and the deterministic
  * sigmoid against in-kernel scalar restatements; host pointer `failures` receives the number of
  * mismatching lanes.  Synchronises the stream.  For tests only.

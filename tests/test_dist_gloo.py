@@ -139,8 +139,8 @@ def test_strong_scaling_plan_partitions_and_balances():
     assert [len(p[0]) for p in bench.strong_plan(100, 8, "imagenet4", 6)] == [13, 13, 13, 13, 12, 12, 12, 12]
 
 
-def _worker_strong(rank, world, port, outdir):
-    """bench.py's strong-scaling exchange at world size 2 over gloo: every rank makes the streams of ITS chains of the plan
+def _worker_strong(rank, world, port, outdir, total=11):
+    """bench.py's strong-scaling exchange over gloo: every rank makes the streams of ITS chains of the plan
     (here: a function of the global chain id), rank 0 gathers all of them and the digest is the one a single process gets."""
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -150,11 +150,11 @@ def _worker_strong(rank, world, port, outdir):
     bench = _bench()
     assert dist.init("gloo") == (rank, world)
     for name in ("imagenet4", "imagenetcrop4"):
-        ids, lengths = bench.strong_plan(11, world, name, 8)[rank]
+        ids, lengths = bench.strong_plan(total, world, name, 8)[rank]
         streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
-        g = bench.gather_and_digest(streams, ids, 11, rank)
+        g = bench.gather_and_digest(streams, ids, total, rank)
         if rank == 0:
-            assert g["complete"] and g["own_streams_intact"] and g["chains"] == 11
+            assert g["complete"] and g["own_streams_intact"] and g["chains"] == total
             with open(os.path.join(outdir, f"digest_{name}_w{world}.txt"), "w") as f:
                 f.write(g["crc32_of_streams_in_chain_order"])
         else:
@@ -173,6 +173,21 @@ def test_strong_scaling_gather_digest_is_independent_of_world_size(tmp_path):
         streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
         one = bench.gather_and_digest(streams, ids, 11, 0)
         assert one["crc32_of_streams_in_chain_order"] == open(tmp_path / f"digest_{name}_w2.txt").read()
+
+
+def test_eight_rank_strong_plan_and_gather(tmp_path):
+    """The world size north_star's curve ends at: BASELINE configs 4 / 5 -- 100 chains in total -- planned over
+    EIGHT ranks (13, 13, 13, 13, 12, 12, 12, 12 equal chains round-robin; the ragged crop chains by LPT), every rank's streams
+    gathered to rank 0 over gloo, and the CRC-32 of the streams in chain order equal to the one a single process computes."""
+    mp.spawn(_worker_strong, args=(8, free_port(), str(tmp_path), 100), nprocs=8, join=True)
+    bench = _bench()
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    for name in ("imagenet4", "imagenetcrop4"):
+        ids, lengths = bench.strong_plan(100, 1, name, 8)[0]
+        streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
+        one = bench.gather_and_digest(streams, ids, 100, 0)
+        assert one["crc32_of_streams_in_chain_order"] == open(tmp_path / f"digest_{name}_w8.txt").read()
 
 
 def test_two_rank_gather_and_sharded_experiment(tmp_path):
