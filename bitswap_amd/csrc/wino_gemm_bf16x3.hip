@@ -56,7 +56,10 @@ __device__ constexpr int X_ORDER9[9][2] = {{2, 2}, {1, 2}, {2, 1}, {0, 2}, {1, 1
 // CLAIM / STRICT: diagnostics of the co-residency failure (BITSWAP_BF16X3_DIAG, tests/test_codec_gpu.py::test_bf16x3_gemm_beside_a_small_kernel):
 // CLAIM = false leaves the register share as the compiler sized it (a small wavefront of another kernel then fits beside this
 // one on the SIMD); STRICT = true replaces every counted wait by vmcnt(0).
-template <int NPROD, int LAB = 0, bool CLAIM = true, bool STRICT = false>     // LAB != 0: timing experiments with WRONG results (-DBS_GEMM_LAB builds only)
+// STRAY = true RE-INTRODUCES the round-4 defect for the record: every step issues its LDS-DMA (the last three re-fetch the final
+// stage) and the workgroup exits without waiting for them -- a write still in flight lands in the LDS of whatever workgroup the
+// CU runs next, which without the register claim may belong to ANOTHER kernel.
+template <int NPROD, int LAB = 0, bool CLAIM = true, bool STRICT = false, bool STRAY = false>     // LAB != 0: timing experiments with WRONG results (-DBS_GEMM_LAB builds only)
 __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
                                                               float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                               int ncc, int nrt) {
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
             if constexpr (STRICT) __builtin_amdgcn_s_waitcnt(0x0070);
             else __builtin_amdgcn_s_waitcnt(0x007A);                      // vmcnt(10), lgkmcnt(0): stage kt + 1 has landed
             __builtin_amdgcn_s_barrier();                                 // ... in every wavefront; stage kt is in registers everywhere
-            if (!(LAB & 4)) load_stage((kt + 3) * X_BK, kt % 3);          // into the buffer stage kt lived in
+            if (!(LAB & 4)) load_stage((STRAY ? min(kt + 3, nk - 1) : kt + 3) * X_BK, kt % 3);   // into the buffer stage kt lived in
         } else {
             __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0)
             __builtin_amdgcn_s_barrier();
@@ -272,7 +275,10 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
     };
     int kt = 0;
     for (; kt < nk - 3; ++kt) step(kt, std::true_type{});
-    for (; kt < nk; ++kt) step(kt, std::false_type{});
+    for (; kt < nk; ++kt) {
+        if constexpr (STRAY) step(kt, std::true_type{});
+        else step(kt, std::false_type{});
+    }
     // register v of lane l: row (v/4)*8 + (l/32)*4 + v%4 of the 32x32 tile, column l%32 -> chunk column 128 h + 4 (l%32) + ni
     float* Mt = M + (int64_t)t * Cout * cols;
 #pragma unroll
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0): nothing of this workgroup is in flight when its LDS is handed on
+    if constexpr (!STRAY) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): nothing of this workgroup is in flight when its LDS is handed on
 }
 
 
@@ -516,8 +522,8 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     const char* shape_env = getenv("BITSWAP_BF16X3_SHAPE");
     const char* diag = getenv("BITSWAP_BF16X3_DIAG");
     const int shape = shape_env ? atoi(shape_env) : 2;
-    const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : -1;
-    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6)) return BS_EINVAL;
+    const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : !strcmp(diag, "stray_exit") ? 3 : -1;
+    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6) || (dg == 3 && shape != 1)) return BS_EINVAL;
 #define BS_X3_O2(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<NP, CL, ST>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt)
 #define BS_X3_O1(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3<NP, 0, CL, ST>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt)
     if (shape == 2) {                     // two workgroups of 256 x 128 per CU (default)
@@ -535,9 +541,11 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         if (!raised_d) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3<6, 0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3<6, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3<6, 0, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             raised_d = true;
         }
         if (dg == 1) BS_X3_O1(6, false, false);
+        else if (dg == 3) hipLaunchKernelGGL((k_wino_gemm_bf16x3<6, 0, false, false, true>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt);
         else BS_X3_O1(6, false, true);
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
     }

@@ -2,7 +2,12 @@
 """Instruction mix of one kernel in a hipcc -S listing (which kernels are issue-bound and by what).
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -S --cuda-device-only -o /tmp/x.s bitswap_amd/csrc/tables.hip   (or pop.hip, push.hip, layer64.hip)
-    python tools/isa_count.py /tmp/x.s k_logisticILi16EfLi3ELb1E [more substrings of mangled names ...]
+    python tools/isa_count.py /tmp/x.s k_logisticILi16EfLi4ELi3E [more substrings of mangled names ...]
+    python tools/isa_count.py --blocks /tmp/x.s k_logisticILi16EfLi4ELi3E     per straight-line run between branches / labels
+
+--blocks: since CDF spec 3 the row loop of k_logistic holds two arms (batch inversion / spec 2's arithmetic for peaked rows) and
+a row takes ONE of them, so "largest loop" over-counts: the issue slots of a row are the runs it executes -- for
+k_logistic<16, float, pivot, spec 3>: row head 38 + batch arm 161 + integer tail 63 + store 6 = 268 (bench.py VALU_SLOTS_PER_ROW).
 """
 import sys
 from collections import Counter
@@ -31,8 +36,26 @@ def mix(ins, tag):
           f"vmem {pick(lambda k: k.startswith(('global_', 'buffer_', 'flat_')))}")
 
 
+def blocks(lines, name):
+    import re
+    b = body(lines, name)
+    if b is None:
+        print(name, "not found")
+        return
+    marks = sorted(set([0] + [i for i, l in enumerate(b) if re.match(r'^\s*s_c?branch', l) or re.match(r'^\.LBB', l)] + [len(b)]))
+    for a, e in zip(marks, marks[1:]):
+        ins = [l for l in b[a:e] if l and not l.startswith(('.', ';', '//')) and not l.split(';')[0].rstrip().endswith(':')]
+        if len(ins) >= 16:
+            mix(ins, f"{name} [lines {a}..{e}]")
+
+
 def main():
     import re
+    if sys.argv[1] == "--blocks":
+        lines = open(sys.argv[2]).read().split('\n')
+        for name in sys.argv[3:]:
+            blocks(lines, name)
+        return
     lines = open(sys.argv[1]).read().split('\n')
     for name in sys.argv[2:]:
         b = body(lines, name)

@@ -4,7 +4,7 @@
 TAG=${1:-rXX}; OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; R=$PWD
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
-  ( cd /tmp && rm -rf pv && timeout 300 rocprofv3 --pmc $set -d /tmp/pv -o pv --output-format csv -- python $R/tools/microbench.py --B 400 --iters 3 > /dev/null 2>$OUT/${TAG}_pmc_$n.err )
+  ( cd /tmp && rm -rf pv && timeout 300 rocprofv3 --pmc $set -d /tmp/pv -o pv --output-format csv -- python $R/tools/microbench.py --B 500 --iters 3 > /dev/null 2>$OUT/${TAG}_pmc_$n.err )
   python - <<PY
 import csv, glob, json, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))

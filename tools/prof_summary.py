@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output directories into small text/JSON summaries for profiles/.
 
-    python tools/prof_summary.py stats <dir> <out.txt>       # --kernel-trace --stats run
+    python tools/prof_summary.py stats <dir> <out.txt> [timed]   # --kernel-trace --stats run; `timed`: only the dispatches between
+                                                                 # the first and the last k_where sentinel (bench.py launches one on
+                                                                 # either side of its timed region when BITSWAP_BENCH_SENTINEL=1)
     python tools/prof_summary.py pmc <dir> <counter> <out.json>   # --pmc <counter> run
     python tools/prof_summary.py traffic <fetch.json> <write.json> <workload> <traffic.json> <rows per launch>
     python tools/prof_summary.py timeline <dir> <out.json>   # --kernel-trace run: who occupies the wall time of the steps
@@ -23,10 +25,19 @@ def short(name):
     return name if len(name) < 110 else name[:107] + "..."
 
 
-def stats(d, out):
+def stats(d, out, timed=False):
     rows = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    note = ""
     for f in find(d, "kernel_trace.csv"):
-        for r in csv.DictReader(open(f)):
+        recs = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+        if timed:
+            marks = [i for i, r in enumerate(recs) if "k_where" in r["Kernel_Name"]]
+            if len(marks) < 2:
+                continue                                  # a process without a timed region (or without the sentinels)
+            wall = (int(recs[marks[-1]]["Start_Timestamp"]) - int(recs[marks[0]]["End_Timestamp"])) * 1e-6
+            note += f"# timed region of {os.path.basename(f)}: {marks[-1] - marks[0] - 1} dispatches in {wall:.2f} ms between the k_where sentinels\n"
+            recs = [r for r in recs[marks[0] + 1: marks[-1]] if "k_where" not in r["Kernel_Name"]]
+        for r in recs:
             n = short(r["Kernel_Name"])
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
             a = rows[n]
@@ -36,18 +47,27 @@ def stats(d, out):
             a[3] = max(a[3], dur)
     tot = sum(a[1] for a in rows.values()) or 1.0
     with open(out, "w") as fo:
-        fo.write(f"# rocprofv3 --kernel-trace --stats summary of {d}\n")
+        fo.write(f"# rocprofv3 --kernel-trace --stats summary of {d}" + (" -- TIMED REGION ONLY" if timed else "") + "\n" + note)
         fo.write(f"# {'calls':>7} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}  kernel\n")
         for n, a in sorted(rows.items(), key=lambda kv: -kv[1][1]):
             fo.write(f"  {a[0]:7d} {a[1]:12.1f} {a[1] / a[0]:10.2f} {a[2]:10.2f} {a[3]:10.2f} {100 * a[1] / tot:6.2f}  {n}\n")
     print(open(out).read()[:3000])
 
 
-def pmc(d, counter, out):
+def pmc(d, counter, out, timed=False):
     acc = defaultdict(lambda: [0, 0.0])
     for f in find(d, "counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") != counter:
+        recs = list(csv.DictReader(open(f)))
+        if timed:       # dispatch order: keep what lies between the first and the last k_where sentinel
+            key = "Dispatch_Id" if recs and "Dispatch_Id" in recs[0] else None
+            if key:
+                recs.sort(key=lambda r: int(r[key]))
+            marks = [i for i, r in enumerate(recs) if "k_where" in r["Kernel_Name"]]
+            if len(marks) < 2:
+                continue
+            recs = recs[marks[0] + 1: marks[-1]]
+        for r in recs:
+            if r.get("Counter_Name") != counter or "k_where" in r["Kernel_Name"]:
                 continue
             a = acc[short(r["Kernel_Name"])]
             a[0] += 1
@@ -194,10 +214,10 @@ def traffic(fetch_json, write_json, workload, out, rows_per_launch):
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
-        stats(sys.argv[2], sys.argv[3])
+        stats(sys.argv[2], sys.argv[3], timed=len(sys.argv) > 4 and sys.argv[4] == "timed")
     elif sys.argv[1] == "timeline":
         timeline(sys.argv[2], sys.argv[3], *[float(x) for x in sys.argv[4:6]])
     elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], timed=len(sys.argv) > 5 and sys.argv[5] == "timed")
