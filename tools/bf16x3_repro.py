@@ -47,7 +47,33 @@ def fillers(dev, cols, C):
     }
 
 
-def micro(reps):
+def small_fillers(dev):
+    """Kernels of <= 24 registers: the only ones that fit beside two 240-register wavefronts of the unclaimed shape-2 kernel
+    (k_rans_push 21, k_head_params 20, k_gather_centres 13)."""
+    rng = np.random.RandomState(1)
+    B, D, K = 32, 2048, 1024
+    x = torch.from_numpy(rng.randn(B, 16, 16, 16).astype(np.float32)).to(dev)
+    bias = torch.from_numpy(rng.randn(16).astype(np.float32)).to(dev)
+    cen = torch.from_numpy(rng.randn(D, K)).to(dev)
+    sym = torch.from_numpy(rng.randint(0, K, (B, D)).astype(np.int32)).to(dev)
+    f = torch.from_numpy(rng.randint(1, 1 << 22, (B, D)).astype(np.int32)).to(dev)
+    c = torch.from_numpy(rng.randint(0, 1 << 30, (B, D)).astype(np.int32)).to(dev)
+    np.random.seed(2)
+    words = np.random.randint(1 << 16, (1 << 32) - 1, size=(B, 3000), dtype=np.uint32)
+    st = hip.RansState(B, 3000 + 4 * D, dev)
+    st.stack[:, :3000] = torch.from_numpy(words.view(np.int32)).to(dev)
+    h0 = torch.from_numpy((words[:, -1].astype(np.uint64) << np.uint64(32)).view(np.int64)).to(dev)
+
+    def push():
+        st.len.fill_(2999)
+        st.head.copy_(h0)
+        hip.rans_push(st, f, c)
+        return torch.cat([st.head.clone(), st.len.to(torch.int64), st.stack[:, 2999:3400].reshape(-1).to(torch.int64)])
+    return {"k_rans_push": push, "k_head_params": lambda: torch.cat(hip.head_params(x, bias, 0)),
+            "k_gather_centres": lambda: hip.gather_centres(cen, sym)}
+
+
+def micro(reps, small=False):
     dev = "cuda"
     torch.manual_seed(0)
     T, C, cols = 36, 256, 2048
@@ -58,7 +84,7 @@ def micro(reps):
     ref = hip.wino_gemm_bf16x3(Uf, V, 6).clone()
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
-    fl = fillers(dev, cols, C)
+    fl = small_fillers(dev) if small else fillers(dev, cols, C)
     res = {}
     fl_ref = {name: f().clone() for name, f in fl.items()}
     torch.cuda.synchronize()
@@ -96,7 +122,7 @@ def micro(reps):
     return res
 
 
-def codec_leg():
+def codec_leg(focus=False):
     """The forked codec (32 and 100 chains, cifar8 full width, bf16x3 arithmetic) per variant: lossless?"""
     import subprocess
     code = r'''
@@ -106,27 +132,33 @@ from bitswap_amd import workload
 from bitswap_amd.codec import BitSwapCodec, initial_states
 model, zend, zcen = workload.build("cifar8", "cuda", quantbits=10)
 out = {}
-for B in (32, 100):
+for B in [int(b) for b in os.environ.get("REPRO_B", "32,100").split(",")]:
     images = workload.synthetic_blocks(B * 2, model.xs, seed=19).view(B, 2, -1).to(torch.int32)
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
     if os.environ.get("REPRO_EAGER_FORK") == "1":      # round 4's failing scenario (profiles/archive/visits_r04/dbg3_bf16.py)
         codec.use_graphs = False
         codec.fork = "1"
     ok = 0
-    for rep in range(3):
+    NREP = int(os.environ.get("REPRO_REPS", "3"))
+    for rep in range(NREP):
         try:
             state, met = codec.compress(images.to("cuda"))
             back = codec.decompress(state, 2)
             ok += int(torch.equal(back.cpu(), images) and state.to_lists() == initial_states(B))
         except Exception as e:
             out[f"B{B}_err{rep}"] = repr(e)[:200]
-    out[f"B{B}_lossless"] = f"{ok}/3"
+    out[f"B{B}_lossless"] = f"{ok}/{NREP}"
 print("RESULT " + json.dumps(out))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     res = {}
-    for shape, diag, eager in (("2", None, "0"), ("2", "noclaim", "1"), ("1", None, "1"), ("1", "noclaim", "1"), ("1", "noclaim", "0"),
-                               ("1", "stray_exit", "1"), ("1", "stray_exit", "0")):
+    plan = (("2", None, "0"), ("2", "noclaim", "1"), ("1", None, "1"), ("1", "noclaim", "1"), ("1", "noclaim", "0"),
+            ("1", "stray_exit", "1"), ("1", "stray_exit", "0"))
+    if focus:      # the scenario that failed in round 5 visit c (shape 2 without the claim, eager forked codec, 32 chains): statistics
+        plan = (("2", "noclaim", "1"), ("2", "noclaim_strict", "1"), ("2", None, "1"), ("1", "noclaim", "1"), ("1", "noclaim_strict", "1"))
+    for shape, diag, eager in plan:
         env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK=eager)
+        if focus:
+            env.update(REPRO_REPS="14", REPRO_B="32")
         env.pop("BITSWAP_BF16X3_DIAG", None)
         if diag:
             env["BITSWAP_BF16X3_DIAG"] = diag
@@ -142,8 +174,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--codec", action="store_true")
+    ap.add_argument("--focus", action="store_true", help="codec leg only: the failing scenario with and without counted waits, 14 runs each")
+    ap.add_argument("--small", action="store_true", help="micro leg with the neighbours that fit beside the unclaimed shape-2 kernel (<= 32 registers)")
     a = ap.parse_args()
-    out = {"micro": micro(a.reps)}
-    if a.codec:
-        out["codec"] = codec_leg()
+    out = {}
+    if not a.focus or a.small:
+        out["micro"] = micro(a.reps, small=a.small)
+    if a.codec or a.focus:
+        out["codec"] = codec_leg(focus=a.focus)
     print(json.dumps(out, indent=1))
