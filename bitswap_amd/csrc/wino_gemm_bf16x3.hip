@@ -311,7 +311,9 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
 // split of two column tiles) with a burst of 4 NPROD back-to-back MFMAs, and while one splits the other multiplies.
 constexpr int Y_BN = 128, Y_STAGE = X_BK * Y_BN * 4;      // 8 KB per stage, three stages per workgroup
 
-template <int NPROD, bool CLAIM = true, bool STRICT = false>
+// LATE (diagnostics): the fragment loads of step k + 1, which land IN PLACE in the registers the multiplies of step k read, are
+// issued after the step's barrier instead of right behind the last multiply.
+template <int NPROD, bool CLAIM = true, bool STRICT = false, bool LATE = false>
 __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
                                                                  float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                                  int ncc, int nrt) {
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
     read_b(lds);
     auto step = [&](int kt, auto dma) {
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (decltype(dma)::value && !STRICT) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): this step's fragments are here
+        if constexpr (decltype(dma)::value && !STRICT && !LATE) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): this step's fragments are here
         else __builtin_amdgcn_s_waitcnt(0x0F70);
         landed_a();
         split_pair(0);
@@ -441,15 +443,21 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
         __builtin_amdgcn_sched_barrier(0);
         products(1);
         __builtin_amdgcn_sched_barrier(0);
-        load_a_async(min(kt + 1, nk - 1));
+        if constexpr (!LATE) load_a_async(min(kt + 1, nk - 1));
         if constexpr (decltype(dma)::value) {
             if constexpr (STRICT) __builtin_amdgcn_s_waitcnt(0x0070);
+            else if constexpr (LATE) __builtin_amdgcn_s_waitcnt(0x0072);   // (no fragment loads in flight: vmcnt(2) = all but the DMA of stage kt + 2)
             else __builtin_amdgcn_s_waitcnt(0x0078);                      // vmcnt(8), lgkmcnt(0): stage kt + 1 has landed
             __builtin_amdgcn_s_barrier();
             load_stage((kt + 3) * X_BK, kt % 3);
         } else {
             __builtin_amdgcn_s_waitcnt(0x0070);
             __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_a_async(min(kt + 1, nk - 1));
+            __builtin_amdgcn_sched_barrier(0);
         }
         read_b(lds + ((kt + 1) % 3) * Y_STAGE);
     };
@@ -522,8 +530,9 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     const char* shape_env = getenv("BITSWAP_BF16X3_SHAPE");
     const char* diag = getenv("BITSWAP_BF16X3_DIAG");
     const int shape = shape_env ? atoi(shape_env) : 2;
-    const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : !strcmp(diag, "stray_exit") ? 3 : -1;
-    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6) || (dg == 3 && shape != 1)) return BS_EINVAL;
+    const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : !strcmp(diag, "stray_exit") ? 3
+                   : !strcmp(diag, "noclaim_late") ? 4 : -1;
+    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6) || (dg == 3 && shape != 1) || (dg == 4 && shape != 2)) return BS_EINVAL;
 #define BS_X3_O2(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<NP, CL, ST>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt)
 #define BS_X3_O1(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3<NP, 0, CL, ST>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt)
     if (shape == 2) {                     // two workgroups of 256 x 128 per CU (default)
@@ -532,6 +541,7 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         const size_t shm2 = 3 * (size_t)Y_STAGE;
         if (dg == 1) BS_X3_O2(6, false, false);
         else if (dg == 2) BS_X3_O2(6, false, true);
+        else if (dg == 4) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<6, false, false, true>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
         else if (nprod == 9) BS_X3_O2(9, true, false);
         else BS_X3_O2(6, true, false);
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;

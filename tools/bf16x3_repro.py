@@ -122,6 +122,52 @@ def micro(reps, small=False):
     return res
 
 
+def storm(n_launch=30000):
+    """Who is the victim?  The codec's own GEMM shape (36 x 256 x 256 x 512 columns = 32 chains) launched n_launch times on one
+    stream, every result compared ON THE DEVICE with the solo result (no host sync in the loop), while a second stream keeps
+    launching the <= 24-register kernels that fit beside two unclaimed shape-2 wavefronts, each compared on the device too."""
+    dev = "cuda"
+    torch.manual_seed(1)
+    T, C, cols = 36, 256, 512
+    U, V = torch.randn(T, C, C, device=dev), torch.randn(T, C, cols, device=dev)
+    Uf = hip.frags_bf16x3(U)
+    for k in ("BITSWAP_BF16X3_DIAG", "BITSWAP_BF16X3_SHAPE"):
+        os.environ.pop(k, None)
+    ref = hip.wino_gemm_bf16x3(Uf, V, 6).clone()
+    fl = small_fillers(dev)
+    fl_ref = {k: f().clone() for k, f in fl.items()}
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    res = {}
+    for diag in (None, "noclaim", "noclaim_late", "noclaim", None):
+        if diag:
+            os.environ["BITSWAP_BF16X3_DIAG"] = diag
+        else:
+            os.environ.pop("BITSWAP_BF16X3_DIAG", None)
+        bad_g = torch.zeros((), dtype=torch.int64, device=dev)
+        bad_n = {k: torch.zeros((), dtype=torch.int64, device=dev) for k in fl}
+        outs = [torch.empty_like(ref) for _ in range(4)]
+        side.wait_stream(torch.cuda.current_stream())
+        for it in range(n_launch // 4):
+            for o in outs:
+                hip.wino_gemm_bf16x3(Uf, V, 6, out=o)
+            for o in outs:
+                bad_g += (o != ref).any()
+            with torch.cuda.stream(side):
+                for k, f in fl.items():
+                    bad_n[k] += (f() != fl_ref[k]).any()
+            if it % 500 == 499:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        key = (diag or "claim")
+        while key in res:
+            key += "_again"
+        res[key] = {"gemm_launches": n_launch, "gemm_results_differing": int(bad_g), **{f"{k}_differing": int(v) for k, v in bad_n.items()}}
+        print("storm", key, res[key], flush=True)
+    os.environ.pop("BITSWAP_BF16X3_DIAG", None)
+    return res
+
+
 def codec_leg(focus=False):
     """The forked codec (32 and 100 chains, cifar8 full width, bf16x3 arithmetic) per variant: lossless?"""
     import subprocess
@@ -144,7 +190,11 @@ for B in [int(b) for b in os.environ.get("REPRO_B", "32,100").split(",")]:
         try:
             state, met = codec.compress(images.to("cuda"))
             back = codec.decompress(state, 2)
-            ok += int(torch.equal(back.cpu(), images) and state.to_lists() == initial_states(B))
+            good = torch.equal(back.cpu(), images) and state.to_lists() == initial_states(B)
+            ok += int(good)
+            if not good:
+                wrong = (back.cpu() != images).reshape(B, -1).any(1).nonzero().flatten().tolist()
+                out.setdefault(f"B{B}_bad_chains", []).append(wrong[:40])
         except Exception as e:
             out[f"B{B}_err{rep}"] = repr(e)[:200]
     out[f"B{B}_lossless"] = f"{ok}/{NREP}"
@@ -153,18 +203,23 @@ print("RESULT " + json.dumps(out))
     res = {}
     plan = (("2", None, "0"), ("2", "noclaim", "1"), ("1", None, "1"), ("1", "noclaim", "1"), ("1", "noclaim", "0"),
             ("1", "stray_exit", "1"), ("1", "stray_exit", "0"))
-    if focus:      # the scenario that failed in round 5 visit c (shape 2 without the claim, eager forked codec, 32 chains): statistics
-        plan = (("2", "noclaim", "1"), ("2", "noclaim_strict", "1"), ("2", None, "1"), ("1", "noclaim", "1"), ("1", "noclaim_strict", "1"))
+    if focus:      # the scenario that failed in round 5 visit c (shape 2 without the claim, eager forked codec, 32 chains): statistics,
+        # with the CONTROL the round-4 hunt never ran: the same eager forked codec on the default fp32 GEMM ("fp32" below)
+        plan = (("2", "noclaim", "1"), ("2", "noclaim_late", "1"), ("2", None, "1"), ("2", "noclaim", "1"), ("2", "noclaim_late", "1"), ("2", None, "1"))
     for shape, diag, eager in plan:
         env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK=eager)
+        if shape == "fp32":
+            env.pop("BITSWAP_GEMM_ARITH"), env.pop("BITSWAP_BF16X3_SHAPE")
         if focus:
-            env.update(REPRO_REPS="14", REPRO_B="32")
+            env.update(REPRO_REPS=os.environ.get("REPRO_FOCUS_REPS", "150"), REPRO_B="32")
         env.pop("BITSWAP_BF16X3_DIAG", None)
         if diag:
             env["BITSWAP_BF16X3_DIAG"] = diag
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         key = f"shape{shape}_{diag or 'claim'}_{'eager_fork' if eager == '1' else 'graph'}"
+        while key in res:
+            key += "_again"
         res[key] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
         print("codec", key, res[key], flush=True)
     return res
@@ -175,10 +230,13 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--codec", action="store_true")
     ap.add_argument("--focus", action="store_true", help="codec leg only: the failing scenario with and without counted waits, 14 runs each")
+    ap.add_argument("--storm", type=int, default=0, help="GEMM launches of the victim hunt (0: skip)")
     ap.add_argument("--small", action="store_true", help="micro leg with the neighbours that fit beside the unclaimed shape-2 kernel (<= 32 registers)")
     a = ap.parse_args()
     out = {}
-    if not a.focus or a.small:
+    if a.storm:
+        out["storm"] = storm(a.storm)
+    if (not a.focus and not a.storm) or a.small:
         out["micro"] = micro(a.reps, small=a.small)
     if a.codec or a.focus:
         out["codec"] = codec_leg(focus=a.focus)
