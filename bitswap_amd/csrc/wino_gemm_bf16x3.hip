@@ -457,6 +457,9 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
         if constexpr (LATE) {
             __builtin_amdgcn_sched_barrier(0);
             load_a_async(min(kt + 1, nk - 1));
+            // (the last steps have no counted wait ahead of them: an asynchronous load must have landed before the registers
+            // it writes are handed to the epilogue)
+            if constexpr (!decltype(dma)::value) __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_sched_barrier(0);
         }
         read_b(lds + ((kt + 1) % 3) * Y_STAGE);

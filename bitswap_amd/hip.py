@@ -756,7 +756,24 @@ def wino_gemm_bf16x3(Uf, V, nprod=6, out=None):
     M = out if out is not None else torch.empty((T, Cout, cols), dtype=torch.float32, device=V.device)
     assert M.is_contiguous() and tuple(M.shape) == (T, Cout, cols) and M.dtype == torch.float32
     _check(load().bs_wino_gemm_bf16x3(_ptr(Uf.frags), _ptr(V), _ptr(M), T, Cout, Cin, cols, int(nprod), _stream()), "bs_wino_gemm_bf16x3")
+    if SELFCHECK_BF16X3 is not None:      # diagnostics (tools/bf16x3_repro.py): the same launch again, compared on the device
+        M2 = torch.empty_like(M)
+        _check(load().bs_wino_gemm_bf16x3(_ptr(Uf.frags), _ptr(V), _ptr(M2), T, Cout, Cin, cols, int(nprod), _stream()), "bs_wino_gemm_bf16x3")
+        d = M != M2
+        acc = SELFCHECK_BF16X3.setdefault((T, Cout, Cin, cols), {
+            "launches": 0, "differing": torch.zeros((), dtype=torch.int64, device=M.device),
+            "cols": torch.zeros(cols, dtype=torch.bool, device=M.device), "rows": torch.zeros(Cout, dtype=torch.bool, device=M.device),
+            "t": torch.zeros(T, dtype=torch.bool, device=M.device), "elements": torch.zeros((), dtype=torch.int64, device=M.device)})
+        acc["launches"] += 1
+        acc["differing"] += d.any()
+        acc["elements"] += d.sum()
+        acc["cols"] |= d.any(0).any(0)
+        acc["rows"] |= d.any(0).any(1)
+        acc["t"] |= d.any(1).any(1)
     return M
+
+
+SELFCHECK_BF16X3 = None     # set to {} to make every bs_wino_gemm_bf16x3 launch run twice and record where the two results differ
 
 
 def small_k_gemm(U, V):
@@ -789,3 +806,65 @@ def wino_fused(src, shape, ts_in=0, bias=None, res=None, act=True, want_sum=Fals
     _check(load().bs_wino_fused_f32(_ptr(src), ts_in, _ptr(bias), _ptr(res), int(act), _ptr(s_out), _ptr(a_out),
                                     _ptr(V), ts_out, N, Cc, H, W, _stream()), "bs_wino_fused_f32")
     return s_out, a_out, V
+
+
+# ---- diagnostics: run a kernel wrapper twice and record on the device whether (and for which image) the two results differ ---
+SELFCHECK = None     # set to {} (tools/bf16x3_repro.py): wino_fused / conv3_wino / wino_gemm / head_params launches are doubled
+
+
+def _selfchecked(name, fn, image_of):
+    """image_of(tensor, args) -> per-element image index or None; wraps fn so that with SELFCHECK set every call runs twice."""
+    def wrapped(*a, **k):
+        out = fn(*a, **k)
+        if SELFCHECK is None:
+            return out
+        out2 = fn(*a, **k)
+        o1 = out if isinstance(out, (tuple, list)) else (out,)
+        o2 = out2 if isinstance(out2, (tuple, list)) else (out2,)
+        acc = SELFCHECK.setdefault(name, {"calls": 0, "differing": torch.zeros((), dtype=torch.int64, device="cuda"),
+                                          "images": torch.zeros(4096, dtype=torch.bool, device="cuda")})
+        acc["calls"] += 1
+        for x, y in zip(o1, o2):
+            if x is None or not torch.is_tensor(x):
+                continue
+            d = x != y
+            acc["differing"] += d.any()
+            idx = image_of(x, a, k)
+            if idx is not None:
+                n = int(idx[1])
+                acc["images"][:n] |= d.reshape(idx[0]).any(dim=tuple(i for i in range(len(idx[0])) if i != idx[2]))
+        return out
+    return wrapped
+
+
+def _img_fused(x, a, k):
+    N, C, H, W = a[1]
+    T = (H // 4) * (W // 4)
+    if x.dim() == 4:                      # [N, C, H, W]
+        return ((N, C * H * W), N, 0)
+    return ((x.shape[0] * x.shape[1], N, T), N, 1)     # V / M [ts^2, C, N*T]
+
+
+def _img_conv3(x, a, k):
+    N = a[0].shape[0]
+    if x.dim() == 4:
+        return ((N, x.numel() // N), N, 0)
+    T = x.shape[2] // N
+    return ((x.shape[0] * x.shape[1], N, T), N, 1)
+
+
+def _img_gemm(x, a, k):
+    cols = x.shape[2]
+    if cols % 16:
+        return None
+    return ((x.shape[0] * x.shape[1], cols // 16, 16), cols // 16, 1)
+
+
+def _img_head(x, a, k):
+    return ((x.shape[0], x.numel() // x.shape[0]), x.shape[0], 0)
+
+
+wino_fused = _selfchecked("wino_fused", wino_fused, _img_fused)
+conv3_wino = _selfchecked("conv3_wino", conv3_wino, _img_conv3)
+wino_gemm = _selfchecked("wino_gemm", wino_gemm, _img_gemm)
+head_params = _selfchecked("head_params", head_params, _img_head)

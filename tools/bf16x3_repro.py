@@ -139,7 +139,7 @@ def storm(n_launch=30000):
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     res = {}
-    for diag in (None, "noclaim", "noclaim_late", "noclaim", None):
+    for diag in ("noclaim", None, "noclaim", None):
         if diag:
             os.environ["BITSWAP_BF16X3_DIAG"] = diag
         else:
@@ -178,12 +178,31 @@ from bitswap_amd import workload
 from bitswap_amd.codec import BitSwapCodec, initial_states
 model, zend, zcen = workload.build("cifar8", "cuda", quantbits=10)
 out = {}
+from bitswap_amd import hip as _hip
+if os.environ.get("REPRO_SELFCHECK") == "1":
+    _hip.SELFCHECK_BF16X3 = {}
+    _hip.SELFCHECK = {}
 for B in [int(b) for b in os.environ.get("REPRO_B", "32,100").split(",")]:
     images = workload.synthetic_blocks(B * 2, model.xs, seed=19).view(B, 2, -1).to(torch.int32)
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
     if os.environ.get("REPRO_EAGER_FORK") == "1":      # round 4's failing scenario (profiles/archive/visits_r04/dbg3_bf16.py)
         codec.use_graphs = False
         codec.fork = "1"
+    if os.environ.get("REPRO_NOFORK") == "1":          # the reference's order on ONE stream, eager
+        codec.use_graphs = False
+        codec.fork = "0"
+    if os.environ.get("REPRO_KEEPALL") == "1":         # nothing a step allocates is freed before the run's end: no block is reused
+        stash = []
+        real_empty, real_zeros, real_empty_like = torch.empty, torch.zeros, torch.empty_like
+        def _k(f):
+            def g(*a, **k):
+                t = f(*a, **k); stash.append(t); return t
+            return g
+        torch.empty, torch.zeros, torch.empty_like = _k(real_empty), _k(real_zeros), _k(real_empty_like)
+        orig_net = codec._net
+        def wrapped(fn, given):
+            o = orig_net(fn, given); stash.extend(o); stash.append(given); return o
+        codec._net = wrapped
     ok = 0
     NREP = int(os.environ.get("REPRO_REPS", "3"))
     for rep in range(NREP):
@@ -198,6 +217,21 @@ for B in [int(b) for b in os.environ.get("REPRO_B", "32,100").split(",")]:
         except Exception as e:
             out[f"B{B}_err{rep}"] = repr(e)[:200]
     out[f"B{B}_lossless"] = f"{ok}/{NREP}"
+if _hip.SELFCHECK_BF16X3:
+    torch.cuda.synchronize()
+    sc = {}
+    for shp, a in _hip.SELFCHECK_BF16X3.items():
+        if int(a["differing"]):
+            sc[str(shp)] = {"launches": a["launches"], "launch_pairs_differing": int(a["differing"]), "elements": int(a["elements"]),
+                            "cols": a["cols"].nonzero().flatten().tolist()[:64], "rows": a["rows"].nonzero().flatten().tolist()[:64],
+                            "t": a["t"].nonzero().flatten().tolist()}
+        else:
+            sc[str(shp)] = {"launches": a["launches"], "launch_pairs_differing": 0}
+    out["selfcheck"] = sc
+if _hip.SELFCHECK:
+    torch.cuda.synchronize()
+    out["selfcheck_others"] = {k: {"calls": a["calls"], "call_pairs_differing": int(a["differing"]),
+                                   "images": a["images"].nonzero().flatten().tolist()[:64]} for k, a in _hip.SELFCHECK.items()}
 print("RESULT " + json.dumps(out))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     res = {}
@@ -205,9 +239,16 @@ print("RESULT " + json.dumps(out))
             ("1", "stray_exit", "1"), ("1", "stray_exit", "0"))
     if focus:      # the scenario that failed in round 5 visit c (shape 2 without the claim, eager forked codec, 32 chains): statistics,
         # with the CONTROL the round-4 hunt never ran: the same eager forked codec on the default fp32 GEMM ("fp32" below)
-        plan = (("2", "noclaim", "1"), ("2", "noclaim_late", "1"), ("2", None, "1"), ("2", "noclaim", "1"), ("2", "noclaim_late", "1"), ("2", None, "1"))
+        plan = (("2", "noclaim", "nofork"), ("2", "noclaim", "keepall"), ("2", "noclaim", "1"), ("2", "noclaim", "nofork"), ("2", "noclaim", "keepall"))
     for shape, diag, eager in plan:
-        env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK=eager)
+        env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK="0" if eager == "0" else "1")
+        if eager == "nofork":
+            env["REPRO_EAGER_FORK"], env["REPRO_NOFORK"] = "0", "1"
+        if eager == "keepall":
+            env["REPRO_KEEPALL"] = "1"
+        if eager == "nocache":      # no caching allocator: a freed block is never handed to another stream's allocation early
+            env["PYTORCH_NO_CUDA_MEMORY_CACHING"] = "1"
+            env["PYTORCH_NO_HIP_MEMORY_CACHING"] = "1"
         if shape == "fp32":
             env.pop("BITSWAP_GEMM_ARITH"), env.pop("BITSWAP_BF16X3_SHAPE")
         if focus:
@@ -217,7 +258,7 @@ print("RESULT " + json.dumps(out))
             env["BITSWAP_BF16X3_DIAG"] = diag
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-        key = f"shape{shape}_{diag or 'claim'}_{'eager_fork' if eager == '1' else 'graph'}"
+        key = f"shape{shape}_{diag or 'claim'}_{ {'1': 'eager_fork', '0': 'graph', 'nocache': 'eager_fork_no_caching_allocator', 'nofork': 'eager_ONE_stream', 'keepall': 'eager_fork_nothing_freed'}[eager]}"
         while key in res:
             key += "_again"
         res[key] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}

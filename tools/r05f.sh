@@ -4,4 +4,4 @@
 # issued after the barrier / claimed
 TAG=${1:-r05f}
 OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 2400 python tools/bf16x3_repro.py --storm 30000 --focus > $OUT/${TAG}_bf16x3_repro.txt 2>&1; grep "^codec\|^storm" $OUT/${TAG}_bf16x3_repro.txt | cut -c1-600
+timeout 2400 python tools/bf16x3_repro.py --storm 300000 --focus > $OUT/${TAG}_bf16x3_repro.txt 2>&1; grep "^codec\|^storm" $OUT/${TAG}_bf16x3_repro.txt | cut -c1-600
