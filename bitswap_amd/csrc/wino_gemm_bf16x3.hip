@@ -64,13 +64,14 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
                                                               float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                               int ncc, int nrt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [3][X_STAGE]
-    // The wavefront claims the WHOLE register file of its SIMD (256 architectural + 256 accumulation registers).  It needs
-    // 436 / 444 of the 512; allocated as 440 (NPROD = 6), a 72-register wavefront of another kernel fits beside it -- and with
-    // one there (k_logistic<4> or k_wino_fused of the other stream, round 4 visit K) this kernel's products came out wrong:
-    // the forked and the two-group codecs decoded garbage, while the kernel alone, beside other launches in a stress loop
-    // (tools/bf16x3_stress.py), with one hardware queue, or with 448 registers (NPROD = 9) was bit-exact every time.  With
-    // nothing beside it: lossless 6 / 6.  Cause not established (LABNOTES.md); occupancy is one by design, so this costs
-    // nothing but the co-residency of small wavefronts on these SIMDs.
+    // The wavefront claims the WHOLE register file of its SIMD (256 architectural + 256 accumulation registers; it needs 448).
+    // History: round 4 saw the forked and the two-group codecs decode garbage with this arithmetic, blamed a small wavefront of
+    // another kernel beside this one, and added the claim so that nothing fits.  Round 5 (tools/bf16x3_repro.py):
+    // the claim changes the allocation and nothing else (identical instruction streams); the products are bit-stable with or
+    // without it -- 600,000 launches beside the kernels that fit next to it, and every launch doubled inside failing codec runs --
+    // and the FORKED block step with the two-workgroup shape fails with the claim too (2.3 % of runs against 5-7 % without).
+    // The claim stays because it costs nothing (occupancy is one by design) and makes the failure rarer; the fix is in the codec,
+    // which does not fork the step with this arithmetic.
     if constexpr (CLAIM) asm volatile("" ::: "v255");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;
