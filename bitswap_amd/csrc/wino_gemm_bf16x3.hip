@@ -314,7 +314,8 @@ constexpr int Y_BN = 128, Y_STAGE = X_BK * Y_BN * 4;      // 8 KB per stage, thr
 
 // LATE (diagnostics): the fragment loads of step k + 1, which land IN PLACE in the registers the multiplies of step k read, are
 // issued after the step's barrier instead of right behind the last multiply.
-template <int NPROD, bool CLAIM = true, bool STRICT = false, bool LATE = false>
+// PLAIN_STORE (diagnostics): M leaves through ordinary stores instead of nontemporal ones.
+template <int NPROD, bool CLAIM = true, bool STRICT = false, bool LATE = false, bool PLAIN_STORE = false>
 __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
                                                                  float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                                  int ncc, int nrt) {
@@ -479,7 +480,8 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
                 const int row = row0 + (v >> 2) * 8 + (v & 3);
                 if (row < Cout) {
                     f32x4 o = {acc[mi][0][v], acc[mi][1][v], acc[mi][2][v], acc[mi][3][v]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Mt + (int64_t)row * cols + c0 + cl));
+                    if constexpr (PLAIN_STORE) *reinterpret_cast<f32x4*>(Mt + (int64_t)row * cols + c0 + cl) = o;
+                    else __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Mt + (int64_t)row * cols + c0 + cl));
                 }
             }
         }
@@ -535,8 +537,8 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     const char* diag = getenv("BITSWAP_BF16X3_DIAG");
     const int shape = shape_env ? atoi(shape_env) : 2;
     const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : !strcmp(diag, "stray_exit") ? 3
-                   : !strcmp(diag, "noclaim_late") ? 4 : -1;
-    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6) || (dg == 3 && shape != 1) || (dg == 4 && shape != 2)) return BS_EINVAL;
+                   : !strcmp(diag, "noclaim_late") ? 4 : !strcmp(diag, "noclaim_plainstore") ? 5 : -1;
+    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6) || (dg == 3 && shape != 1) || (dg >= 4 && shape != 2)) return BS_EINVAL;
 #define BS_X3_O2(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<NP, CL, ST>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt)
 #define BS_X3_O1(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3<NP, 0, CL, ST>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt)
     if (shape == 2) {                     // two workgroups of 256 x 128 per CU (default)
@@ -546,6 +548,7 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         if (dg == 1) BS_X3_O2(6, false, false);
         else if (dg == 2) BS_X3_O2(6, false, true);
         else if (dg == 4) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<6, false, false, true>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
+        else if (dg == 5) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<6, false, false, false, true>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
         else if (nprod == 9) BS_X3_O2(9, true, false);
         else BS_X3_O2(6, true, false);
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;

@@ -191,18 +191,6 @@ for B in [int(b) for b in os.environ.get("REPRO_B", "32,100").split(",")]:
     if os.environ.get("REPRO_NOFORK") == "1":          # the reference's order on ONE stream, eager
         codec.use_graphs = False
         codec.fork = "0"
-    if os.environ.get("REPRO_KEEPALL") == "1":         # nothing a step allocates is freed before the run's end: no block is reused
-        stash = []
-        real_empty, real_zeros, real_empty_like = torch.empty, torch.zeros, torch.empty_like
-        def _k(f):
-            def g(*a, **k):
-                t = f(*a, **k); stash.append(t); return t
-            return g
-        torch.empty, torch.zeros, torch.empty_like = _k(real_empty), _k(real_zeros), _k(real_empty_like)
-        orig_net = codec._net
-        def wrapped(fn, given):
-            o = orig_net(fn, given); stash.extend(o); stash.append(given); return o
-        codec._net = wrapped
     ok = 0
     NREP = int(os.environ.get("REPRO_REPS", "3"))
     for rep in range(NREP):
@@ -239,13 +227,11 @@ print("RESULT " + json.dumps(out))
             ("1", "stray_exit", "1"), ("1", "stray_exit", "0"))
     if focus:      # the scenario that failed in round 5 visit c (shape 2 without the claim, eager forked codec, 32 chains): statistics,
         # with the CONTROL the round-4 hunt never ran: the same eager forked codec on the default fp32 GEMM ("fp32" below)
-        plan = (("2", "noclaim", "nofork"), ("2", "noclaim", "keepall"), ("2", "noclaim", "1"), ("2", "noclaim", "nofork"), ("2", "noclaim", "keepall"))
+        plan = (("2", "noclaim_plainstore", "1"), ("2", "noclaim", "1"), ("2", "noclaim_plainstore", "1"), ("2", "noclaim", "1"))
     for shape, diag, eager in plan:
         env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK="0" if eager == "0" else "1")
         if eager == "nofork":
             env["REPRO_EAGER_FORK"], env["REPRO_NOFORK"] = "0", "1"
-        if eager == "keepall":
-            env["REPRO_KEEPALL"] = "1"
         if eager == "nocache":      # no caching allocator: a freed block is never handed to another stream's allocation early
             env["PYTORCH_NO_CUDA_MEMORY_CACHING"] = "1"
             env["PYTORCH_NO_HIP_MEMORY_CACHING"] = "1"
@@ -258,11 +244,147 @@ print("RESULT " + json.dumps(out))
             env["BITSWAP_BF16X3_DIAG"] = diag
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-        key = f"shape{shape}_{diag or 'claim'}_{ {'1': 'eager_fork', '0': 'graph', 'nocache': 'eager_fork_no_caching_allocator', 'nofork': 'eager_ONE_stream', 'keepall': 'eager_fork_nothing_freed'}[eager]}"
+        key = f"shape{shape}_{diag or 'claim'}_{ {'1': 'eager_fork', '0': 'graph', 'nocache': 'eager_fork_no_caching_allocator', 'nofork': 'eager_ONE_stream'}[eager]}"
         while key in res:
             key += "_again"
         res[key] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
         print("codec", key, res[key], flush=True)
+    return res
+
+
+TRAIL_CODE = r"""
+import os, sys, json, torch
+sys.path.insert(0, "__ROOT__")
+from bitswap_amd import workload
+from bitswap_amd.codec import BitSwapCodec, initial_states
+model, zend, zcen = workload.build("cifar8", "cuda", quantbits=10)
+B, n = 32, 2
+images = workload.synthetic_blocks(B * n, model.xs, seed=19).view(B, n, -1).to(torch.int32)
+
+def make(fork):
+    codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
+    codec.use_graphs = False
+    codec.fork = fork
+    trail = {"ops": [], "nets": {}}
+    be = codec.backend
+    o_pop, o_pp, o_pt, o_net = be.pop, be.push_params, be.push_table, codec._net
+    def pop(state, cdf, K, bits, centres=None):
+        r = o_pop(state, cdf, K, bits, centres=centres)
+        trail["ops"].append(("pop", state.head.clone(), r[0].sum(1)))
+        return r
+    def push_params(state, *a, **k):
+        o_pp(state, *a, **k)
+        trail["ops"].append(("push", state.head.clone(), None))
+    def push_table(state, *a, **k):
+        o_pt(state, *a, **k)
+        trail["ops"].append(("push_prior", state.head.clone(), None))
+    def net(fn, given):
+        CUR["key"] = (fn.bs_key, len(trail["nets"].get(fn.bs_key, [])))
+        CUR["trail"] = trail
+        mu, sc = o_net(fn, given)
+        CUR["key"] = None
+        trail["nets"].setdefault(fn.bs_key, []).append((mu.sum(1), sc.sum(1), given.reshape(given.shape[0], -1).sum(1)))
+        return mu, sc
+    be.pop, be.push_params, be.push_table, codec._net = pop, push_params, push_table, net
+    return codec, trail
+
+# per-kernel trail inside a stack: per-image sums of every output tensor of every stack kernel
+from bitswap_amd import hip as _hip
+CUR = {"key": None, "trail": None}
+def _per_image(x, N):
+    if x is None or not torch.is_tensor(x) or x.numel() % N:
+        return None
+    if x.dim() == 4 and x.shape[0] == N:
+        return x.reshape(N, -1).sum(1)
+    if x.dim() == 3 and x.shape[2] % N == 0:                 # [ts^2 or T, C, N * tiles]
+        return x.reshape(x.shape[0] * x.shape[1], N, -1).sum((0, 2))
+    if x.dim() == 2 and x.shape[0] == N:
+        return x.sum(1)
+    return None
+def _wrap(name):
+    orig = getattr(_hip, name)
+    def w(*a, **k):
+        out = orig(*a, **k)
+        if CUR["key"] is not None:
+            o = out if isinstance(out, (tuple, list)) else (out,)
+            sums = [_per_image(t, 32) for t in o]
+            CUR["trail"].setdefault("kern", {}).setdefault(CUR["key"], []).append((name, [s_ for s_ in sums if s_ is not None]))
+        return out
+    setattr(_hip, name, w)
+for _n in ("conv3_wino", "wino_fused", "wino_gemm", "wino_gemm_bf16x3", "head_params", "small_k_gemm", "wino_in", "wino_out"):
+    _wrap(_n)
+
+def run(codec, trail):
+    trail["ops"].clear(); trail["nets"].clear(); trail.setdefault("kern", {}).clear()
+    state, met = codec.compress(images.to("cuda"))
+    back = codec.decompress(state, n)
+    torch.cuda.synchronize()
+    good = torch.equal(back.cpu(), images) and state.to_lists() == initial_states(B)
+    return good, {"ops": [(k, h.cpu(), None if s is None else s.cpu()) for k, h, s in trail["ops"]],
+                  "nets": {k: [tuple(t.cpu() for t in e) for e in v] for k, v in trail["nets"].items()},
+                  "kern": {k: [(nm, [t.cpu() for t in ss]) for nm, ss in v] for k, v in trail.get("kern", {}).items()}}
+
+ref_codec, ref_trail = make("0")
+ok, ref = run(ref_codec, ref_trail)
+assert ok
+ok2, ref2 = run(ref_codec, ref_trail)
+same = all(torch.equal(a[1], b[1]) for a, b in zip(ref["ops"], ref2["ops"]))
+codec, trail = make("1")
+out = {"reference_run_repeats": bool(same), "ops_per_run": len(ref["ops"]), "findings": [], "lossless": 0}
+NREP = int(os.environ.get("REPRO_REPS", "100"))
+for rep in range(NREP):
+    good, t = run(codec, trail)
+    out["lossless"] += int(good)
+    if good:
+        continue
+    f = {"run": rep}
+    for i, (a, b) in enumerate(zip(ref["ops"], t["ops"])):
+        if a[0] != b[0] or not torch.equal(a[1], b[1]):
+            f["first_stack_op"] = {"index": i, "kind": b[0], "of": len(ref["ops"]), "chains": (a[1] != b[1]).nonzero().flatten().tolist(),
+                                   "popped_symbols_differ": (None if a[2] is None else (a[2] != b[2]).nonzero().flatten().tolist())}
+            break
+    nets = []
+    for key, lst in ref["nets"].items():
+        for j, (a, b) in enumerate(zip(lst, t["nets"].get(key, []))):
+            d_in, d_mu, d_sc = (a[2] != b[2]), (a[0] != b[0]), (a[1] != b[1])
+            if bool(d_in.any()) or bool(d_mu.any()) or bool(d_sc.any()):
+                nets.append({"stack": list(key) if isinstance(key, tuple) else str(key), "call": j, "input_differs": d_in.nonzero().flatten().tolist(),
+                             "mu_differs": d_mu.nonzero().flatten().tolist(), "scale_differs": d_sc.nonzero().flatten().tolist()})
+                break
+    # stacks whose OUTPUT differs although their input is the reference's: the origin
+    f["stacks_wrong_on_right_input"] = [x for x in nets if not x["input_differs"]][:6]
+    for x in f["stacks_wrong_on_right_input"][:2]:          # ... and inside such a stack: the first kernel whose output differs
+        key = (tuple(x["stack"]), x["call"])
+        seq_r, seq_t = ref["kern"].get(key, []), t["kern"].get(key, [])
+        x["kernels_in_stack"] = [nm for nm, _ in seq_t]
+        for ki, ((nr, sr), (nt, st_)) in enumerate(zip(seq_r, seq_t)):
+            bad = [i for i, (u, v) in enumerate(zip(sr, st_)) if not torch.equal(u, v)]
+            if nr != nt or bad:
+                x["first_wrong_kernel"] = {"index": ki, "kernel": nt, "outputs_differing": bad,
+                                           "images": sorted(set(sum(((u != v).nonzero().flatten().tolist() for u, v in zip(sr, st_)), [])))}
+                break
+    f["stacks_with_wrong_input"] = [(x["stack"], x["call"]) for x in nets if x["input_differs"]][:8]
+    out["findings"].append(f)
+out["lossless"] = f"{out['lossless']}/{NREP}"
+print("RESULT " + json.dumps(out))
+"""
+
+
+def trail_leg(reps=120):
+    """Where does a failing forked run first leave the one-stream run?  Head of every chain after every stack operation and a
+    per-chain checksum of every conv stack's input and output, compared with the one-stream run of the same codec."""
+    import subprocess
+    code = TRAIL_CODE.replace("__ROOT__", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for diag in ("noclaim", None):
+        env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE="2", BITSWAP_FORK="1", REPRO_REPS=str(reps))
+        env.pop("BITSWAP_BF16X3_DIAG", None)
+        if diag:
+            env["BITSWAP_BF16X3_DIAG"] = diag
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        res[diag or "claim"] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-600:]}
+        print("trail", diag or "claim", json.dumps(res[diag or "claim"]), flush=True)
     return res
 
 
@@ -271,13 +393,16 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--codec", action="store_true")
     ap.add_argument("--focus", action="store_true", help="codec leg only: the failing scenario with and without counted waits, 14 runs each")
+    ap.add_argument("--trail", type=int, default=0, help="runs of the checksum-trail leg (0: skip)")
     ap.add_argument("--storm", type=int, default=0, help="GEMM launches of the victim hunt (0: skip)")
     ap.add_argument("--small", action="store_true", help="micro leg with the neighbours that fit beside the unclaimed shape-2 kernel (<= 32 registers)")
     a = ap.parse_args()
     out = {}
+    if a.trail:
+        out["trail"] = trail_leg(a.trail)
     if a.storm:
         out["storm"] = storm(a.storm)
-    if (not a.focus and not a.storm) or a.small:
+    if (not a.focus and not a.storm and not a.trail) or a.small:
         out["micro"] = micro(a.reps, small=a.small)
     if a.codec or a.focus:
         out["codec"] = codec_leg(focus=a.focus)
