@@ -227,7 +227,7 @@ print("RESULT " + json.dumps(out))
             ("1", "stray_exit", "1"), ("1", "stray_exit", "0"))
     if focus:      # the scenario that failed in round 5 visit c (shape 2 without the claim, eager forked codec, 32 chains): statistics,
         # with the CONTROL the round-4 hunt never ran: the same eager forked codec on the default fp32 GEMM ("fp32" below)
-        plan = (("2", "noclaim_plainstore", "1"), ("2", "noclaim", "1"), ("2", "noclaim_plainstore", "1"), ("2", "noclaim", "1"))
+        plan = (("fp32", None, "0"), ("fp32", None, "1"), ("fp32", None, "0"), ("fp32", None, "1"))   # the DEFAULT route: graph replay / eager, forked
     for shape, diag, eager in plan:
         env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK="0" if eager == "0" else "1")
         if eager == "nofork":
