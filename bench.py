@@ -589,7 +589,7 @@ def extra_in_child(args, spec, steps, warmup):
                       + (", calibrated low-rate regime (workload.calibrate_lowrate: latent scales at the 0.1 clamp, pixel scale "
                          "0.0035, blocks drawn from the model's own generative path)" if spec.get("regime") == "lowrate" else "")
                       + (", opt-in 64-state stream format (not the reference's word stream)" if spec.get("format") == "wave64" else ""),
-            "why": spec.get("why"), "workload": spec["workload"], "bitswap": int(spec.get("bitswap", args.bitswap)),
+            "why": spec.get("why"), "workload": spec["workload"], "bitswap": int(spec.get("bitswap", args.bitswap)), "tag": spec.get("tag"),
             "chains_per_gpu": d["config"]["chains_per_gpu"],
             "chain_groups": d["config"]["chain_groups"], "scaling": d["scaling"], "steps": d["steps"], "warmup": d["warmup"],
             "value": round(d["value"], 1), "ms_per_step": round(d["ms_per_step"], 3), "lossless": d["lossless"],
@@ -623,6 +623,9 @@ EXTRAS = (
     dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_GEMM_ARITH": "bf16x3"},
          why="OPT-IN conv arithmetic, not the headline: the ResNet products as three bf16 limbs per float32 operand, 6 limb products "
              "per k block on the bf16 matrix cores, float32 accumulate (bs_wino_gemm_bf16x3; error table: profiles/r04_bf16x3_error.json)"),
+    dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_SERIAL_CUS": "32", "BITSWAP_GEMM_CUS": "224"}, tag="cumask32",
+         why="EXPERIMENT, a loss (DESIGN 8): CU-masked streams -- the serial pop / push streams on 32 compute units (4 per XCD), the bulk "
+             "streams on the other 224 (bs_stream_create_cu_mask); more masks and the bf16x3 pairing: profiles/r05b_cu_mask_ab.txt"),
     dict(workload="cifar8", chains=800, groups=2, format="wave64", why="opt-in 64-state format"),
     dict(workload="cifar8", chains=13, groups=1, format="wave64", why="opt-in 64-state format, few chains"),
 )
@@ -721,14 +724,14 @@ def main(args):
             return (f"{e['workload']}{'' if e.get('bitswap', 1) else '_bbans'}_{e['chains_per_gpu']}"
                     + ("_wave64" if e.get("stream_format") == "wave64" else "")
                     + ("_lowrate" if e.get("regime") == "lowrate" else "")
-                    + ("_" + e["conv_dtype"] if e.get("conv_dtype") not in (None, "f32") else ""))
+                    + ("_" + e["conv_dtype"] if e.get("conv_dtype") not in (None, "f32") else "") + ("_" + e["tag"] if e.get("tag") else ""))
         shapes = {label(e): [round(e["value"] / 1e6, 3), e["ms_per_step"], e["lossless"]] for e in extra if "value" in e}
         predicted = {}
         for cfg, wl, bs in (("configs[1] cifar8 Bit-Swap", "cifar8", 1), ("configs[4] imagenet4 BB-ANS", "imagenet4", 0),
                             ("configs[3] imagenetcrop4 ragged", "imagenetcrop4", 1)):
             pick = lambda n: next((e["value"] for e in extra if e.get("workload") == wl and e.get("bitswap", 1) == bs and "value" in e
                                    and e.get("chains_per_gpu") == n and e.get("stream_format", "reference") == "reference"
-                                   and e.get("conv_dtype", "f32") == "f32" and e.get("regime") != "lowrate"), None)
+                                   and e.get("conv_dtype", "f32") == "f32" and e.get("regime") != "lowrate" and not e.get("tag")), None)
             v = {1: pick(100), 2: pick(50), 4: pick(25), 8: pick(13)}
             if v[1]:
                 predicted[cfg] = {"Mpixel_per_s": {str(n): (None if x is None else round(n * x / 1e6, 2)) for n, x in v.items()},

@@ -508,7 +508,7 @@ class BitSwapCodec:
         # Fail closed (round 5): with the opt-in bf16x3 conv arithmetic the forked two-stream step is NOT taken unless forced.
         # In 150-run series of the forked step at 32 chains (eager and graph replay alike) 2-7 % of the runs decoded ONE chain
         # wrong -- always a chain with index 3 mod 4 -- while the same codec on one stream, the fp32 route forked, and every
-        # bf16x3 GEMM launch compared with a second launch of itself inside the failing runs were exact (DESIGN 3.4,
+        # bf16x3 GEMM launch compared with a second launch of itself inside the failing runs were exact (1,120 forked fp32 runs; DESIGN 3.4,
         # profiles/r05*_bf16x3_repro.txt, tools/bf16x3_repro.py).  The kernel pair that interferes is not identified.
         if self.fork != "1" and getattr(self.model, "gemm_arith", "fp32") != "fp32" and getattr(self.model, "_ufrags", None):
             return False
