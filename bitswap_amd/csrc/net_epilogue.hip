@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
             for (int q = 0; q < TI; ++q) {
                 float colv[TI], y[4];
 #pragma unroll
-                for (int r = 0; r < TI; ++r) colv[r] = FUSED_NT ? __builtin_nontemporal_load(m + (int64_t)(r * TI + q) * tstride) : m[(int64_t)(r * TI + q) * tstride];
+                for (int r = 0; r < TI; ++r) colv[r] = (FUSED_NT && !(act & 4)) ? __builtin_nontemporal_load(m + (int64_t)(r * TI + q) * tstride) : m[(int64_t)(r * TI + q) * tstride];
                 wino_at<TI, 4>(colv, y);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t1[r][q] = y[r];
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
             wino_bt<TO>(t1[r], o);
 #pragma unroll
             for (int q = 0; q < TO; ++q) {
-                if (FUSED_NT) __builtin_nontemporal_store(o[q], out + (int64_t)(r * TO + q) * tstride);
+                if (FUSED_NT && !(act & 4)) __builtin_nontemporal_store(o[q], out + (int64_t)(r * TO + q) * tstride);
                 else out[(int64_t)(r * TO + q) * tstride] = o[q];
             }
         }
@@ -753,6 +753,10 @@ int bs_wino_fused_f32(const float* src, int ts_in, const float* bias, const floa
     const int IMG = 256 / T;
     dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
     const size_t shm = ts_out ? (size_t)IMG * fused_lp(H, W) * sizeof(float) : 0;
+    act &= 3;
+    if (const char* e = getenv("BITSWAP_FUSED_PLAIN")) {      // diagnostics: ordinary instead of nontemporal loads of M / stores of V
+        if (atoi(e)) act |= 4;
+    }
 #define BS_WF(TI, TO)                                                                                             \
     hipLaunchKernelGGL((k_wino_fused<TI, TO>), grid, block, shm, S(stream), src, bias, res, sum_out, act_out, V, N, C, H, \
                        W, act)

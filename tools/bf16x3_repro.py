@@ -182,6 +182,17 @@ from bitswap_amd import hip as _hip
 if os.environ.get("REPRO_SELFCHECK") == "1":
     _hip.SELFCHECK_BF16X3 = {}
     _hip.SELFCHECK = {}
+if os.environ.get("REPRO_NOP_AFTER"):       # a one-wavefront no-op launch behind every call of the named kernel wrappers
+    _nopbuf = torch.zeros(4, dtype=torch.int32, device="cuda")
+    def _nop_after(name):
+        orig = getattr(_hip, name)
+        def w(*a, **k):
+            r = orig(*a, **k)
+            _hip.load().bs_debug_where(_hip._ptr(_nopbuf), 1, 0, _hip._stream())
+            return r
+        setattr(_hip, name, w)
+    for _n in os.environ["REPRO_NOP_AFTER"].split(","):
+        _nop_after(_n)
 for B in [int(b) for b in os.environ.get("REPRO_B", "32,100").split(",")]:
     images = workload.synthetic_blocks(B * 2, model.xs, seed=19).view(B, 2, -1).to(torch.int32)
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
@@ -228,8 +239,17 @@ print("RESULT " + json.dumps(out))
     if focus:      # the scenario that failed in round 5 visit c (shape 2 without the claim, eager forked codec, 32 chains): statistics,
         # with the CONTROL the round-4 hunt never ran: the same eager forked codec on the default fp32 GEMM ("fp32" below)
         plan = (("fp32", None, "0"), ("fp32", None, "1"), ("fp32", None, "0"), ("fp32", None, "1"))   # the DEFAULT route: graph replay / eager, forked
+        if os.environ.get("REPRO_BISECT") == "1":     # swap single kernels of the stacks for their alternatives (no launch added)
+            plan = (("2", "noclaim", "1"), ("2", "noclaim", "nop:wino_fused"), ("2", "noclaim", "nop:wino_gemm_bf16x3"),
+                    ("2", "noclaim", "nop:wino_gemm,head_params"), ("2", "noclaim", "1"), ("2", "noclaim", "nop:wino_fused"))
     for shape, diag, eager in plan:
         env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK="0" if eager == "0" else "1")
+        if eager.startswith("nop:"):
+            env["REPRO_NOP_AFTER"] = eager[4:]
+        if eager == "fusedplain":      # k_wino_fused with ordinary instead of nontemporal loads of M / stores of V
+            env["BITSWAP_FUSED_PLAIN"] = "1"
+        if eager == "nofusedin":       # the 3x3 input convs through MIOpen + k_wino_fused<0, 6> instead of k_conv3_wino
+            env["BITSWAP_FUSED_INPUTS"] = "0"
         if eager == "nofork":
             env["REPRO_EAGER_FORK"], env["REPRO_NOFORK"] = "0", "1"
         if eager == "nocache":      # no caching allocator: a freed block is never handed to another stream's allocation early
@@ -244,7 +264,7 @@ print("RESULT " + json.dumps(out))
             env["BITSWAP_BF16X3_DIAG"] = diag
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-        key = f"shape{shape}_{diag or 'claim'}_{ {'1': 'eager_fork', '0': 'graph', 'nocache': 'eager_fork_no_caching_allocator', 'nofork': 'eager_ONE_stream'}[eager]}"
+        key = f"shape{shape}_{diag or 'claim'}_nop_after_{eager[4:]}" if eager.startswith("nop:") else f"shape{shape}_{diag or 'claim'}_{ {'1': 'eager_fork', '0': 'graph', 'nocache': 'eager_fork_no_caching_allocator', 'nofork': 'eager_ONE_stream', 'nofusedin': 'eager_fork_without_k_conv3_wino', 'fusedplain': 'eager_fork_k_wino_fused_plain_loads_stores'}[eager]}"
         while key in res:
             key += "_again"
         res[key] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-300:]}
