@@ -315,7 +315,8 @@ constexpr int Y_BN = 128, Y_STAGE = X_BK * Y_BN * 4;      // 8 KB per stage, thr
 // LATE (diagnostics): the fragment loads of step k + 1, which land IN PLACE in the registers the multiplies of step k read, are
 // issued after the step's barrier instead of right behind the last multiply.
 // PLAIN_STORE (diagnostics): M leaves through ordinary stores instead of nontemporal ones.
-template <int NPROD, bool CLAIM = true, bool STRICT = false, bool LATE = false, bool PLAIN_STORE = false>
+// COHERENT (diagnostics): the LDS-DMA loads of V carry sc0 sc1 (system scope: served past a possibly stale L2 line).
+template <int NPROD, bool CLAIM = true, bool STRICT = false, bool LATE = false, bool PLAIN_STORE = false, bool COHERENT = false>
 __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t* __restrict__ Uf, const float* __restrict__ V,
                                                                  float* __restrict__ M, int T, int Cout, int Cin, int64_t cols,
                                                                  int ncc, int nrt) {
@@ -372,7 +373,8 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
     auto load_stage = [&](int k0, int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds(b_src[j] + (int64_t)k0 * cols, (lds_ptr_t)(lds + buf * Y_STAGE + (wbase + j * X_NT) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(b_src[j] + (int64_t)k0 * cols, (lds_ptr_t)(lds + buf * Y_STAGE + (wbase + j * X_NT) * 16), 16, 0,
+                                             COHERENT ? 17 : 0);      // 17 = sc0 | sc1
     };
 
     f32x16 acc[2][4];
@@ -537,7 +539,7 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     const char* diag = getenv("BITSWAP_BF16X3_DIAG");
     const int shape = shape_env ? atoi(shape_env) : 2;
     const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : !strcmp(diag, "stray_exit") ? 3
-                   : !strcmp(diag, "noclaim_late") ? 4 : !strcmp(diag, "noclaim_plainstore") ? 5 : -1;
+                   : !strcmp(diag, "noclaim_late") ? 4 : !strcmp(diag, "noclaim_plainstore") ? 5 : !strcmp(diag, "noclaim_coherent") ? 6 : -1;
     if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6) || (dg == 3 && shape != 1) || (dg >= 4 && shape != 2)) return BS_EINVAL;
 #define BS_X3_O2(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<NP, CL, ST>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt)
 #define BS_X3_O1(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3<NP, 0, CL, ST>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt)
@@ -549,6 +551,7 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         else if (dg == 2) BS_X3_O2(6, false, true);
         else if (dg == 4) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<6, false, false, true>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
         else if (dg == 5) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<6, false, false, false, true>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
+        else if (dg == 6) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<6, false, false, false, false, true>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt);
         else if (nprod == 9) BS_X3_O2(9, true, false);
         else BS_X3_O2(6, true, false);
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;

@@ -240,8 +240,7 @@ print("RESULT " + json.dumps(out))
         # with the CONTROL the round-4 hunt never ran: the same eager forked codec on the default fp32 GEMM ("fp32" below)
         plan = (("fp32", None, "0"), ("fp32", None, "1"), ("fp32", None, "0"), ("fp32", None, "1"))   # the DEFAULT route: graph replay / eager, forked
         if os.environ.get("REPRO_BISECT") == "1":     # swap single kernels of the stacks for their alternatives (no launch added)
-            plan = (("2", "noclaim", "1"), ("2", "noclaim", "nop:wino_fused"), ("2", "noclaim", "nop:wino_gemm_bf16x3"),
-                    ("2", "noclaim", "nop:wino_gemm,head_params"), ("2", "noclaim", "1"), ("2", "noclaim", "nop:wino_fused"))
+            plan = (("2", "noclaim", "1"), ("2", "noclaim_coherent", "1"), ("2", "noclaim", "1"), ("2", "noclaim_coherent", "1"))
     for shape, diag, eager in plan:
         env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE=shape, REPRO_EAGER_FORK="0" if eager == "0" else "1")
         if eager.startswith("nop:"):
