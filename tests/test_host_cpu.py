@@ -692,3 +692,31 @@ def test_overlap_stats_tool(tmp_path):
     assert "some kernel 6.0 ms" in head and "a bulk kernel 5.0 ms" in head and "a serial kernel 3.0 ms" in head
     assert "only serial 1.0 ms" in head and "nothing 1.0 ms" in head
     assert "sum of bulk kernel time 7.0 ms, of serial kernel time 3.0 ms" in out
+
+
+def test_bf16x3_async_fragment_loads_are_not_touched_before_their_wait(tmp_path):
+    """bs_wino_gemm_bf16x3 requests its U fragments with inline-asm global loads and places the s_waitcnt by hand; the
+    compiler treats the destination registers as defined from the asm statement on, so a copy or spill of them ahead of the wait
+    would read stale data -- a property of the register allocation, not of the source.  Checked on the BUILT code: hipcc -S of
+    the translation unit, then no instruction of the four product kernels (both tile shapes, 6 and 9 limb products) reads or
+    writes an asynchronously loaded register before the next vmcnt wait (tools/isa_count.py::async_load_hazards)."""
+    import importlib.util
+    import subprocess
+    from bitswap_amd import build
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(ROOT, "bitswap_amd", "csrc", "wino_gemm_bf16x3.hip")
+    out = str(tmp_path / "x3.s")
+    flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    r = subprocess.run([build.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    spec = importlib.util.spec_from_file_location("isa_count", os.path.join(ROOT, "tools", "isa_count.py"))
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    lines = [l.strip() for l in open(out).read().split("\n")]
+    for name in ("k_wino_gemm_bf16x3_o2ILi6ELb1ELb0ELb0ELb0ELb0E", "k_wino_gemm_bf16x3_o2ILi9ELb1ELb0ELb0ELb0ELb0E",
+                 "k_wino_gemm_bf16x3ILi6ELi0ELb1ELb0ELb0E", "k_wino_gemm_bf16x3ILi9ELi0ELb1ELb0ELb0E"):
+        res = ic.async_load_hazards(lines, name)
+        assert res is not None, name
+        nloads, hazards = res
+        assert nloads >= 12 and not hazards, (name, nloads, hazards[:3])
+

@@ -49,8 +49,57 @@ def blocks(lines, name):
             mix(ins, f"{name} [lines {a}..{e}]")
 
 
+def async_load_hazards(lines, name):
+    """Inline-asm `global_load_dwordx4` (between ;;#ASMSTART / ;;#ASMEND) land asynchronously in registers the compiler
+    believes defined: list every instruction of kernel `name` that reads or writes such a register before the next
+    `s_waitcnt ... vmcnt(...)` (the correctness of the hand-placed waits of wino_gemm_bf16x3.hip is a property of the
+    register allocation, so it is checked on the built code, tests/test_host_cpu.py).  -> (number of asm loads seen, hazards)."""
+    import re
+    b = body(lines, name)
+    if b is None:
+        return None
+
+    def regs(text):
+        out = set()
+        for a, z in re.findall(r'\bv\[(\d+):(\d+)\]', text):
+            out |= set(range(int(a), int(z) + 1))
+        for a in re.findall(r'\bv(\d+)\b', text):
+            out.add(int(a))
+        return out
+    pending, hazards, inasm, nloads = {}, [], False, 0
+    for i, t in enumerate(b):
+        if t.startswith(';;#ASMSTART'):
+            inasm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            inasm = False
+            continue
+        if not t or t.startswith((';', '.')) or t.split(';')[0].rstrip().endswith(':'):
+            continue
+        op = t.split()[0]
+        if inasm and op.startswith('global_load_dword'):
+            nloads += 1
+            for r in regs(t.split()[1].rstrip(',')):
+                pending[r] = i
+            continue
+        if op == 's_waitcnt' and 'vmcnt' in t:
+            pending = {}
+            continue
+        if op.startswith('s_'):
+            continue
+        hit = regs(' '.join(t.split()[1:])) & set(pending)
+        if hit:
+            hazards.append((i, t, sorted(hit)))
+    return nloads, hazards
+
+
 def main():
     import re
+    if sys.argv[1] == "--async-loads":
+        lines = open(sys.argv[2]).read().split('\n')
+        for name in sys.argv[3:]:
+            print(name, async_load_hazards(lines, name))
+        return
     if sys.argv[1] == "--blocks":
         lines = open(sys.argv[2]).read().split('\n')
         for name in sys.argv[3:]:
