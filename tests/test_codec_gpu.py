@@ -159,6 +159,12 @@ def test_winograd_convs_match_torch(ks, small):
         s2, a2, v2 = hip.wino_fused(m, tuple(x.shape), ts, b_out, res, True, want_sum=True, want_act=True, ts_out=ts)
         assert torch.equal(s2, s) and torch.equal(a2, act)
         assert torch.equal(v2, hip.wino_in(act, None, False, ms))
+        os.environ["BITSWAP_FUSED_PLAIN"] = "1"      # diagnostics switch: ordinary loads of M / stores of V -- same bits
+        try:
+            s3, a3, v3 = hip.wino_fused(m, tuple(x.shape), ts, b_out, res, True, want_sum=True, want_act=True, ts_out=ts)
+        finally:
+            del os.environ["BITSWAP_FUSED_PLAIN"]
+        assert torch.equal(s3, s2) and torch.equal(a3, a2) and torch.equal(v3, v2)
         n7 = x[:3].contiguous()   # a partial image block (3 of 16 images of the workgroup live)
         assert torch.equal(hip.wino_fused(n7, tuple(n7.shape), 0, None, None, False, ts_out=ts)[2],
                            hip.wino_in(n7, None, False, ms))
