@@ -303,13 +303,14 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
 // k_rans_pop_pivot: BS_LAYOUT_PIVOT rows (uniform-width bins, CDF spec 2 or 3), one wavefront per chain.
 //
 // The table kernel hands over 64 cumulative values per row (one per group of NPL bins) plus which bin took the remnant
-// and how much.  Per symbol: ballot(pivot <= m) names the group L; lanes 0 .. NPL-1 rebuild the cdf of its NPL bins and
-// lanes NPL .. 2 NPL-1 those of group L-1 (whose last cdf is what the first bin of L is differenced against), each with
+// and how much.  Per symbol: ballot(pivot <= m) names the group L; lanes 0 .. NPL-1 rebuild the cdf of its NPL bins, each with
 // exactly the operations logistic_row spends on that bin (own anchor exponential, own geometric factor, residual of the
 // stored endpoint; spec 2: a correctly rounded reciprocal per bin, spec 3: the block's product tree built by a butterfly
 // exchange over its lanes -- IEEE multiplication commutes, so every lane holds the node values the table kernel computed --
 // ONE reciprocal of the root and one multiplication per level back down) -- the truncated
-// differences are therefore the table's, and a 6-step scan on top of the pivot gives c_s and f_s.  About 2.5x the
+// differences of bins 1 .. NPL-1 are therefore the table's; the frequency of the group's FIRST bin, whose pmf is differenced
+// against the last cdf of the group below, is what the integers leave: pivot[L+1] - pivot[L] - sum of the others (the remnant
+// bump included), so the group below is never evaluated.  A scan on top of the pivot gives c_s and f_s.  About 2.5x the
 // instructions of k_rans_pop_wave per symbol, but 512 B of HBM traffic per row instead of 4352 B: at 400 chains the
 // row-reading pop kernel ran at the HBM roof (3.57 GB per launch in 0.57 ms) and nothing overlapped with it
 // (profiles/r03m_overlap2.txt); this one touches the L2-resident endpoint table and little else.
@@ -317,21 +318,31 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
 // that do not need them; pivots and the 64 anchor endpoints of a row are prefetched PF rows ahead like the rows of
 // k_rans_pop_wave; (mu, scale, bin width) wait in registers per 64-symbol chunk.
 // ------------------------------------------------------------------------------------------
-// lane i <- lane i-1 of the whole wavefront (DPP wave_shr:1; lane 0 keeps its value)
+// lane i <- lane i-1 of the whole wavefront (DPP wave_shr:1; lane 0 has no source: its result is not used)
 __device__ __forceinline__ double wave_shr1_f64(double v) {
     const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, 0x138, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), 0x138, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)u, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), 0x138, 0xf, 0xf, false);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
-// 64-bit lane exchange by DPP (two 32-bit moves; every lane of a row has a source, so `old` never shows)
+// 64-bit lane exchange by DPP: two 32-bit moves (every lane of a row has a source, so no `old` value is needed -- with
+// update_dpp(old = v, ...) hipcc copied v first: four instructions per exchange instead of two)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     const uint64_t u = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// the two half-waves of v, each spread over the whole wavefront (gfx950 v_permlane32_swap: no LDS round trip as __shfl's
+// ds_bpermute has): lo = lane k & 31 of v, up = lane 32 + (k & 31) of v
+__device__ __forceinline__ void split_halves_f64(double v, double& lo, double& up) {
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const auto a = __builtin_amdgcn_permlane32_swap((uint32_t)u, (uint32_t)u, false, false);
+    const auto c = __builtin_amdgcn_permlane32_swap((uint32_t)(u >> 32), (uint32_t)(u >> 32), false, false);
+    lo = __longlong_as_double((long long)(((uint64_t)c[0] << 32) | a[0]));
+    up = __longlong_as_double((long long)(((uint64_t)c[1] << 32) | a[1]));
 }
 // 1 / x of every lane by CDF spec 3's product tree over aligned blocks of N <= 16 lanes (bitswap_dev.h::tree_inverse, one bin
 // per lane): level k pairs the node of lanes [2^k j', 2^k (j'+1)) with its sibling -- quad_perm [1,0,3,2], [2,3,0,1],
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
     constexpr int K = NPL * 64;
     constexpr bool ONE_EXP = NPL <= 16;      // both exponentials of a symbol in ONE instruction stream (lower / upper half-wave)
     extern __shared__ int32_t sh_sym[];
+    __shared__ double4 sh_prm[64];           // (mu, 1/scale, h, h/scale) of the chunk's 64 rows: one broadcast read per symbol
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     if (status[b] != BS_ST_OK) {  // failed chain (a bad table among them): skipped, outputs well-defined
@@ -384,11 +396,11 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
     const double M = (double)((1ll << bits) - (1ll << quantbits));
     int st = BS_ST_OK;
     const int64_t ld2 = ld / 2;
-    // this lane's role in the rebuild.  Lanes 0 .. NPL-1: bin `bi` of the symbol's group L; lanes NPL .. 2 NPL-1: bin `bi` of
-    // the group below it (its last cdf closes the first bin of L; spec 3 needs the whole group for that one quotient).
+    // this lane's role in the rebuild.  Lanes 0 .. NPL-1: bin `bi` of the symbol's group L (the other lanes repeat them, unused).
     // With ONE_EXP the upper half-wave evaluates the geometric factors Q_b = exp(-b h/scale) in the same instructions in
     // which the lower half evaluates the anchors exp(-t_a); lane 32 + k serves lane k (NPL divides 32: same bin index).
-    const bool is_bin = lane < NPL;
+    const bool is_rest = lane >= 1 && lane < NPL;      // bins 1 .. NPL-1: frequencies from the cdf; bin 0: from the pivots
+    constexpr unsigned long long REST_MASK = ((NPL >= 64 ? 0ull : (1ull << NPL)) - 1ull) & ~1ull;
     const int bi = lane & (NPL - 1);
     const bool q_lane = ONE_EXP && lane >= 32;
 
@@ -428,6 +440,9 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
         const double hr_l = h_l * rs_l;
         // spec 3: which rows of the chunk take the batch inversion (logistic_row's test, one bit per row)
         const unsigned long long batch_rows = SPEC == 3 ? __ballot((double)NPL * fabs(hr_l) < BS_SPEC3_FAST_HR) : 0ull;
+        __syncthreads();                      // one wavefront per block: orders the LDS accesses, costs nothing
+        sh_prm[lane] = make_double4(mu_l, rs_l, h_l, hr_l);
+        __syncthreads();
         int o = 0;
         uint32_t mysym = 0;
         for (int g = 64 / PF - 1; g >= 0; --g) {
@@ -436,16 +451,16 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                 const int dk = d & 63;
                 const uint32_t m = (uint32_t)h & mask;
                 const int L = __popcll(__ballot(pv[u].x <= m)) - 1;          // group of the symbol: 0..63 (c_0 = 0 <= m)
-                const int Lb = max(L - 1, 0);
-                const int j = (is_bin ? L : Lb) * NPL + bi;                  // this lane's bin (lanes 0 .. 2 NPL-1)
+                const int j = L * NPL + bi;                                  // this lane's bin
                 // its upper endpoint: data dependent, requested first, used last
                 const double e_j = erow[min(j, K - 2)];
                 erow -= d > 0 ? e_stride : 0;
-                const double m_ = readlane_f64(mu_l, dk), rs = readlane_f64(rs_l, dk), hstep = readlane_f64(h_l, dk);
-                const double hr = readlane_f64(hr_l, dk);
-                const double eL = readlane_f64(anc[u], L), eLb = readlane_f64(anc[u], Lb);
-                const double e_a = is_bin ? eL : eLb;
+                const double4 prm4 = sh_prm[dk];                             // every lane the same address: a broadcast
+                const double m_ = prm4.x, rs = prm4.y, hstep = prm4.z, hr = prm4.w;
+                const double e_a = readlane_f64(anc[u], L);
                 const uint32_t piv_L = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].x, L);
+                const uint32_t piv_up = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].x, min(L + 1, 63));
+                const uint32_t piv_N = L == 63 ? (1u << bits) : piv_up;      // cumulative value behind the group
                 const uint32_t bumped = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 0);
                 const uint32_t rem = (uint32_t)__builtin_amdgcn_readlane((int)pv[u].y, 1);
                 // refill: the row PF steps ahead
@@ -459,8 +474,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                 double A, Q;
                 if (ONE_EXP) {
                     const double x = det_exp_hi(q_lane ? -((double)bi * hr) : -((e_a - m_) * rs), hi);
-                    A = x;
-                    Q = __shfl(x, lane | 32, 64);                            // lane k < 32 <- lane 32 + k
+                    split_halves_f64(x, A, Q);                               // lane k < 32: its own A, the Q of lane 32 + k
                 } else {
                     A = det_exp_hi(-((e_a - m_) * rs), hi);
                     Q = det_exp(-((double)bi * hr));
@@ -478,26 +492,33 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                     c = recip_1_to_huge(fma(Q, uu, 1.0));
                 }
                 if (j == K - 1) c = 1.0;                                     // the last bin has no upper endpoint
-                // cdf of the bin below: lane-1 within the group, the last lane of the group below for bin 0, nothing for the very first bin
-                double below = wave_shr1_f64(c);
-                const double c_grp_below = readlane_f64(c, 2 * NPL - 1);
-                if (lane == 0) below = L == 0 ? 0.0 : c_grp_below;
+                // bins 1 .. NPL-1: pmf = cdf - cdf of the lane below (mnist_compress.py:184), frequency as ANS.__init__ has it
+                const double below = wave_shr1_f64(c);
                 uint32_t f = trunc_u32((c - below) * M) + 1u;
                 if ((uint32_t)j == bumped) f += rem;
-                if (!is_bin) f = 0u;
+                if (!is_rest) f = 0u;
                 uint32_t incl = f;                                           // inclusive scan over the NPL bins
                 incl += dpp_or0<0x111, 0xf>(incl);
                 incl += dpp_or0<0x112, 0xf>(incl);
                 if (NPL > 4) incl += dpp_or0<0x114, 0xf>(incl);
                 if (NPL > 8) incl += dpp_or0<0x118, 0xf>(incl);
                 if (NPL > 16) incl += dpp_or0<0x142, 0xa>(incl);
-                const uint32_t cst = piv_L + incl - f;                       // c of this lane's bin
-                const int pos = __popcll(__ballot(is_bin && cst <= m));      // 1..NPL
-                const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)cst, pos - 1);
-                const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)f, pos - 1);
+                // bin 0: what the integers leave (the group's total is pivot[L+1] - pivot[L], remnant bump included)
+                const uint32_t rest = (uint32_t)__builtin_amdgcn_readlane((int)incl, NPL - 1);
+                const uint32_t f0 = piv_N - piv_L - rest;
+                const uint32_t cst = (piv_L + f0) + (incl - f);              // c of this lane's bin (lanes 1 .. NPL-1)
+                const int pos = __popcll(__ballot(cst <= m) & REST_MASK) + 1;   // 1..NPL (bin 0 starts at pivot[L] <= m)
+                const uint32_t cs_r = (uint32_t)__builtin_amdgcn_readlane((int)cst, pos - 1);
+                const uint32_t fs_r = (uint32_t)__builtin_amdgcn_readlane((int)f, pos - 1);
+                const uint32_t cs = pos == 1 ? piv_L : cs_r;
+                const uint32_t fs = pos == 1 ? f0 : fs_r;
                 mysym = (lane == dk) ? (uint32_t)(L * NPL + pos - 1) : mysym;
                 h = (uint64_t)fs * (h >> bits) + (uint64_t)(m - cs);
-                if ((uint32_t)(h >> 32) == 0u) {  // h < 2^32, mnist_compress.py:65
+                uint32_t hhi = (uint32_t)(h >> 32);
+#if !__has_feature(address_sanitizer)
+                asm("" : "+s"(hhi));              // keep this a 32-bit scalar compare (hipcc otherwise builds a 64-bit VALU one)
+#endif
+                if (hhi == 0u) {  // h < 2^32, mnist_compress.py:65
                     h = (h << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, o);
                     ++o;
                 }
