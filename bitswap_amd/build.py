@@ -19,11 +19,18 @@ PRODUCT_LIB = os.path.join(HERE, "csrc", "libbitswap_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-pass-failed"]   # K = 2048 rows cannot reach the occupancy hint of k_logistic; that is expected
 EXTRA_FLAGS = [f for f in os.environ.get("BITSWAP_HIPCC_EXTRA", "").split() if f]   # e.g. -DBS_GEMM_LAB (tools/gemm_probe.py)
+# Per-file flags.  net_epilogue.hip WITHOUT the SLP vectorizer: under plain -O3 hipcc packs the transforms' float32 additions into
+# v_pk_add_f32 with op_sel shuffles (k_wino_fused<6,6>: 112 packed operations + the moves that line their operands up = 1,787
+# instructions, 72 registers; without: 1,417 instructions, 66 registers, the same IEEE operations on the same values).  Beside
+# the bf16 MFMA wavefronts of the bf16x3 GEMM one such packed addition lost its result in lanes 48..63 about once in 10^5
+# workgroups (round 5, visits v-z: DESIGN 3.4); the packed form is slower beside MFMAs anyway.
+FILE_FLAGS = {"net_epilogue.hip": ["-fno-slp-vectorize"]}
 
 
 def _flag_hash():
     import hashlib
-    return hashlib.md5(" ".join([f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS).encode()).hexdigest()[:8]
+    per_file = [k + ":" + ",".join(v) for k, v in sorted(FILE_FLAGS.items())]
+    return hashlib.md5(" ".join([f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS + per_file).encode()).hexdigest()[:8]
 
 
 # A build with extra flags (lab kernels that give WRONG results, selectable by environment) never lands on the product's
@@ -81,7 +88,7 @@ def build_hip(force=False, verbose=False):
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), deps):
-            cmd = [hipcc_path()] + cflags + ["-c", "-o", obj, src]
+            cmd = [hipcc_path()] + cflags + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -505,13 +505,10 @@ class BitSwapCodec:
     def _fork_ok(self, state):
         if self.fork == "0" or self.serial is not None or self.bulk is not None or not isinstance(self.backend, HipBackend):
             return False
-        # Fail closed (round 5): with the opt-in bf16x3 conv arithmetic the forked two-stream step is NOT taken unless forced.
-        # In 150-run series of the forked step at 32 chains (eager and graph replay alike) 2-7 % of the runs decoded ONE chain
-        # wrong -- always a chain with index 3 mod 4 -- while the same codec on one stream, the fp32 route forked, and every
-        # bf16x3 GEMM launch compared with a second launch of itself inside the failing runs were exact (1,120 forked fp32 runs; DESIGN 3.4,
-        # profiles/r05*_bf16x3_repro.txt, tools/bf16x3_repro.py).  The kernel pair that interferes is not identified.
-        if self.fork != "1" and getattr(self.model, "gemm_arith", "fp32") != "fp32" and getattr(self.model, "_ufrags", None):
-            return False
+        # (Round 5, first half: with the opt-in bf16x3 conv arithmetic the forked step was not taken -- 2-7 % of the forked runs
+        # decoded one chain wrong.  Cause found in visits v-A: a compiler-packed v_pk_add_f32 of k_wino_fused lost its
+        # result in lanes 48..63 beside the bf16 MFMA wavefronts; net_epilogue.hip is built without the SLP vectorizer since,
+        # 0 failures in 1,500 forked runs against 22 in 800 with the packed build on the same box -- the gate is gone.)
         return self.fork == "1" or state.B <= self.fork_max_chains
 
     def _aux_stream(self):

@@ -1071,27 +1071,34 @@ def test_bf16x3_gemm_is_bit_stable_beside_small_kernels_without_the_register_cla
         assert int(bad_g) == 0 and int(bad_n) == 0, (shape, int(bad_g), int(bad_n))
 
 
-def test_bf16x3_codec_takes_the_one_stream_step_and_stays_lossless(monkeypatch):
-    """Fail closed (round 5): with the opt-in bf16x3 arithmetic the codec does not fork the block step over two streams -- in
-    150-run series the forked step decoded one chain (always index 3 mod 4) wrong in 2-7 % of the runs, eager and from a
-    hipGraph alike, while this one-stream order never failed in 200 -- and twenty sender / receiver runs in a row return every
-    block and unwind every chain.  The fp32 route keeps the forked step (0 failures in 120 eager runs, and every bench run)."""
+def test_bf16x3_forked_codec_stays_lossless(monkeypatch):
+    """The opt-in bf16x3 arithmetic under the forked two-stream block step, eager, 32 chains: the scenario that decoded one chain
+    (always index 3 mod 4) wrong in 2-7 % of the runs until visit A of round 5.  tools/bf16x3_repro.py --record kept every stack
+    kernel call of the failing runs and repeated them alone: ONE k_wino_fused<6,6> call per failing run did not repeat, 400 wrong
+    values = one channel of one chain = lanes 48..63 of one wavefront, and the wrong pre-activation value was exactly the right
+    one minus the term t1[r][4] that a compiler-packed v_pk_add_f32 (op_sel crossing halves) adds -- beside bf16 MFMA wavefronts
+    only.  net_epilogue.hip is now built without the SLP vectorizer (no packed float32 operations:
+    tests/test_host_cpu.py::test_conv_epilogue_kernels_are_built_without_packed_float32_operations); same box, 0 failures in
+    1,500 runs against 22 in 800 with the packed build (profiles/r05A_bf16x3_slp_ab.txt).  Here: 120 runs (the packed build
+    would fail this with probability 0.96), every block back, every chain unwound, the forked step taken."""
     monkeypatch.setenv("BITSWAP_GEMM_ARITH", "bf16x3")
     model, zend, zcen = workload.build("cifar8", DEV, quantbits=10)
     assert model.gemm_arith == "bf16x3" and model._ufrags
     B, n = 32, 2
     images = workload.synthetic_blocks(B * n, model.xs, seed=19).view(B, n, -1).to(torch.int32)
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
-    for rep in range(20):
+    codec.use_graphs = False
+    want = initial_states(B)
+    for rep in range(120):
         state, _ = codec.compress(images.to(DEV))
         out = codec.decompress(state, n)
-        assert torch.equal(out.cpu(), images) and state.to_lists() == initial_states(B), rep
-    assert codec.forked_steps == 0
-    monkeypatch.delenv("BITSWAP_GEMM_ARITH")
-    base, zend, zcen = workload.build("cifar8", DEV, quantbits=10)
-    c32 = BitSwapCodec(base, zend, zcen, quantbits=10, bitswap=True)
-    state, _ = c32.compress(images.to(DEV))
-    assert torch.equal(c32.decompress(state, n).cpu(), images) and c32.forked_steps > 0
+        assert torch.equal(out.cpu(), images) and state.to_lists() == want, rep
+    assert codec.forked_steps > 0
+    graphs = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)       # and from the hipGraph of the forked step
+    for rep in range(20):
+        state, _ = graphs.compress(images.to(DEV))
+        assert torch.equal(graphs.decompress(state, n).cpu(), images) and state.to_lists() == want, rep
+    assert graphs.forked_steps > 0
 
 
 def test_own_gemm_route_round_trip():

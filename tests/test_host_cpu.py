@@ -720,3 +720,21 @@ def test_bf16x3_async_fragment_loads_are_not_touched_before_their_wait(tmp_path)
         nloads, hazards = res
         assert nloads >= 12 and not hazards, (name, nloads, hazards[:3])
 
+
+
+def test_conv_epilogue_kernels_are_built_without_packed_float32_operations(tmp_path):
+    """Round 5, visits v-z: the one wrong result of the bf16x3 hunt was a v_pk_add_f32 of k_wino_fused<6,6> -- hipcc's SLP
+    vectorizer packs the transforms' additions -- that lost its result in lanes 48..63 beside bf16 MFMA wavefronts.  net_epilogue.hip
+    is therefore compiled with -fno-slp-vectorize (bitswap_amd/build.py::FILE_FLAGS); checked on the BUILT code: with the flags the
+    product build uses, the translation unit holds no packed float32 arithmetic at all."""
+    import subprocess
+    from bitswap_amd import build
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(ROOT, "bitswap_amd", "csrc", "net_epilogue.hip")
+    assert "-fno-slp-vectorize" in build.FILE_FLAGS["net_epilogue.hip"]
+    out = str(tmp_path / "net.s")
+    flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")] + build.FILE_FLAGS["net_epilogue.hip"]
+    r = subprocess.run([build.hipcc_path()] + flags + ["-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    packed = [l.strip() for l in open(out) if l.strip().startswith(("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"))]
+    assert not packed, packed[:5]

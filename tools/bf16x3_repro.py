@@ -389,6 +389,273 @@ print("RESULT " + json.dumps(out))
 """
 
 
+RECORD_CODE = r"""
+import os, sys, json, torch
+sys.path.insert(0, "__ROOT__")
+from bitswap_amd import workload
+from bitswap_amd.codec import BitSwapCodec, initial_states
+from bitswap_amd import hip as _hip
+model, zend, zcen = workload.build("cifar8", "cuda", quantbits=10)
+B, n = 32, 2
+images = workload.synthetic_blocks(B * n, model.xs, seed=19).view(B, n, -1).to(torch.int32)
+codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)
+codec.use_graphs = False
+codec.fork = os.environ.get("REPRO_FORK", "1")
+
+# NO launch is added to the run: every stack kernel call only leaves references to its arguments and results behind (so no buffer
+# of the run is reused before its end); after a failing run every call is repeated alone on one stream and compared bit by bit.
+REC, ON = [], [False]
+MAIN = torch.cuda.current_stream().cuda_stream
+# REPRO_POISON=nan | value: after every run each float32 RESULT of a stack kernel is overwritten with it before its memory goes
+# back to the allocator -- a later kernel that reads memory its producer has not (visibly) written yet shows the poison
+POISON = os.environ.get("REPRO_POISON")
+POISON_VALUE = float(POISON) if POISON else -1.0e30
+SWEEP = int(os.environ.get("REPRO_SWEEP_MB", "0"))      # after poisoning: read this much other memory (evicts the poison lines from every L2)
+sweep_buf = torch.zeros(SWEEP * (1 << 18), dtype=torch.float32, device="cuda") if SWEEP else None
+def _wrap(name):
+    orig = getattr(_hip, name)
+    def w(*a, **k):
+        out = orig(*a, **k)
+        if ON[0]:
+            REC.append((name, orig, a, k, out, torch.cuda.current_stream().cuda_stream != MAIN))
+        return out
+    setattr(_hip, name, w)
+for _n in ("conv3_wino", "wino_fused", "wino_gemm", "wino_gemm_bf16x3", "head_params", "small_k_gemm", "wino_in", "wino_out"):
+    _wrap(_n)
+
+def tensors(o):
+    return [t for t in (o if isinstance(o, (tuple, list)) else (o,)) if torch.is_tensor(t)]
+
+def describe(x, y):
+    d = x != y
+    idx = d.nonzero()
+    r = {"shape": list(x.shape), "differing": int(idx.shape[0]), "of": x.numel()}
+    for dim in range(x.dim()):
+        u = idx[:, dim].unique()
+        r[f"dim{dim}"] = {"distinct": int(u.numel()), "values": u[:48].tolist()}
+    if x.dim() == 3 and x.shape[2] % B == 0:           # [ts^2, C, chain * tiles]
+        T = x.shape[2] // B
+        r["chains"] = (idx[:, 2] // T).unique().tolist()
+        r["tiles"] = (idx[:, 2] % T).unique().tolist()
+    elif x.dim() >= 2 and x.shape[0] == B:
+        r["chains"] = idx[:, 0].unique().tolist()
+    xs, ys = x[d][:12], y[d][:12]
+    r["first"] = [{"at": idx[i].tolist(), "run": float(xs[i]), "alone": float(ys[i]),
+                   "run_bits": hex(int(xs[i].view(torch.int32)) & 0xffffffff), "alone_bits": hex(int(ys[i].view(torch.int32)) & 0xffffffff)}
+                  for i in range(xs.numel())] if x.dtype == torch.float32 else []
+    # is the run's value a value the lone launch has elsewhere in the tensor (a shifted or stale read)?
+    if x.dtype == torch.float32 and xs.numel():
+        r["run_values_found_elsewhere_alone"] = [int((y == v).sum()) for v in xs[:6]]
+        r["run_values_zero"] = int((x[d] == 0).sum())
+        r["run_values_nan"] = int(torch.isnan(x[d]).sum())
+        r["run_values_poison"] = int((x[d] == POISON_VALUE).sum())
+    return r
+
+BT6 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+
+def autopsy(orig, a, k, v_run, v_alone):
+    # A failing wino_fused(M [36, C, 32 * 16] -> V [36, C, 32 * 16]) call: which elements of the ACTIVATED PLANE (between the two
+    # transforms) explain V_run - V_alone, by least squares through B^T d B; what value the kernel must have held there; and where
+    # in the run's tensors such values exist.
+    d = v_run != v_alone
+    idx = d.nonzero()
+    c, chain = int(idx[0, 1]), int(idx[0, 2]) // 16
+    dv = (v_run[:, c, chain * 16:chain * 16 + 16].double() - v_alone[:, c, chain * 16:chain * 16 + 16].double()).cpu()   # [36, 16 tiles]
+    # forward operator: plane perturbation [16, 16] -> V of the 16 tiles (window of tile (ty, tx): rows 4 ty - 1 .. 4 ty + 4)
+    cols_ = []
+    for pr in range(16):
+        for pc in range(16):
+            out_ = torch.zeros(36, 16, dtype=torch.float64)
+            for ty in range(4):
+                for tx in range(4):
+                    wr, wc = pr - (4 * ty - 1), pc - (4 * tx - 1)
+                    if 0 <= wr < 6 and 0 <= wc < 6:
+                        out_[:, ty * 4 + tx] += torch.outer(BT6[:, wr], BT6[:, wc]).reshape(36)
+            cols_.append(out_.reshape(-1))
+    A = torch.stack(cols_, 1)                                  # [576, 256]
+    sol = torch.linalg.lstsq(A, dv.reshape(-1, 1)).solution.reshape(16, 16)
+    resid = float((A @ sol.reshape(-1, 1) - dv.reshape(-1, 1)).abs().max())
+    nz = (sol.abs() > 1e-3 * float(dv.abs().max())).nonzero().tolist()
+    r = {"channel": c, "chain": chain, "plane_elements_changed": [(pr, pc, round(float(sol[pr, pc]), 5)) for pr, pc in nz][:40],
+         "lstsq_residual": resid, "max_dV": float(dv.abs().max())}
+    # the activated plane alone (same call, act plane requested)
+    try:
+        kk = dict(k); kk["want_act"] = True
+        plane = orig(*a, **kk)[1]                              # [32, C, 16, 16]
+        if plane is not None:
+            r["plane_alone_at_changed"] = [round(float(plane[chain, c, pr, pc]), 5) for pr, pc in nz][:40]
+    except Exception as e:
+        r["plane_error"] = repr(e)[:200]
+    return r, nz, sol
+
+def find_vector(vec, tol):
+    # 16 consecutive floats (64-byte aligned) anywhere in the run's recorded float32 tensors within tol of vec (a [16] tensor)
+    hits, seen = [], set()
+    v = vec.to("cuda", torch.float32).reshape(1, 16)
+    for i, (name, orig, a, k, o, aux) in enumerate(REC):
+        for role, ts in (("arg", [t for t in a if torch.is_tensor(t)]), ("out", tensors(o))):
+            for j, t in enumerate(ts):
+                if t.dtype != torch.float32 or t.numel() % 16 or t.data_ptr() in seen or not t.is_contiguous():
+                    continue
+                seen.add(t.data_ptr())
+                dist = (t.reshape(-1, 16) - v).abs().amax(1)
+                m = float(dist.min())
+                if m <= tol:
+                    row = int(dist.argmin())
+                    hits.append({"call": i, "kernel": name, "role": role, "tensor": j, "shape": list(t.shape), "row16": row,
+                                 "index": [int(x) for x in torch.unravel_index(torch.tensor(row * 16), t.shape)], "max_abs_diff": m})
+    return hits[:12]
+
+def find_lanes(targets, scale, skip_call):
+    # targets: {name: [16] tensor}: the 16 tiles' values of ONE plane element.  Sources: for every plane-shaped float32 tensor of the
+    # run [32, C, 16, 16] (arguments, results, and the sum / activated planes of every TS_IN = 6 fused call repeated alone) the
+    # 16 values X[n, c, r' + 4 ty, q' + 4 tx]; for Winograd-domain tensors [.., C, 32 * 16] the 16 consecutive values of a chain.
+    hits, seen = [], set()
+    tg = {k_: v_.to("cuda", torch.float32) for k_, v_ in targets.items()}
+    def scan(x, label):
+        if x is None or x.dtype != torch.float32:
+            return
+        if x.dim() == 4 and x.shape[0] == B and x.shape[2:] == (16, 16):
+            g = x.reshape(B, x.shape[1], 4, 4, 4, 4).permute(0, 1, 3, 5, 2, 4).reshape(B, x.shape[1], 16, 16)   # [n, c, (r', q'), (ty, tx)]
+        elif x.dim() == 3 and x.shape[2] == B * 16:
+            g = x.reshape(x.shape[0], x.shape[1], B, 16).permute(2, 1, 0, 3)                                    # [n, c, t, tile]
+        else:
+            return
+        for nm, t in tg.items():
+            dist = (g - t.reshape(1, 1, 1, 16)).abs().amax(3)
+            m = float(dist.min())
+            if m <= 1e-4 * scale:
+                i = int(dist.argmin())
+                n_, c_, e_ = i // (g.shape[1] * g.shape[2]), (i // g.shape[2]) % g.shape[1], i % g.shape[2]
+                hits.append({"target": nm, "source": label, "shape": list(x.shape), "chain": n_, "channel": c_, "element_or_t": e_, "max_abs_diff": m})
+    for i, (name, orig, a, k, o, aux) in enumerate(REC):
+        for role, ts in (("arg", [t for t in a if torch.is_tensor(t)]), ("out", tensors(o))):
+            for j, t in enumerate(ts):
+                if t.data_ptr() in seen:
+                    continue
+                seen.add(t.data_ptr())
+                scan(t, f"call {i} {name} {role}{j}" + (" aux" if aux else " main"))
+        if name == "wino_fused" and len(a) >= 3 and a[2] == 6:
+            try:
+                so, ao, _ = orig(*a, **dict(k, want_sum=True, want_act=True))
+                tag = f"call {i} wino_fused" + (" aux" if aux else " main") + (" (THE FAILING CALL)" if i == skip_call else "")
+                scan(so, tag + " sum plane alone")
+                scan(ao, tag + " act plane alone")
+            except Exception as e:
+                hits.append({"error": repr(e)[:200], "call": i})
+        if len(hits) > 40:
+            break
+    return hits
+
+def replay():
+    found = []
+    for i, (name, orig, a, k, out, aux) in enumerate(REC):
+        out2 = orig(*a, **k)
+        bad = [(j, x, y) for j, (x, y) in enumerate(zip(tensors(out), tensors(out2))) if x.shape != y.shape or not torch.equal(x, y)]
+        if bad:
+            found.append({"call": i, "of": len(REC), "kernel": name, "aux_stream": bool(aux),
+                          "before": [r[0] for r in REC[max(0, i - 3):i]],
+                          "args": [list(t.shape) if torch.is_tensor(t) else (type(t).__name__ if not isinstance(t, (int, float, bool, tuple, type(None))) else t) for t in a],
+                          "outputs": {j: describe(x, y) for j, x, y in bad}})
+            if name == "wino_fused" and len(found) == 1 and len(a) >= 3 and a[2] == 6:
+                try:
+                    j, x, y = bad[0]
+                    rep_, nz, sol = autopsy(orig, a, k, x, y)
+                    found[-1]["autopsy"] = rep_
+                    # hypothesis: ONE element of the inverse transform's input was different per lane.  For plane element (0, 0)
+                    # of a tile that is M position t = 0, for (3, 0) it is t = 30 (the only M positions that reach one output alone)
+                    rq = sorted({(pr % 4, pc % 4) for pr, pc in nz})
+                    found[-1]["autopsy"]["tile_elements"] = rq
+                    M = a[0]
+                    c, chain = rep_["channel"], rep_["chain"]
+                    # raw material for an offline analysis: the 36 inputs of each of the 16 lanes, the bias, the plane alone / its change
+                    found[-1]["autopsy"]["M_lanes"] = [[float(v) for v in row] for row in M[:, c, chain * 16:chain * 16 + 16].cpu()]
+                    found[-1]["autopsy"]["bias"] = None if a[3] is None else float(a[3][c])
+                    found[-1]["autopsy"]["plane_delta"] = [[float(v) for v in row] for row in sol]
+                    pl_ = orig(*a, **dict(k, want_act=True, want_sum=True))
+                    found[-1]["autopsy"]["plane_act_alone"] = [[float(v) for v in row] for row in pl_[1][chain, c].cpu()]
+                    found[-1]["autopsy"]["plane_sum_alone"] = [[float(v) for v in row] for row in pl_[0][chain, c].cpu()]
+                    if len(rq) == 1:
+                        pos = [(4 * (t // 4) + rq[0][0], 4 * (t % 4) + rq[0][1]) for t in range(16)]
+                        a_al = torch.stack([pl_[1][chain, c, i_, j_] for i_, j_ in pos]).double().cpu()
+                        s_al = torch.stack([pl_[0][chain, c, i_, j_] for i_, j_ in pos]).double().cpu()
+                        a_sn = a_al + torch.stack([sol[i_, j_] for i_, j_ in pos])
+                        s_sn = torch.where(a_sn > 0, a_sn, torch.log1p(a_sn.clamp(min=-0.999999)))
+                        found[-1]["autopsy"]["a_seen"] = [float(v) for v in a_sn]
+                        found[-1]["autopsy"]["lane_search"] = find_lanes({"a_seen": a_sn, "s_seen": s_sn, "delta_s": s_sn - s_al, "delta_a": a_sn - a_al},
+                                                                         float(a_al.abs().max()) + 1.0, i)
+                    if len(rq) == 1 and rq[0] in ((0, 0), (3, 0), (0, 3), (3, 3)):
+                        tp = {(0, 0): 0, (3, 0): 30, (0, 3): 5, (3, 3): 35}[rq[0]]
+                        kk = dict(k); kk["want_sum"] = True
+                        s_alone = orig(*a, **kk)[0]                                   # pre-activation sums [32, C, 16, 16]
+                        pl = orig(*a, **dict(k, want_act=True))[1]
+                        a_alone = torch.stack([pl[chain, c, 4 * (t // 4) + rq[0][0], 4 * (t % 4) + rq[0][1]] for t in range(16)]).double().cpu()
+                        dlt = torch.stack([sol[4 * (t // 4) + rq[0][0], 4 * (t % 4) + rq[0][1]] for t in range(16)])
+                        a_seen = a_alone + dlt
+                        s_seen = torch.where(a_seen > 0, a_seen, torch.log1p(a_seen.clamp(min=-0.999999)))      # ELU^-1
+                        s_al = torch.stack([s_alone[chain, c, 4 * (t // 4) + rq[0][0], 4 * (t % 4) + rq[0][1]] for t in range(16)]).double().cpu() if s_alone is not None else None
+                        m_true = M[tp, c, chain * 16:chain * 16 + 16].double().cpu()
+                        if s_al is not None:
+                            m_seen = m_true + (s_seen - s_al)
+                            found[-1]["autopsy"].update(M_position=tp, M_true=[round(float(v), 4) for v in m_true], M_seen=[round(float(v), 4) for v in m_seen])
+                            scale = float(m_true.abs().max()) + 1.0
+                            found[-1]["autopsy"]["M_seen_found_at"] = find_vector(m_seen, 2e-3 * scale)
+                            found[-1]["autopsy"]["M_true_found_at"] = find_vector(m_true, 1e-6)[:3]
+                except Exception as e:
+                    found[-1]["autopsy_error"] = repr(e)[:300]
+            if len(found) >= 2:
+                break
+    return found
+
+out = {"runs": 0, "lossless": 0, "baseline_replay_mismatches": None, "failures": [], "poison": POISON, "sweep_mb": SWEEP}
+NREP = int(os.environ.get("REPRO_REPS", "100"))
+for rep in range(NREP):
+    REC.clear()
+    ON[0] = True
+    state, met = codec.compress(images.to("cuda"))
+    back = codec.decompress(state, n)
+    torch.cuda.synchronize()
+    ON[0] = False
+    good = torch.equal(back.cpu(), images) and state.to_lists() == initial_states(B)
+    out["runs"] += 1
+    out["lossless"] += int(good)
+    if good and out["baseline_replay_mismatches"] is None:
+        out["calls_per_run"] = len(REC)
+        out["baseline_replay_mismatches"] = [(f["kernel"], f["call"]) for f in replay()]      # [] expected: every call repeats
+    if not good:
+        wrong = (back.cpu() != images).reshape(B, -1).any(1).nonzero().flatten().tolist()
+        out["failures"].append({"run": rep, "bad_chains": wrong, "calls": len(REC), "first_calls_that_do_not_repeat": replay()})
+        print("PARTIAL " + json.dumps(out["failures"][-1]), flush=True)
+        if len(out["failures"]) >= int(os.environ.get("REPRO_MAX_FAIL", "4")):
+            break
+    if POISON and rep >= 1:
+        seen = set()
+        for (name, orig, a, k, o, aux) in REC:
+            for t in tensors(o):
+                if t.dtype == torch.float32 and t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    t.fill_(POISON_VALUE)
+        if sweep_buf is not None:
+            sweep_buf.add_(1.0)
+        torch.cuda.synchronize()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def record_leg(reps=150):
+    """Which kernel call of a failing forked run does not repeat?  (no launch added to the run, see RECORD_CODE)"""
+    import subprocess
+    code = RECORD_CODE.replace("__ROOT__", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, BITSWAP_GEMM_ARITH="bf16x3", BITSWAP_BF16X3_SHAPE="2", BITSWAP_FORK="1", REPRO_REPS=str(reps))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=1500)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    res = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-1500:],
+                                                 "partial": [l[8:] for l in r.stdout.splitlines() if l.startswith("PARTIAL ")]}
+    print("record", json.dumps(res), flush=True)
+    return res
+
+
 def trail_leg(reps=120):
     """Where does a failing forked run first leave the one-stream run?  Head of every chain after every stack operation and a
     per-chain checksum of every conv stack's input and output, compared with the one-stream run of the same codec."""
@@ -411,12 +678,17 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--codec", action="store_true")
+    ap.add_argument("--record", action="store_true", help="forked bf16x3 codec with every stack kernel call kept; failing runs are replayed call by call")
     ap.add_argument("--focus", action="store_true", help="codec leg only: the failing scenario with and without counted waits, 14 runs each")
     ap.add_argument("--trail", type=int, default=0, help="runs of the checksum-trail leg (0: skip)")
     ap.add_argument("--storm", type=int, default=0, help="GEMM launches of the victim hunt (0: skip)")
     ap.add_argument("--small", action="store_true", help="micro leg with the neighbours that fit beside the unclaimed shape-2 kernel (<= 32 registers)")
     a = ap.parse_args()
     out = {}
+    if a.record:
+        out["record"] = record_leg(int(os.environ.get("REPRO_RECORD_REPS", "150")))
+        print(json.dumps(out, indent=1))
+        sys.exit(0)
     if a.trail:
         out["trail"] = trail_leg(a.trail)
     if a.storm:
