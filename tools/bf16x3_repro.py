@@ -656,6 +656,79 @@ def record_leg(reps=150):
     return res
 
 
+def pair_leg(rounds=100, ring=160):
+    """Two kernels only: k_wino_fused<6,6> (M [36, 256, 32 x 16] -> V, the call that fails in the codec) `ring` times into `ring`
+    different buffers on a side stream while the main stream runs the GEMM of the 32-chain codec on other operands (144
+    workgroups: the chip half empty); after a synchronize every V is compared with the first one.  Per library
+    (BITSWAP_HIP_LIB: the packed build / the product) and per GEMM (bf16x3 shape 2, fp32, none)."""
+    dev = "cuda"
+    torch.manual_seed(0)
+    T, C, cols, N = 36, 256, 512, 32
+    U, Vg = torch.randn(T, C, C, device=dev), torch.randn(T, C, cols, device=dev)
+    Uf = hip.frags_bf16x3(U)
+    M = torch.randn(T, C, cols, device=dev) * 2.0
+    bias = torch.randn(C, device=dev)
+    shape = (N, C, 16, 16)
+    ref = hip.wino_fused(M, shape, 6, bias, None, True, ts_out=6)[2].clone()
+    side = torch.cuda.Stream()
+    res = {"library": os.environ.get("BITSWAP_HIP_LIB", "product")}
+    for name, bulk in (("beside_bf16x3_gemm", lambda: hip.wino_gemm_bf16x3(Uf, Vg, 6)), ("beside_fp32_gemm", lambda: hip.wino_gemm(U, Vg)),
+                       ("alone", None), ("beside_bf16x3_gemm_again", lambda: hip.wino_gemm_bf16x3(Uf, Vg, 6))):
+        calls = differing = 0
+        where = []
+        for _ in range(rounds):
+            outs = []
+            torch.cuda.synchronize()
+            for i in range(ring):
+                with torch.cuda.stream(side):
+                    outs.append(hip.wino_fused(M, shape, 6, bias, None, True, ts_out=6)[2])
+                if bulk is not None:
+                    bulk()
+            torch.cuda.synchronize()
+            for o in outs:
+                calls += 1
+                if not torch.equal(o, ref):
+                    differing += 1
+                    idx = (o != ref).nonzero()
+                    where.append({"values": int(idx.shape[0]), "channels": idx[:, 1].unique().tolist()[:4], "chains": (idx[:, 2] // 16).unique().tolist()[:4],
+                                  "t": idx[:, 0].unique().tolist()[:8]})
+        res[name] = {"fused_calls": calls, "differing": differing, "where": where[:6]}
+        print("pair", res["library"][-24:], name, res[name], flush=True)
+    # the codec's own shape: BOTH streams run GEMM -> k_wino_fused chains (the layers of two conv stacks side by side)
+    for name, gemm in (("two_stacks_bf16x3", lambda v: hip.wino_gemm_bf16x3(Uf, v, 6)), ("two_stacks_fp32", lambda v: hip.wino_gemm(U, v))):
+        def stack(v, depth=3):
+            outs = []
+            for _ in range(depth):
+                m = gemm(v)
+                v = hip.wino_fused(m, shape, 6, bias, None, True, ts_out=6)[2]
+                outs.append(v)
+            return outs
+        want = [o.clone() for o in stack(Vg[:, :, :cols].contiguous())]
+        torch.cuda.synchronize()
+        calls = differing = 0
+        where = []
+        for _ in range(rounds):
+            got = []
+            torch.cuda.synchronize()
+            for i in range(ring // 8):
+                with torch.cuda.stream(side):
+                    got.append(stack(Vg))
+                got.append(stack(Vg))
+            torch.cuda.synchronize()
+            for outs in got:
+                for d_, (o, w) in enumerate(zip(outs, want)):
+                    calls += 1
+                    if not torch.equal(o, w):
+                        differing += 1
+                        idx = (o != w).nonzero()
+                        where.append({"layer": d_, "values": int(idx.shape[0]), "channels": idx[:, 1].unique().tolist()[:4],
+                                      "chains": (idx[:, 2] // 16).unique().tolist()[:4]})
+                        break
+        res[name] = {"fused_calls": calls, "differing": differing, "where": where[:6]}
+        print("pair", res["library"][-24:], name, res[name], flush=True)
+    return res
+
+
 def trail_leg(reps=120):
     """Where does a failing forked run first leave the one-stream run?  Head of every chain after every stack operation and a
     per-chain checksum of every conv stack's input and output, compared with the one-stream run of the same codec."""
@@ -678,6 +751,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--codec", action="store_true")
+    ap.add_argument("--pair", action="store_true", help="two kernels only: k_wino_fused<6,6> on a side stream beside the bf16x3 / fp32 GEMM (BITSWAP_HIP_LIB picks the build)")
     ap.add_argument("--record", action="store_true", help="forked bf16x3 codec with every stack kernel call kept; failing runs are replayed call by call")
     ap.add_argument("--focus", action="store_true", help="codec leg only: the failing scenario with and without counted waits, 14 runs each")
     ap.add_argument("--trail", type=int, default=0, help="runs of the checksum-trail leg (0: skip)")
@@ -685,6 +759,10 @@ if __name__ == "__main__":
     ap.add_argument("--small", action="store_true", help="micro leg with the neighbours that fit beside the unclaimed shape-2 kernel (<= 32 registers)")
     a = ap.parse_args()
     out = {}
+    if a.pair:
+        out["pair"] = pair_leg()
+        print(json.dumps(out, indent=1))
+        sys.exit(0)
     if a.record:
         out["record"] = record_leg(int(os.environ.get("REPRO_RECORD_REPS", "150")))
         print(json.dumps(out, indent=1))
