@@ -623,6 +623,9 @@ EXTRAS = (
     dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_GEMM_ARITH": "bf16x3"},
          why="OPT-IN conv arithmetic, not the headline: the ResNet products as three bf16 limbs per float32 operand, 6 limb products "
              "per k block on the bf16 matrix cores, float32 accumulate (bs_wino_gemm_bf16x3; error table: profiles/r04_bf16x3_error.json)"),
+    dict(workload="cifar8", chains=100, scaling="strong", env={"BITSWAP_GEMM_ARITH": "bf16x3"},
+         why="OPT-IN conv arithmetic at the reference's own shape (100 chains, forked two-stream step): where the faster GEMM shows "
+             "(DESIGN 3.4; the forked step with it is open again since the packed-addition cause was found and removed)"),
     dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_SERIAL_CUS": "32", "BITSWAP_GEMM_CUS": "224"}, tag="cumask32",
          why="EXPERIMENT, a loss (DESIGN 8): CU-masked streams -- the serial pop / push streams on 32 compute units (4 per XCD), the bulk "
              "streams on the other 224 (bs_stream_create_cu_mask); more masks and the bf16x3 pairing: profiles/r05b_cu_mask_ab.txt"),

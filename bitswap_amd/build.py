@@ -102,6 +102,29 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+PACKED_LIB = os.path.join(HERE, "csrc", "libbitswap_hip_slp.so")
+
+
+def build_packed_epilogue(verbose=False):
+    """DIAGNOSTICS ONLY: the product objects with ONE exception -- net_epilogue.hip compiled WITHOUT its per-file flag, i.e. with
+    hipcc's SLP vectorizer and its packed float32 additions -- linked as libbitswap_hip_slp.so.  This is the library that
+    reproduces the forked bf16x3 failure of round 5:
+        BITSWAP_HIP_LIB=bitswap_amd/csrc/libbitswap_hip_slp.so python tools/bf16x3_repro.py --record"""
+    build_hip()
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS
+    objdir = OBJ_DIR + "_" + _flag_hash()
+    src = os.path.join(HERE, "csrc", "net_epilogue.hip")
+    packed = os.path.join(objdir, "net_epilogue.packed.o")
+    cmd = [hipcc_path()] + cflags + ["-c", "-o", packed, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    objs = [packed if os.path.basename(s_) == "net_epilogue.hip" else os.path.join(objdir, os.path.basename(s_) + ".o") for s_ in SRCS]
+    subprocess.check_call([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PACKED_LIB] + objs)
+    return PACKED_LIB
+
+
 if __name__ == "__main__":
     import sys
-    print(build_asan(verbose=True) if "--asan" in sys.argv else build_hip(force=True, verbose=True))
+    print(build_asan(verbose=True) if "--asan" in sys.argv else build_packed_epilogue(verbose=True) if "--packed-epilogue" in sys.argv
+          else build_hip(force=True, verbose=True))
