@@ -47,11 +47,24 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: libbitswap_hip.so cannot be built (set HIPCC=...)")
 
 
+def _stamp():
+    return LIB + ".flags"
+
+
 def is_stale():
+    """Missing, older than a source, or built with another flag set (global, extra or per-file: the stamp written beside the
+    library at link time holds the flag hash -- round 5's -fno-slp-vectorize is a correctness flag, not a tuning one)."""
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SRCS + [HDR, DEV_HDR] if os.path.exists(p))
+    if any(os.path.getmtime(p) > t for p in SRCS + [HDR, DEV_HDR] if os.path.exists(p)):
+        return True
+    if os.environ.get("BITSWAP_HIP_LIB"):       # a library named by hand (diagnostics) is taken as it is
+        return False
+    try:
+        return open(_stamp()).read().strip() != _flag_hash()
+    except OSError:
+        return True
 
 
 ASAN_LIB = os.path.join(HERE, "csrc", "libbitswap_hip_asan.so")
@@ -99,6 +112,9 @@ def build_hip(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if not os.environ.get("BITSWAP_HIP_LIB"):
+        with open(_stamp(), "w") as f:
+            f.write(_flag_hash() + "\n")
     return LIB
 
 
