@@ -738,3 +738,23 @@ def test_conv_epilogue_kernels_are_built_without_packed_float32_operations(tmp_p
     assert r.returncode == 0, r.stderr[-1500:]
     packed = [l.strip() for l in open(out) if l.strip().startswith(("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"))]
     assert not packed, packed[:5]
+
+
+def test_library_built_with_other_flags_counts_as_stale(monkeypatch, tmp_path):
+    """build.py keys the in-tree library by its flag set (global, BITSWAP_HIPCC_EXTRA and per-file flags -- round 5's
+    -fno-slp-vectorize on net_epilogue.hip is a correctness flag): the stamp beside the library must match, a library named by hand
+    (BITSWAP_HIP_LIB, diagnostics) is taken as it is."""
+    from bitswap_amd import build
+    lib = tmp_path / "libx.so"
+    lib.write_bytes(b"\0")
+    future = os.path.getmtime(build.DEV_HDR) + 10 ** 6
+    os.utime(lib, (future, future))                       # newer than every source
+    monkeypatch.setattr(build, "LIB", str(lib))
+    monkeypatch.delenv("BITSWAP_HIP_LIB", raising=False)
+    assert build.is_stale()                               # no stamp
+    (tmp_path / "libx.so.flags").write_text(build._flag_hash() + "\n")
+    assert not build.is_stale()
+    monkeypatch.setitem(build.FILE_FLAGS, "net_epilogue.hip", [])          # the per-file flag dropped: another hash
+    assert build.is_stale()
+    monkeypatch.setenv("BITSWAP_HIP_LIB", str(lib))
+    assert not build.is_stale()
