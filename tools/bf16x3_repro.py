@@ -729,6 +729,58 @@ def pair_leg(rounds=100, ring=160):
     return res
 
 
+STACKS_CODE = r"""
+import os, sys, json, torch
+sys.path.insert(0, "__ROOT__")
+from bitswap_amd import workload
+from bitswap_amd.codec import BitSwapCodec, deterministic_convs
+model, zend, zcen = workload.build("cifar8", "cuda", quantbits=10)
+codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=True)      # (puts the model into its coding configuration)
+B = 32
+torch.manual_seed(3)
+z = torch.randn(B, model.zdim_flat, device="cuda") * 1.5
+inf = [model.infer(i) for i in range(1, model.nz)]
+gen = [model.generate(i) for i in range(1, model.nz)]
+side = torch.cuda.Stream()
+def run(fns):
+    with torch.no_grad(), deterministic_convs():
+        return [tuple(t.contiguous() for t in f(z)) for f in fns]
+ref_i, ref_g = run(inf), run(gen)
+torch.cuda.synchronize()
+out = {"library": os.environ.get("BITSWAP_HIP_LIB", "product"), "gemm_arith": model.gemm_arith, "stack_pairs": 0, "differing_stacks": 0, "where": []}
+for rep in range(int(os.environ.get("REPRO_REPS", "1500"))):
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        a = run(inf)
+    g = run(gen)
+    torch.cuda.synchronize()
+    for name, got, want in (("infer", a, ref_i), ("generate", g, ref_g)):
+        for i, ((m1, s1), (m0, s0)) in enumerate(zip(got, want)):
+            out["stack_pairs"] += 1
+            if not (torch.equal(m1, m0) and torch.equal(s1, s0)):
+                out["differing_stacks"] += 1
+                bad = ((m1 != m0) | (s1 != s0)).reshape(B, -1).any(1).nonzero().flatten().tolist()
+                out["where"].append({"rep": rep, "stack": f"{name}({i + 1})", "stream": "side" if name == "infer" else "main", "chains": bad})
+out["where"] = out["where"][:12]
+print("RESULT " + json.dumps(out))
+"""
+
+
+def stacks_leg(reps=1500):
+    """Two conv stacks side by side and NOTHING else (no coder kernel, no table kernel): infer(1..7) of the cifar8 model on a side stream
+    while generate(1..7) runs on the main stream, 32 chains, bf16x3 and fp32 arithmetic, compared with the one-stream results."""
+    import subprocess
+    code = STACKS_CODE.replace("__ROOT__", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for arith in ("bf16x3", "fp32"):
+        env = dict(os.environ, BITSWAP_GEMM_ARITH=arith, BITSWAP_BF16X3_SHAPE="2", REPRO_REPS=str(reps))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        res[arith] = json.loads(line[-1][7:]) if line else {"error": (r.stderr or r.stdout)[-800:]}
+        print("stacks", arith, json.dumps(res[arith]), flush=True)
+    return res
+
+
 def trail_leg(reps=120):
     """Where does a failing forked run first leave the one-stream run?  Head of every chain after every stack operation and a
     per-chain checksum of every conv stack's input and output, compared with the one-stream run of the same codec."""
@@ -751,6 +803,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--codec", action="store_true")
+    ap.add_argument("--stacks", action="store_true", help="two conv stacks side by side and nothing else (BITSWAP_HIP_LIB picks the build)")
     ap.add_argument("--pair", action="store_true", help="two kernels only: k_wino_fused<6,6> on a side stream beside the bf16x3 / fp32 GEMM (BITSWAP_HIP_LIB picks the build)")
     ap.add_argument("--record", action="store_true", help="forked bf16x3 codec with every stack kernel call kept; failing runs are replayed call by call")
     ap.add_argument("--focus", action="store_true", help="codec leg only: the failing scenario with and without counted waits, 14 runs each")
@@ -759,6 +812,10 @@ if __name__ == "__main__":
     ap.add_argument("--small", action="store_true", help="micro leg with the neighbours that fit beside the unclaimed shape-2 kernel (<= 32 registers)")
     a = ap.parse_args()
     out = {}
+    if a.stacks:
+        out["stacks"] = stacks_leg()
+        print(json.dumps(out, indent=1))
+        sys.exit(0)
     if a.pair:
         out["pair"] = pair_leg()
         print(json.dumps(out, indent=1))
