@@ -758,3 +758,24 @@ def test_library_built_with_other_flags_counts_as_stale(monkeypatch, tmp_path):
     assert build.is_stale()
     monkeypatch.setenv("BITSWAP_HIP_LIB", str(lib))
     assert not build.is_stale()
+
+
+def test_shipped_library_holds_no_packed_float32_arithmetic(tmp_path):
+    """The same property on what actually ships: every gfx950 code object inside the built libbitswap_hip.so (one per translation
+    unit), disassembled -- no v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 anywhere (a packed addition beside bf16 MFMA
+    wavefronts was the one wrong result of round 5; only net_epilogue.hip ever had any, and only it carries the flag)."""
+    import importlib.util
+    import re
+    from bitswap_amd import build
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = build.build_hip()
+    spec = importlib.util.spec_from_file_location("isa_count", os.path.join(ROOT, "tools", "isa_count.py"))
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    objs = ic.code_objects(lib)
+    assert len(objs) == len(build.SRCS), [i for i, _ in objs]
+    for k, (ident, blob) in enumerate(objs):
+        text = ic.disassemble(blob, str(tmp_path), f"co{k}.o")
+        assert text.count("\n") > 500, (k, ident)                      # it did disassemble something
+        packed = re.findall(r"\bv_pk_(?:add|mul|fma)_f32[^\n]*", text)
+        assert not packed, (k, packed[:3])

@@ -93,6 +93,38 @@ def async_load_hazards(lines, name):
     return nloads, hazards
 
 
+def code_objects(path, arch="gfx950"):
+    """The device code objects inside a built library or object file: clang offload bundles (magic, count, then per entry offset /
+    size / id) -> [(id, bytes)] of the entries for `arch`."""
+    import struct
+    data = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            return out
+        n, = struct.unpack_from("<Q", data, i + 24)
+        p = i + 32
+        for _ in range(n):
+            off, size, idlen = struct.unpack_from("<QQQ", data, p)
+            p += 24
+            ident = data[p:p + idlen].decode()
+            p += idlen
+            if arch in ident and size:
+                out.append((ident, data[i + off:i + off + size]))
+        pos = i + 24
+
+
+def disassemble(blob, tmpdir, name="co.o", objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    import os
+    import subprocess
+    path = os.path.join(tmpdir, name)
+    with open(path, "wb") as f:
+        f.write(blob)
+    return subprocess.run([objdump, "-d", path], capture_output=True, text=True, check=True).stdout
+
+
 def main():
     import re
     if sys.argv[1] == "--async-loads":
