@@ -310,13 +310,13 @@ __global__ __launch_bounds__(64) void k_rans_pop_wave(uint64_t* __restrict__ hea
 // ONE reciprocal of the root and one multiplication per level back down) -- the truncated
 // differences of bins 1 .. NPL-1 are therefore the table's; the frequency of the group's FIRST bin, whose pmf is differenced
 // against the last cdf of the group below, is what the integers leave: pivot[L+1] - pivot[L] - sum of the others (the remnant
-// bump included), so the group below is never evaluated.  A scan on top of the pivot gives c_s and f_s.  About 2.5x the
-// instructions of k_rans_pop_wave per symbol, but 512 B of HBM traffic per row instead of 4352 B: at 400 chains the
+// bump included), so the group below is never evaluated.  A scan on top of the pivot gives c_s and f_s.  About five times the
+// instructions of k_rans_pop_wave per symbol (205 against 38), but 512 B of HBM traffic per row instead of 4352 B: at 400 chains the
 // row-reading pop kernel ran at the HBM roof (3.57 GB per launch in 0.57 ms) and nothing overlapped with it
 // (profiles/r03m_overlap2.txt); this one touches the L2-resident endpoint table and little else.
 // Endpoints of the group are fetched AFTER the group is known (data dependent) and consumed after the two exponentials
 // that do not need them; pivots and the 64 anchor endpoints of a row are prefetched PF rows ahead like the rows of
-// k_rans_pop_wave; (mu, scale, bin width) wait in registers per 64-symbol chunk.
+// k_rans_pop_wave; (mu, 1 / scale, bin width, their product) of a 64-symbol chunk wait in LDS, one broadcast read per symbol.
 // ------------------------------------------------------------------------------------------
 // lane i <- lane i-1 of the whole wavefront (DPP wave_shr:1; lane 0 has no source: its result is not used)
 __device__ __forceinline__ double wave_shr1_f64(double v) {
