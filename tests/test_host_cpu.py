@@ -779,3 +779,17 @@ def test_shipped_library_holds_no_packed_float32_arithmetic(tmp_path):
         assert text.count("\n") > 500, (k, ident)                      # it did disassemble something
         packed = re.findall(r"\bv_pk_(?:add|mul|fma)_f32[^\n]*", text)
         assert not packed, (k, packed[:3])
+
+
+def test_repro_tool_embedded_programs_parse():
+    """tools/bf16x3_repro.py carries the programs of its legs as strings run in child processes on the GPU box; a syntax slip in one
+    would only show there."""
+    import ast
+    import re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(ROOT, "tools", "bf16x3_repro.py")).read()
+    ast.parse(src)
+    names = re.findall(r'^([A-Z_]+_CODE) = r"""', src, re.M)
+    assert {"TRAIL_CODE", "RECORD_CODE", "STACKS_CODE"} <= set(names), names
+    for n in names:
+        ast.parse(re.search(n + r' = r"""(.*?)"""', src, re.S).group(1))
