@@ -729,6 +729,58 @@ def pair_leg(rounds=100, ring=160):
     return res
 
 
+def trio_leg(rounds=60, ring=160):
+    """Three kernels: k_wino_fused<6,6> on one stream, the 32-chain GEMM (bf16x3 / fp32) on a second, a float64 table kernel
+    (k_logistic<16>, the (f, c) flavour at 32 chains) on a third.  Packed float32 instructions execute on the float64 datapath of
+    a SIMD: is the table kernel the missing partner?"""
+    dev = "cuda"
+    torch.manual_seed(0)
+    T, C, cols, N = 36, 256, 512, 32
+    U, Vg = torch.randn(T, C, C, device=dev), torch.randn(T, C, cols, device=dev)
+    Uf = hip.frags_bf16x3(U)
+    M = torch.randn(T, C, cols, device=dev) * 2.0
+    bias = torch.randn(C, device=dev)
+    shape = (N, C, 16, 16)
+    rng = np.random.RandomState(0)
+    Dz, Kz = 2048, 1024
+    lo, hi = rng.uniform(-8, -2, Dz), rng.uniform(2, 8, Dz)
+    ez_np = np.stack([np.linspace(a, b, Kz + 1)[1:-1] for a, b in zip(lo, hi)])
+    ez, stepz = torch.from_numpy(ez_np).to(dev), torch.from_numpy(uniform_step(ez_np)).to(dev)
+    muz = torch.from_numpy(rng.randn(N, Dz).astype(np.float32)).to(dev)
+    scz = torch.from_numpy(rng.uniform(0.1, 1, (N, Dz)).astype(np.float32)).to(dev)
+    symz = torch.from_numpy(rng.randint(0, Kz, (N, Dz)).astype(np.int32)).to(dev)
+    stz = torch.zeros(N, dtype=torch.int32, device=dev)
+    tables = lambda: hip.logistic_fc(ez, muz, scz, symz, stz, 31, 10, step=stepz)
+    ref = hip.wino_fused(M, shape, 6, bias, None, True, ts_out=6)[2].clone()
+    s_fused, s_tab = torch.cuda.Stream(), torch.cuda.Stream()
+    res = {"library": os.environ.get("BITSWAP_HIP_LIB", "product")}
+    for name, gemm in (("fused + bf16x3 gemm + f64 tables", lambda: hip.wino_gemm_bf16x3(Uf, Vg, 6)), ("fused + fp32 gemm + f64 tables", lambda: hip.wino_gemm(U, Vg)),
+                       ("fused + f64 tables", None), ("fused + bf16x3 gemm + f64 tables (again)", lambda: hip.wino_gemm_bf16x3(Uf, Vg, 6))):
+        calls = differing = 0
+        where = []
+        for _ in range(rounds):
+            outs = []
+            torch.cuda.synchronize()
+            for i in range(ring):
+                with torch.cuda.stream(s_fused):
+                    outs.append(hip.wino_fused(M, shape, 6, bias, None, True, ts_out=6)[2])
+                if gemm is not None:
+                    gemm()
+                if i % 4 == 0:
+                    with torch.cuda.stream(s_tab):
+                        tables()
+            torch.cuda.synchronize()
+            for o in outs:
+                calls += 1
+                if not torch.equal(o, ref):
+                    differing += 1
+                    idx = (o != ref).nonzero()
+                    where.append({"values": int(idx.shape[0]), "channels": idx[:, 1].unique().tolist()[:4], "chains": (idx[:, 2] // 16).unique().tolist()[:4]})
+        res[name] = {"fused_calls": calls, "differing": differing, "where": where[:6]}
+        print("trio", res["library"][-24:], name, res[name], flush=True)
+    return res
+
+
 STACKS_CODE = r"""
 import os, sys, json, torch
 sys.path.insert(0, "__ROOT__")
@@ -803,6 +855,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--codec", action="store_true")
+    ap.add_argument("--trio", action="store_true", help="three kernels: packed k_wino_fused<6,6> + GEMM + a float64 table kernel on three streams")
     ap.add_argument("--stacks", action="store_true", help="two conv stacks side by side and nothing else (BITSWAP_HIP_LIB picks the build)")
     ap.add_argument("--pair", action="store_true", help="two kernels only: k_wino_fused<6,6> on a side stream beside the bf16x3 / fp32 GEMM (BITSWAP_HIP_LIB picks the build)")
     ap.add_argument("--record", action="store_true", help="forked bf16x3 codec with every stack kernel call kept; failing runs are replayed call by call")
@@ -812,6 +865,10 @@ if __name__ == "__main__":
     ap.add_argument("--small", action="store_true", help="micro leg with the neighbours that fit beside the unclaimed shape-2 kernel (<= 32 registers)")
     a = ap.parse_args()
     out = {}
+    if a.trio:
+        out["trio"] = trio_leg()
+        print(json.dumps(out, indent=1))
+        sys.exit(0)
     if a.stacks:
         out["stacks"] = stacks_leg()
         print(json.dumps(out, indent=1))
