@@ -78,6 +78,13 @@ def parse():
     ap.add_argument("--bitswap", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline workload only (no imagenet4 / 100-chain sub-results)")
+    ap.add_argument("--extra", default="core", choices=["core", "all", "none"],
+                    help="sub-results measured in child processes at N = 1: core (default) = the six shapes the record needs "
+                         "(north_star's ImageNet32 shape at 1000 and at 100 chains, configs[1] at 100 / 50 / 25 / 13 chains: the "
+                         "predicted strong-scaling curve); all = every shape DESIGN.md quotes (twenty children, ~2 more minutes)")
+    ap.add_argument("--full-record", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where the FULL record goes (every sub-result, every roofline annotation); stdout carries only the "
+                         "compact headline line, < 6 KB (the driver keeps 8 KB of stdout)")
     ap.add_argument("--cpu-blocks", type=int, default=20, help="blocks per chain in the CPU baseline sample")
     ap.add_argument("--no-timeline", action="store_true", help="skip per-kernel events (roofline becomes null)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the exclusive roofline passes after the timed region")
@@ -573,7 +580,7 @@ def extra_in_child(args, spec, steps, warmup):
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", spec["workload"], "--groups", str(spec.get("groups", 0)),
            "--format", spec.get("format", "reference"), "--steps", str(spec.get("steps", steps)), "--warmup", str(warmup),
            "--quantbits", str(args.quantbits), "--bitswap", str(spec.get("bitswap", args.bitswap)), "--cdf-spec", str(args.cdf_spec),
-           "--no-extra", "--no-cpu-baseline", "--no-roofline"]
+           "--no-extra", "--no-cpu-baseline", "--no-roofline", "--full-record", os.devnull]
     if spec.get("scaling") == "strong":
         cmd += ["--scaling", "strong", "--total-chains", str(spec["chains"])]
     else:
@@ -602,19 +609,19 @@ def extra_in_child(args, spec, steps, warmup):
 
 # driver-visible numbers for the other shapes DESIGN.md quotes, each measured like the headline in a process of its own
 EXTRAS = (
-    dict(workload="imagenet4", chains=1000, groups=2, why="north_star's target shape (configs[2]) at the headline's batch"),
-    dict(workload="cifar8", chains=100, scaling="strong", why="configs[1] at the reference's own shape: 100 experiments in total"),
-    dict(workload="imagenet4", chains=100, scaling="strong", why="configs[2]: 100 experiments x 32x32 blocks"),
+    dict(workload="imagenet4", chains=1000, groups=2, core=True, why="north_star's target shape (configs[2]) at the headline's batch"),
+    dict(workload="cifar8", chains=100, scaling="strong", core=True, why="configs[1] at the reference's own shape: 100 experiments in total"),
+    dict(workload="imagenet4", chains=100, scaling="strong", core=True, why="configs[2]: 100 experiments x 32x32 blocks"),
     dict(workload="imagenet4", chains=100, scaling="strong", bitswap=0, why="configs[4] (BB-ANS) at N = 1"),
     dict(workload="imagenetcrop4", chains=100, scaling="strong", steps=16,
          why="configs[3] at N = 1: 100 ragged image chains (a 512 x 512 image = 16 blocks here), crop model on nn_batch 32"),
-    dict(workload="cifar8", chains=13, groups=1, why="one GPU's share of 100 chains on 8 GPUs"),
+    dict(workload="cifar8", chains=13, groups=1, core=True, why="one GPU's share of 100 chains on 8 GPUs"),
     dict(workload="imagenet4", chains=13, groups=1, bitswap=0, why="configs[4]: one GPU's share (13 of 100 chains) on 8 GPUs"),
     dict(workload="imagenetcrop4", chains=13, scaling="strong", steps=16, why="configs[3]: one GPU's share (13 of 100 images) on 8 GPUs"),
     # the 2- and 4-GPU shares of the same 100 chains: with the 100- and 13-chain lines they give the predicted
     # 1 / 2 / 4 / 8-GPU strong-scaling curve of configs[1], [3], [4] (predicted_scaling below)
-    dict(workload="cifar8", chains=50, groups=1, share_of=2, why="one GPU's share of 100 chains on 2 GPUs"),
-    dict(workload="cifar8", chains=25, groups=1, share_of=4, why="one GPU's share of 100 chains on 4 GPUs"),
+    dict(workload="cifar8", chains=50, groups=1, share_of=2, core=True, why="one GPU's share of 100 chains on 2 GPUs"),
+    dict(workload="cifar8", chains=25, groups=1, share_of=4, core=True, why="one GPU's share of 100 chains on 4 GPUs"),
     dict(workload="imagenet4", chains=50, groups=1, bitswap=0, share_of=2, why="configs[4]: one GPU's share on 2 GPUs"),
     dict(workload="imagenet4", chains=25, groups=1, bitswap=0, share_of=4, why="configs[4]: one GPU's share on 4 GPUs"),
     dict(workload="imagenetcrop4", chains=50, scaling="strong", steps=16, share_of=2, why="configs[3]: one GPU's share (50 of 100 images) on 2 GPUs"),
@@ -699,7 +706,8 @@ def main(args):
     del codec, model
 
     extra = None
-    if world == 1 and not args.no_extra and not strong and name == "cifar8" and args.format == "reference":
+    if (world == 1 and not args.no_extra and args.extra != "none" and not strong and name == "cifar8"
+            and args.format == "reference"):
         extra = []
         ks, ws = min(args.steps, 6), max(min(args.warmup, 1), 2)
         import gc
@@ -707,6 +715,8 @@ def main(args):
         torch.cuda.empty_cache()
         torch.cuda.synchronize()
         for spec in EXTRAS:
+            if args.extra == "core" and not spec.get("core"):
+                continue
             try:
                 extra.append(extra_in_child(args, spec, ks, ws))
             except Exception as ex:   # a sub-result never costs the headline
@@ -767,12 +777,6 @@ def main(args):
         "lossless": r["lossless"], "bits_per_dim": round(r["bits_per_dim"], 4),
         "stream_time_fraction": r["stream_time_fraction"],
         "roofline": r["roofline"], "cpu_baseline": cpu, "stream_gather": r["stream_gather"], "extra": extra,
-        # last on the line so that a reader of the line's tail sees them: the shapes and the curve again, compact
-        "summary": {"headline_Mpixel_per_s": round(r["value"] / 1e6, 3), "ms_per_step": round(r["ms_per_step"], 3),
-                    "lossless": r["lossless"], "path_frac": (r["roofline"] or {}).get("frac"),
-                    "valu_issue_frac": (r["roofline"] or {}).get("valu_issue_frac"),
-                    "measured_shapes": shapes, "predicted_scaling": {k: v.get("Mpixel_per_s") for k, v in (predicted or {}).items()
-                                                                     if isinstance(v, dict)} or None},
     }
     if strong:
         out["config"].update({"total_chains": args.total_chains, "chains_per_rank": [len(p[0]) for p in plan],
@@ -780,9 +784,88 @@ def main(args):
         for k in ("blocks_total", "nn_batch"):
             if k in r:
                 out["config"][k] = r[k]
-    print(json.dumps(out))
+    # the FULL record (every sub-result and annotation) goes to a file; stdout's LAST line is the compact headline: the
+    # driver keeps 8 KB of stdout, and round 5's 26 KB line reached it cut in two (BENCH_r05.json: parsed null)
+    try:
+        if args.full_record != os.devnull:
+            os.makedirs(os.path.dirname(args.full_record), exist_ok=True)
+        with open(args.full_record, "w") as f:
+            json.dump(out, f)
+    except OSError as e:
+        print(f"bench.py: full record not written: {e!r}", file=sys.stderr)
+    print(headline_line(out, args.full_record), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+HEADLINE_MAX_BYTES = 6144
+BENCH_SCHEMA = 6   # 6: compact stdout line + full record on file; roofline.frac = whole path as in schema 5,
+#                       the dominant kernel's own figures under roofline.kernel (rounds 1-4: roofline.frac = kernel VALU issue)
+
+
+def headline(out, full_path=None):
+    """The compact line the driver parses: the contract's keys, ONE copy of the measured shapes and the predicted curve, the
+    whole-path roofline with the dominant hot-path kernel's and the GEMM's own figures beside it, the CPU baseline.  Everything
+    else (twenty-odd annotations per object) stays in the full record."""
+    def pick(d, keys):
+        return None if not isinstance(d, dict) else {k: d[k] for k in keys if k in d}
+    cfg = out["config"]
+    roof = out.get("roofline")
+    hroof = None
+    if roof:
+        hb = roof.get("hbm") or {}
+        mf = roof.get("mfma") or {}
+        hroof = {"bound": roof["bound"], "achieved": roof["achieved"], "peak": roof["peak"], "unit": roof["unit"],
+                 "frac": roof["frac"], "traffic": roof.get("traffic"),
+                 "what": "frac = whole path, SURVEY 8(d): 2 x A_block x blocks / (t_sender + t_receiver) / 8 TB/s; kernel.* = the "
+                         "dominant hot-path kernel, exclusive HIP-event launch time; traffic = its PMC bytes per launch",
+                 "alg_bytes_per_block": roof.get("path_alg_bytes_per_block"),
+                 "kernel": {"name": str(roof.get("kernel", "")).split(" (")[0], "rows_per_launch": roof.get("rows_per_launch"),
+                            "avg_launch_ms": roof.get("avg_launch_ms"), "avg_launch_ms_in_pipeline": roof.get("avg_launch_ms_in_pipeline"),
+                            "bound": roof.get("kernel_bound"), "valu_issue_frac": roof.get("valu_issue_frac"),
+                            "slots_per_row": roof.get("slots_per_row"),
+                            "valu_busy_pmc": (roof.get("valu_busy_pmc") or {}).get("valu_busy"),
+                            "hbm_survey_frac": roof.get("hbm_survey_frac"), "hbm_alg_frac": hb.get("frac"),
+                            "hbm_traffic_frac": hb.get("traffic_frac"), "fp64_frac": (roof.get("fp64") or {}).get("frac")},
+                 "mfma": pick(mf, ("kernel", "shape", "achieved", "peak", "unit", "frac", "avg_launch_ms", "error"))}
+        if hroof["mfma"] and "kernel" in hroof["mfma"]:
+            hroof["mfma"]["kernel"] = hroof["mfma"]["kernel"].split(" (")[0]
+    cpu = out.get("cpu_baseline")
+    hcpu = None
+    if cpu:
+        hcpu = pick(cpu, ("value", "unit", "cores", "kind", "same_host", "sample"))
+        if hcpu.get("value") is not None:
+            hcpu["value"] = round(hcpu["value"], 1)
+        rp = cpu.get("reference_python")
+        hcpu["reference_python"] = pick(rp, ("value", "unit", "cores", "same_host", "tool"))
+    ps = cfg.get("predicted_scaling") or {}
+    h = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data")}
+    h["config"] = {k: cfg[k] for k in ("workload", "chains_per_gpu", "chain_groups", "blocks_per_chain", "quantbits", "ansbits",
+                                       "cdf_spec", "stream_format", "conv_dtype", "forked_block_step", "total_chains",
+                                       "chains_per_rank", "blocks_per_rank", "blocks_total", "nn_batch") if k in cfg}
+    h["config"]["weights"] = "seeded random init" + (", low-rate calibrated" if "low-rate" in str(cfg.get("weights")) else "")
+    h.update({"lossless": out["lossless"], "bits_per_dim": out["bits_per_dim"], "rccl_ranks": out["rccl_ranks"],
+              "roofline": hroof, "cpu_baseline": hcpu,
+              "stream_gather": pick(out.get("stream_gather"), ("chains", "bytes", "ms", "complete", "crc32_of_streams_in_chain_order", "error")),
+              # label -> [Mpixel/s enc+dec, ms per step, lossless], each the first workload of a process of its own
+              "measured_shapes": cfg.get("measured_shapes"),
+              "predicted_scaling": {k: v.get("Mpixel_per_s") for k, v in ps.items() if isinstance(v, dict)} or None,
+              "schema": BENCH_SCHEMA, "full_record": None if full_path is None else os.path.relpath(full_path, ROOT)})
+    return h
+
+
+def headline_line(out, full_path=None):
+    """headline() as ONE line below HEADLINE_MAX_BYTES: optional objects are dropped, longest first, before the contract's keys
+    would be cut (never needed with the shapes bench.py measures today; a guard, not a code path)."""
+    h = headline(out, full_path)
+    for drop in (None, "measured_shapes", "predicted_scaling", "stream_gather"):
+        if drop:
+            h[drop] = None
+        line = json.dumps(h, separators=(",", ":"))
+        if len(line) < HEADLINE_MAX_BYTES:
+            return line
+    raise RuntimeError(f"bench headline is {len(line)} bytes")
 
 
 def _spawned(rank, args, world, port):
