@@ -487,6 +487,44 @@ def test_divergence_horizon_on_the_gpu(golden, sched, spec):
         assert len(got[0]) == len(ref) and sum(x != y for x, y in zip(got[0], ref)) == want_ndiff
 
 
+@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
+@pytest.mark.parametrize("spec", [1, 2, 3])
+def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched, spec):
+    """bits/dim <= 1e-4 pinned on BASELINE configs[0] at full width, 100 blocks, per CDF spec.  The ideal code
+    length of the reference's own 500 operations' symbols (tests/golden/chain_mnist_full_*.npz, written by the reference's
+    sender: mnist_compress.py:176-251) under the frequencies the HIP table kernel builds from the teacher-forced (mu, scale)
+    against the same under the reference's torch.sigmoid tables -- per operation and in total -- and the total against the
+    fixture's `nets` (mnist_compress.py:253-261).  The frequencies must also be the oracle's, symbol for symbol."""
+    from bitswap_amd.bins import uniform_step
+    from test_oracle import check_rate_against_reference, ideal_bits_of_full_chain, torch_table_bits
+    h = hip()
+    g = golden(f"chain_mnist_full_{sched}.npz")
+    zend, xend, _ = chain_tables(g)
+    zend_d = [dev(z) for z in zend]
+    xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)
+    steps_np = {tab: (uniform_step(e) if (spec >= 2 and e.shape[1] + 1 >= 256) else None)
+                for tab, e in list(enumerate(zend)) + [(-1, xend)]}
+    steps = {tab: None if v is None else dev(v) for tab, v in steps_np.items()}
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nchecked = [0]
+
+    def freqs(tab, q, mu, sc, sym):
+        e = xend_d if tab < 0 else zend_d[tab]
+        sp = None if steps[tab] is None else spec
+        f, _ = h.logistic_fc(e, dev(mu[None]), dev(sc[None]), dev(sym[None]), status, 31, q, step=steps[tab], spec=sp)
+        f = f.cpu().numpy().view(np.uint32)[0]
+        if nchecked[0] < 40:                                 # HIP == oracle on the first blocks' operations (the rest: horizon test)
+            mode = {2: O.MODE_DET2, 3: O.MODE_DET3}[spec] if steps_np[tab] is not None else O.MODE_DET
+            e_np = np.ascontiguousarray(xend if tab < 0 else zend[tab])
+            fo, _, rc = O.tables(O.logistic_pmf(e_np, mu.astype(np.float64), sc.astype(np.float64), mode, steps_np[tab]), 31, q)
+            assert rc == O.OK and np.array_equal(f, fo[np.arange(len(sym)), sym])
+            nchecked[0] += 1
+        return f
+    got = ideal_bits_of_full_chain(g, freqs)
+    assert int(status.item()) == 0
+    check_rate_against_reference(g, got, torch_table_bits(g), f"HIP spec {spec} {sched}")
+
+
 @pytest.mark.parametrize("layout", ["linear", "wave"])
 @pytest.mark.parametrize("spec", [1, 2, 3])
 def test_full_size_round_trip_property(layout, spec):
