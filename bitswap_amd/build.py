@@ -24,7 +24,10 @@ EXTRA_FLAGS = [f for f in os.environ.get("BITSWAP_HIPCC_EXTRA", "").split() if f
 # instructions, 72 registers; without: 1,417 instructions, 66 registers, the same IEEE operations on the same values).  Beside
 # the bf16 MFMA wavefronts of the bf16x3 GEMM one such packed addition lost its result in lanes 48..63 about once in 10^5
 # workgroups (round 5, visits v-z: DESIGN 3.4); the packed form is slower beside MFMAs anyway.
-FILE_FLAGS = {"net_epilogue.hip": ["-fno-slp-vectorize"]}
+# The -D is the source-level half of the guard: net_epilogue.hip refuses to compile (#error) unless the build says it turned the
+# vectorizer off, so another build system cannot silently produce the packed code; tests/test_host_cpu.py
+# disassembles the shipped library for packed float32 arithmetic on top of that.
+FILE_FLAGS = {"net_epilogue.hip": ["-fno-slp-vectorize", "-DBS_BUILT_WITHOUT_SLP_VECTORIZER"]}
 
 
 def _flag_hash():
@@ -47,6 +50,9 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: libbitswap_hip.so cannot be built (set HIPCC=...)")
 
 
+_warned_by_hand = False
+
+
 def _stamp():
     return LIB + ".flags"
 
@@ -59,7 +65,13 @@ def is_stale():
     t = os.path.getmtime(LIB)
     if any(os.path.getmtime(p) > t for p in SRCS + [HDR, DEV_HDR] if os.path.exists(p)):
         return True
-    if os.environ.get("BITSWAP_HIP_LIB"):       # a library named by hand (diagnostics) is taken as it is
+    if os.environ.get("BITSWAP_HIP_LIB"):       # a library named by hand (diagnostics) is taken as it is -- and says so once
+        global _warned_by_hand
+        if not _warned_by_hand:
+            import sys
+            print(f"bitswap_amd: BITSWAP_HIP_LIB={LIB}: a library named by hand, its build flags are NOT checked "
+                  "(the product build needs -fno-slp-vectorize for net_epilogue.hip, DESIGN 3.4)", file=sys.stderr)
+            _warned_by_hand = True
         return False
     try:
         return open(_stamp()).read().strip() != _flag_hash()
@@ -78,7 +90,7 @@ def build_asan(verbose=False):
     only establishes that the sources build instrumented; drive it from a plain HIP program (examples/c_abi_roundtrip.cpp),
     not from torch."""
     flags = [f if not f.startswith("--offload-arch") else "--offload-arch=gfx950:xnack+" for f in HIPCC_FLAGS]
-    flags = [f for f in flags if f != "-O3"] + ["-O1", "-g", "-fsanitize=address", "-shared-libsan"]
+    flags = [f for f in flags if f != "-O3"] + ["-O1", "-g", "-fsanitize=address", "-shared-libsan"] + FILE_FLAGS["net_epilogue.hip"]
     cmd = [hipcc_path()] + flags + ["-o", ASAN_LIB] + SRCS
     if verbose:
         print(" ".join(cmd))
@@ -118,20 +130,22 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
-PACKED_LIB = os.path.join(HERE, "csrc", "libbitswap_hip_slp.so")
+# (outside csrc/: a known-bad library does not sit beside the product's)
+PACKED_LIB = os.path.join(HERE, "..", "tools", "probes", "_build", "libbitswap_hip_slp.so")
 
 
 def build_packed_epilogue(verbose=False):
     """DIAGNOSTICS ONLY: the product objects with ONE exception -- net_epilogue.hip compiled WITHOUT its per-file flag, i.e. with
     hipcc's SLP vectorizer and its packed float32 additions -- linked as libbitswap_hip_slp.so.  This is the library that
     reproduces the forked bf16x3 failure of round 5:
-        BITSWAP_HIP_LIB=bitswap_amd/csrc/libbitswap_hip_slp.so python tools/bf16x3_repro.py --record"""
+        BITSWAP_HIP_LIB=tools/probes/_build/libbitswap_hip_slp.so python tools/bf16x3_repro.py --record"""
     build_hip()
     cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + EXTRA_FLAGS
     objdir = OBJ_DIR + "_" + _flag_hash()
     src = os.path.join(HERE, "csrc", "net_epilogue.hip")
     packed = os.path.join(objdir, "net_epilogue.packed.o")
-    cmd = [hipcc_path()] + cflags + ["-c", "-o", packed, src]
+    cmd = [hipcc_path()] + cflags + ["-DBS_PACKED_EPILOGUE_DIAGNOSTIC", "-c", "-o", packed, src]
+    os.makedirs(os.path.dirname(PACKED_LIB), exist_ok=True)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

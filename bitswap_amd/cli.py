@@ -38,14 +38,22 @@ def seed_everything():
     # cudnn.deterministic / benchmark (:98-99) are scoped to the codec's conv stacks: codec.deterministic_convs()
 
 
-def experiment_draws(ntest, experiments, ndatapoints, nwords=10000):
-    """(randindices, initial states) of a dataset script run: the reference's numpy draw order when its own sequence can
-    serve the shape (codec.reference_draws), else sampling with replacement + codec.initial_states()."""
-    if ntest >= experiments * ndatapoints:
-        return reference_draws(ntest, experiments, ndatapoints, nwords, seed=100)
+def experiment_draws(ntest, experiments, ndatapoints, nwords=10000, convention=None):
+    """(randindices, initial states, convention) of a dataset script run.  convention "reference_order": the reference's numpy
+    draw order (codec.reference_draws: seed, choice(replace=False), then the words experiment by experiment -- the words depend
+    on `ntest`, the permutation consumes the generator); "seed_then_words": sampling with replacement + codec.initial_states()
+    -- the fallback for shapes the reference's own sequence cannot serve (fewer test images than experiments x ndatapoints)
+    and what every stream written before round 5 used.  convention=None picks by shape; a receiver passes the one recorded in
+    stream_meta.json ("init_draws")."""
+    if convention is None:
+        convention = "reference_order" if ntest >= experiments * ndatapoints else "seed_then_words"
+    if convention == "reference_order":
+        return reference_draws(ntest, experiments, ndatapoints, nwords, seed=100) + (convention,)
+    if convention != "seed_then_words":
+        raise meta.StreamMismatch(f"unknown initial-word convention {convention!r} in stream_meta.json")
     np.random.seed(100)
-    randindices = np.random.choice(ntest, size=(experiments, ndatapoints), replace=True)
-    return randindices, initial_states(experiments, nwords, seed=100)
+    randindices = np.random.choice(ntest, size=(experiments, ndatapoints), replace=ntest < experiments * ndatapoints)
+    return randindices, initial_states(experiments, nwords, seed=100), convention
 
 
 def load_images(dataset, path, synthetic, xs, n):
@@ -126,7 +134,7 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
     # but the draw still happens.  Fewer images than experiments x ndatapoints (small synthetic sets): the reference's
     # choice(replace=False) would raise; documented fallback = sampling with replacement + initial_states().
     idx_path = os.path.join(outdir, "bitstreams", dataset, "indices.npy")
-    randindices, inits = experiment_draws(len(images), experiments, ndatapoints)
+    randindices, inits, draws = experiment_draws(len(images), experiments, ndatapoints)
     have = os.path.exists(idx_path)
     if world > 1:
         dist.barrier()       # every rank has looked before rank 0 may write
@@ -167,8 +175,12 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
         cpc = per_rank[0] if len(set(per_rank)) == 1 else per_rank
     fp = meta.fingerprint(codec, chains_per_call=cpc)
     if rank == 0:
+        # ... and what its end-condition checks need: how the initial words were drawn (they depend on the test-set size under
+        # the reference's order) and WHICH datapoints these streams hold -- next to the streams, because the reference's shared
+        # bitstreams/<ds>/indices.npy is rewritten by any later run of another shape in the same outdir
         meta.save(os.path.join(sdir, "stream_meta.json"), fp, world_size=world, experiments=experiments,
-                  ndatapoints=ndatapoints)
+                  ndatapoints=ndatapoints, init_draws=draws, ntest=int(len(images)))
+        np.save(os.path.join(sdir, "indices.npy"), randindices)
     if world > 1:
         dist.barrier()
 
@@ -248,16 +260,28 @@ def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=F
     states = [container.load_state(os.path.join(sdir, stream_name(scheme, quantbits, nz, c, wave64)))
               for c in range(experiments)]
     nwords = max((sum(len(x) for x in s) if wave64 else len(s)) for s in states)
-    _, inits = experiment_draws(len(images), experiments, ndatapoints)     # the sender's draw sequence
+    # the sender's draw sequence: recorded since round 6; streams of rounds 3-5 carry no record -- round 5's followed the
+    # reference's order whenever the shape allowed it, rounds 3-4 seeded and drew all words at once: try the first, accept
+    # the second (the end condition below tells which one it was)
+    recorded = written.get("init_draws")
+    if recorded is not None and "ntest" in written and int(written["ntest"]) != len(images):
+        raise meta.StreamMismatch(f"{sdir}/stream_meta.json: the streams were written against {written['ntest']} test images, this "
+                                  f"receiver has {len(images)} (initial words and datapoint indices depend on that number)")
+    _, inits, _ = experiment_draws(len(images), experiments, ndatapoints, convention=recorded)
+    alt_inits = None if recorded is not None else initial_states(experiments, 10000, seed=100)
     if wave64:
         from .hip import split_state
         inits = [split_state(s) for s in inits]
+        alt_inits = None if alt_inits is None else [split_state(s) for s in alt_inits]
     out = torch.zeros((experiments, ndatapoints, model.xdim), dtype=torch.int32)
     for sh in shards:
         state = codec.backend.new_state([states[c] for c in sh], nwords + ndatapoints * (model.xdim + 64) + 4 * model.zdim_flat)
         out[sh] = codec.decompress(state, ndatapoints).cpu().to(torch.int32)
-        assert state.to_lists() == [inits[c] for c in sh], "initial state not restored"   # (:358)
-    randindices = np.load(os.path.join(outdir, "bitstreams", dataset, "indices.npy"))
+        got = state.to_lists()
+        assert got == [inits[c] for c in sh] or (alt_inits is not None and got == [alt_inits[c] for c in sh]), \
+            "initial state not restored"                                                   # (:358)
+    own_idx = os.path.join(sdir, "indices.npy")             # the stream set's own copy (round 6); else the shared file
+    randindices = np.load(own_idx if os.path.exists(own_idx) else os.path.join(outdir, "bitstreams", dataset, "indices.npy"))
     want = images[torch.from_numpy(randindices.reshape(-1))].view(experiments, ndatapoints, -1).to(torch.int32)
     assert torch.equal(out, want), "decoded datapoint does not match"                     # (:319,354)
     if verbose:

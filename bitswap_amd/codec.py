@@ -436,7 +436,18 @@ class BitSwapCodec:
                 if t is not None and t.is_cuda:
                     t.record_stream(stream)
 
+    def _spec_guard(self, step):
+        """A backend object carries ONE CDF spec for its uniform-bin tables (tables / push_params / the 64-state launches read
+        it); the codec's own copy decides the (f, c) of the split push and the fingerprint.  They are set together in
+        __init__ -- but a second codec built on the same backend object with another spec moves the backend's: refuse to code
+        rather than write tables of one spec and (f, c) of another under a fingerprint that looks valid."""
+        if step is not None and getattr(self.backend, "cdf_spec", self.cdf_spec) != self.cdf_spec:
+            raise RuntimeError(f"this codec codes with CDF spec {self.cdf_spec} but its backend object was re-configured to spec "
+                               f"{self.backend.cdf_spec} (by another BitSwapCodec built on the same backend): give every codec "
+                               "of another spec a backend object of its own")
+
     def _pop_layer(self, state, endpoints, centres, mu, scale, quantbits, K, key, step=None):
+        self._spec_guard(step)
         ts = self._tables_stream((mu, scale))
         with self._on(ts), self.tl.span("tables_" + key):
             cdf = self.backend.tables(endpoints, mu, scale, quantbits, self.bits,
@@ -463,6 +474,7 @@ class BitSwapCodec:
             torch.minimum(ml, cur.to(ml.device), out=ml)
 
     def _push_layer(self, state, endpoints, mu, scale, sym, quantbits, key, step=None):
+        self._spec_guard(step)
         if self.serial is None or not isinstance(self.backend, HipBackend) or isinstance(self.backend, Hip64Backend):
             with self.tl.span("push_" + key):
                 self.backend.push_params(state, endpoints, mu, scale, sym, quantbits, self.bits, step=step)

@@ -8,6 +8,15 @@
 //
 // These kernels are deterministic and batch-invariant by construction (every output element depends
 // on its own inputs only), which is all the decoder needs.
+//
+// BUILD REQUIREMENT (correctness, not tuning): this file must be compiled with -fno-slp-vectorize.  Under plain -O3 hipcc packs the
+// transforms' scalar float32 additions into v_pk_add_f32; beside the bf16 MFMA wavefronts of bs_wino_gemm_bf16x3 one such packed
+// addition lost its result in lanes 48..63 about once in 10^5 workgroups (profiles/r05_packed_add_report.md).  The
+// build says so with -DBS_BUILT_WITHOUT_SLP_VECTORIZER (bitswap_amd/build.py::FILE_FLAGS); any other build system gets an error
+// here instead of a library that decodes one chain in 10^5 wrong.
+#if !defined(BS_BUILT_WITHOUT_SLP_VECTORIZER) && !defined(BS_PACKED_EPILOGUE_DIAGNOSTIC)
+#error "net_epilogue.hip: compile with -fno-slp-vectorize -DBS_BUILT_WITHOUT_SLP_VECTORIZER (see the comment above)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

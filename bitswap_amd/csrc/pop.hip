@@ -680,7 +680,10 @@ int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap
         D < 0 || cap < 0 || bits < 1 || bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || c_stride < 0 ||
         (centres && !centre_out) || ld < 128 || ld % 2 || (reinterpret_cast<uintptr_t>(pivots) & 7u))
         return BS_EINVAL;
-    if (D % 64 != 0 || D > 16384) return BS_EUNSUPPORTED;      // whole 64-symbol chunks; a chain's symbols fit in LDS
+    // whole 64-symbol chunks; a chain's symbols (D x 4 B, dynamic) + sh_prm (2 KB, static) fit the 64 KB a launch gets
+    // without hipFuncAttributeMaxDynamicSharedMemorySize
+    static_assert(BS_POP_PIVOT_MAX_D % 64 == 0 && BS_POP_PIVOT_MAX_D * 4 + 64 * 32 <= 64 * 1024, "pivot pop LDS budget");
+    if (D % 64 != 0 || D > BS_POP_PIVOT_MAX_D) return BS_EUNSUPPORTED;
     if (B == 0 || D == 0) return BS_OK;
     if (param_dtype == BS_PARAM_F32)
         return dispatch_pop_pivot<float>(cdf_spec, head, stack, len, cap, pivots, ld, endpoints, e_stride, bin_step, mu, scale, B, D, K,

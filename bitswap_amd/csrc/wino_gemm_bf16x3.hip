@@ -70,8 +70,9 @@ __global__ __launch_bounds__(X_NT, 1) void k_wino_gemm_bf16x3(const uint16_t* __
     // the claim changes the allocation and nothing else (identical instruction streams); the products are bit-stable with or
     // without it -- 600,000 launches beside the kernels that fit next to it, and every launch doubled inside failing codec runs --
     // and the FORKED block step with the two-workgroup shape fails with the claim too (2.3 % of runs against 5-7 % without).
-    // The claim stays because it costs nothing (occupancy is one by design) and makes the failure rarer; the fix is in the codec,
-    // which does not fork the step with this arithmetic.
+    // The cause was not in this kernel at all: a packed float32 addition in its NEIGHBOUR k_wino_fused<6,6>; the fix
+    // is net_epilogue.hip's -fno-slp-vectorize build flag (bitswap_amd/build.py::FILE_FLAGS).  The claim is a template switch
+    // (CLAIM) kept for the A/B of round 6: claimed, nothing else fits on the SIMD; unclaimed, a coder wavefront does.
     if constexpr (CLAIM) asm volatile("" ::: "v255");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, g = lane >> 5;

@@ -157,11 +157,12 @@ def wave_supported(K):
 
 
 PIVOT_LD = 128      # BS_LAYOUT_PIVOT: 64 x (cumulative value, aux) words per row
+PIVOT_MAX_D = 15872  # BS_POP_PIVOT_MAX_D (include/bitswap_hip.h): symbols + the 2 KB parameter block in 64 KB of LDS
 
 
 def pivot_supported(K, D):
     """bs_rans_pop_pivot takes K = 256 .. 2048 and whole 64-symbol chunks (uniform-width bins only: the caller checks)."""
-    return K in (256, 512, 1024, 2048) and D % 64 == 0 and D <= 16384
+    return K in (256, 512, 1024, 2048) and D % 64 == 0 and D <= PIVOT_MAX_D
 
 
 def selftest():

@@ -86,7 +86,9 @@ def _flat(d, pre=""):
 
 # informational fields: where the stream was written, not how
 # (library_abi: the C interface version -- recorded; what decides decodability is conv_route.rev and the CDF specs)
-_IGNORED = ("backend", "world_size", "experiments", "ndatapoints", "nblocks", "image", "library_abi")
+# (init_draws, ntest: how the CLI drew the initial words / against how many test images -- checked by cli.decompress_streams
+# itself, which can name the remedy; absent in streams written before round 6)
+_IGNORED = ("backend", "world_size", "experiments", "ndatapoints", "nblocks", "image", "library_abi", "init_draws", "ntest")
 
 
 def check(written, mine, what="stream"):

@@ -178,8 +178,10 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
  * of uniform-width bins): the same ANS.decode (mnist_compress.py:58-68), the same symbols and words; the integer row of
  * a symbol's group is rebuilt inside the kernel with the operations bs_logistic_tables spent on it (the SAME endpoints,
  * bin_step, cdf_spec (2 or 3), mu, scale, bits, quantbits must be passed), so only 64 cumulative values per row travel through HBM.
- * pivots [B,D,ld] as written by bs_logistic_tables(layout = BS_LAYOUT_PIVOT); D % 64 == 0, D <= 16384.
+ * pivots [B,D,ld] as written by bs_logistic_tables(layout = BS_LAYOUT_PIVOT); D % 64 == 0, D <= BS_POP_PIVOT_MAX_D
+ * (a chain's D symbols and the 2 KB parameter block of a 64-row chunk share one 64 KB LDS allocation).
  */
+#define BS_POP_PIVOT_MAX_D 15872
 int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap, const uint32_t* pivots, int64_t ld,
                       const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
                       const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits,

@@ -696,7 +696,8 @@ def test_degenerate_parameters_are_flagged(spec):
 
 @pytest.mark.parametrize("K,D,ptype,shared_row", [(1024, 192, np.float32, False), (256, 128, np.float32, True),
                                                    (512, 64, np.float64, False), (2048, 64, np.float32, False),
-                                                   (1024, 2048, np.float32, False)])
+                                                   (1024, 2048, np.float32, False),
+                                                   (256, 15872, np.float32, True)])     # D = BS_POP_PIVOT_MAX_D: the LDS limit
 @pytest.mark.parametrize("spec", [2, 3])
 def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_row, spec):
     """BS_LAYOUT_PIVOT (64 cumulative values per row; bs_rans_pop_pivot rebuilds the symbol's group of bins with the table
@@ -706,6 +707,7 @@ def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_r
     count; a chain flagged by the table kernel is skipped by both."""
     from bitswap_amd.bins import uniform_step
     h = hip()
+    assert h.pivot_supported(K, D) and not h.pivot_supported(K, h.PIVOT_MAX_D + 64)
     q = int(np.log2(K))
     rng = np.random.RandomState(K + D)
     B = 6

@@ -170,6 +170,30 @@ def test_codec_many_chains_round_trip(bitswap):
     assert torch.equal(out, images) and st.to_lists() == initial_states(B)
 
 
+def test_two_codecs_of_different_cdf_spec_on_one_backend_object_are_refused():
+    """the backend object carries the CDF spec of its uniform-bin tables, the codec its own copy for the (f, c) of
+    the split push and for the fingerprint.  A second codec with another spec on the SAME backend object re-configures the
+    backend under the first one: that codec must refuse to code (tables of one spec, (f, c) of another, under a fingerprint
+    that looks valid) instead of writing an undecodable stream.  A backend object per codec is fine."""
+    model, zend, zcen = workload.build("mnist2", "cpu", quantbits=8, small=8)
+    images = workload.synthetic_blocks(2, model.xs, seed=3).view(1, 2, -1).to(torch.int32)
+    shared = OracleBackend(O.MODE_DET)
+    c3 = BitSwapCodec(model, zend, zcen, quantbits=8, backend=shared, cdf_spec=3)
+    assert any(s is not None for s in c3.zstep) or c3.xstep is not None     # (there IS a uniform-bin table at stake)
+    st, _ = c3.compress(images)
+    assert torch.equal(c3.decompress(st, 2), images)
+    c2 = BitSwapCodec(model, zend, zcen, quantbits=8, backend=shared, cdf_spec=2)
+    with pytest.raises(RuntimeError, match="CDF spec 3 .* spec 2"):
+        c3.compress(images)
+    st, _ = c2.compress(images)                                              # the codec the backend now belongs to works
+    assert torch.equal(c2.decompress(st, 2), images)
+    c3b = BitSwapCodec(model, zend, zcen, quantbits=8, backend=OracleBackend(O.MODE_DET), cdf_spec=3)
+    st, _ = c3b.compress(images)
+    assert torch.equal(c3b.decompress(st, 2), images)
+    st, _ = c2.compress(images)                                              # ... and is not disturbed by c3b's own backend
+    assert torch.equal(c2.decompress(st, 2), images)
+
+
 def test_too_few_initial_bits_is_reported():
     """BB-ANS pops all nz layers first (config 5): 3000 initial words cannot feed 8 x 2048 x 6 bits."""
     model, zend, zcen = workload.build("cifar8", "cpu", quantbits=6, small=8)
@@ -568,6 +592,45 @@ def test_stream_fingerprint_is_enforced_by_receivers(tmp_path):
     cli.decompress_streams(8, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=ob, small=8, verbose=False)
 
 
+def test_stream_set_records_its_draws_and_keeps_its_own_indices(tmp_path):
+    """ADVICE r5 (medium + low): stream_meta.json says how the initial words were drawn and against how many test images
+    (under the reference's order, mnist_compress.py:94,133-137,158, the words depend on both), a receiver with another test
+    set is refused by name, streams written before the record existed still verify (both earlier conventions are tried), and
+    the datapoint indices live next to the streams: a later run of another shape in the same outdir rewrites the reference's
+    shared bitstreams/<ds>/indices.npy without stranding them."""
+    import json
+    from bitswap_amd import meta
+    from bitswap_amd.codec import initial_states, reference_draws
+    ob = OracleBackend(O.MODE_DET)
+    kw = dict(dataset="mnist", outdir=str(tmp_path), backend=ob, small=8, verbose=False)
+    cli.compress(8, 2, 1, 0, experiments=3, ndatapoints=2, decompress=False, **kw)
+    sdir = tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap"
+    good = json.load(open(sdir / "stream_meta.json"))
+    assert good["init_draws"] == "reference_order" and good["ntest"] == 512
+    idx = np.load(sdir / "indices.npy")
+    assert idx.shape == (3, 2) and np.array_equal(idx, reference_draws(512, 3, 2)[0])
+    # the two conventions really are different words (else the record would be decoration)
+    assert cli.experiment_draws(512, 3, 2)[1] != initial_states(3) and cli.experiment_draws(512, 3, 2, convention="seed_then_words")[1] == initial_states(3)
+    assert cli.experiment_draws(4, 3, 2)[2] == "seed_then_words"
+    # another run of another shape rewrites the shared index file; the first stream set still decodes
+    cli.compress(8, 2, 0, 0, experiments=2, ndatapoints=3, decompress=False, **kw)
+    assert np.load(tmp_path / "bitstreams" / "mnist" / "indices.npy").shape == (2, 3)
+    assert cli.decompress_streams(8, 2, 1, 0, **kw).shape == (3, 2, 1024)
+    # a stream set without the record (rounds 3-5) still verifies
+    old = {k: v for k, v in good.items() if k not in ("init_draws", "ntest")}
+    json.dump(old, open(sdir / "stream_meta.json", "w"))
+    cli.decompress_streams(8, 2, 1, 0, **kw)
+    # a receiver whose test set has another size is told so; an unknown convention is refused
+    json.dump(dict(good, ntest=10000), open(sdir / "stream_meta.json", "w"))
+    with pytest.raises(meta.StreamMismatch, match="10000 test images"):
+        cli.decompress_streams(8, 2, 1, 0, **kw)
+    json.dump(dict(good, init_draws="something_else"), open(sdir / "stream_meta.json", "w"))
+    with pytest.raises(meta.StreamMismatch, match="something_else"):
+        cli.decompress_streams(8, 2, 1, 0, **kw)
+    # ... and the fingerprint word of the 64-state container does not move with the new informational fields
+    assert meta.word(good) == meta.word(old)
+
+
 def test_container_fingerprint_and_sidecar():
     """The 64-state container (version 2) carries the CRC-32 of the sender's fingerprint; version 1 files still read; the
     single-image receiver refuses a sidecar / header word it does not reproduce."""
@@ -738,6 +801,11 @@ def test_conv_epilogue_kernels_are_built_without_packed_float32_operations(tmp_p
     assert r.returncode == 0, r.stderr[-1500:]
     packed = [l.strip() for l in open(out) if l.strip().startswith(("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"))]
     assert not packed, packed[:5]
+    # the source-level half of the guard: a build system that does not know about the flag gets an error, not the
+    # packed code
+    bare = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    r = subprocess.run([build.hipcc_path()] + bare + ["-fsyntax-only", "--cuda-device-only", src], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "-fno-slp-vectorize" in r.stderr
 
 
 def test_library_built_with_other_flags_counts_as_stale(monkeypatch, tmp_path):
