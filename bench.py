@@ -103,6 +103,11 @@ def parse():
     ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
                     help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
     ap.add_argument("--cdf-spec", type=int, default=3, choices=[1, 2, 3])
+    ap.add_argument("--nn-batch", type=int, default=0,
+                    help="EXPERIMENT (VERDICT r5 #6, cache-resident layer chunks): run every conv stack over column chunks of this "
+                         "many chains, one after the other (Model.nn_batch: fixed-shape micro-batches), so that the Winograd operands "
+                         "V + M of a chunk can stay in the 256 MiB Infinity Cache between producer and consumer; 0 = one launch over "
+                         "all the chains of a group (the default).  Same bits either way: every conv kernel is batch-invariant")
     ap.add_argument("--no-graphs", action="store_true", help="never replay the block step from a hipGraph (single-stream runs)")
     ap.add_argument("--format", default="reference", choices=["reference", "wave64"],
                     help="reference: the reference's single-state word stream (default, the headline); wave64: the opt-in "
@@ -307,7 +312,7 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     from bitswap_amd import workload
     from bitswap_amd.codec import GroupedCodec, Timeline, initial_states
 
-    model, zend, zcen = workload.build(name, dev, quantbits=args.quantbits, regime=regime)
+    model, zend, zcen = workload.build(name, dev, quantbits=args.quantbits, regime=regime, nn_batch=args.nn_batch or None)
     n = K + W
     strong = chain_ids is not None
     if strong:
@@ -767,7 +772,7 @@ def main(args):
                    "chains_per_gpu": r["chains_per_gpu"], "chain_groups": r["chain_groups"], "blocks_per_chain": args.steps,
                    "quantbits": args.quantbits, "ansbits": 31, "cdf_spec": args.cdf_spec, "stream_format": args.format,
                    "latent_dims": Z, "pixel_dims": X, "conv_dtype": "f32" if arith == "fp32" else arith, "conv_path": conv_path,
-                   "forked_block_step": forked,
+                   "forked_block_step": forked, "nn_batch": args.nn_batch or None,
                    "weights": "seeded random init (no checkpoints offline)"
                               + (", calibrated to the low-rate regime (workload.calibrate_lowrate)" if args.regime else ""),
                    # the other shapes measured by this run, each in a process of its own like the headline (full records:

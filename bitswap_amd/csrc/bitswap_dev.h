@@ -268,15 +268,32 @@ struct InvTree<1> {
     double t;
     __device__ __forceinline__ void up(const double* x) { t = x[0]; }
     template <typename F>
-    __device__ __forceinline__ void down(double inv, int i0, F&& leaf) { leaf(i0, inv); }
+    __device__ __forceinline__ void down(double inv, int i0, F&& leaf) { leaf(i0, inv, t); }
 };
-// leaf(i, 1 / x[i]) for i = 0 .. N-1 in order
+// leaf(i, ~1 / x[i], x[i]) for i = 0 .. N-1 in order (spec 3 uses the quotient as it comes; spec 4 corrects it with x[i])
 template <int N, typename F>
 __device__ __forceinline__ void tree_inverse(const double* x, int i0, F&& leaf) {
     static_assert(N == 2 || N == 4 || N == 8 || N == 16, "block of a power of two, at most 16 bins");
     InvTree<N> tr;
     tr.up(x);
     tr.down(recip_1_to_huge(tr.t), i0, leaf);
+}
+// BS_CDF_SPEC 4 (round 6): spec 3 with blocks of at most 8 bins and ONE residual correction per quotient,
+//   c <- fma(fma(-x, c, 1), c, c),
+// which squares the tree's accumulated rounding error (2 log2 n + 1 roundings) away: c is RN(1 / x) in all but ~2^-50 of the cases,
+// i.e. spec 2's tables (0.03 ppm of entries off torch.sigmoid's, against 0.2 ppm for spec 3; the reference's own 100-block streams
+// reproduced to the word like spec 2, tests/test_oracle.py::HORIZON) for 92 instead of 144 issue slots per 16 bins (spec 3: 54).
+// Blocks of 8: half the live tree registers of spec 3's blocks of 16 -- the table kernel fits 5 wavefronts per SIMD instead of 4.
+// oracle/bitswap_oracle.c::det4_row_cdf is the C restatement.
+template <int SPEC, int NPL>
+struct SpecBlock {
+    static constexpr int MAXN = SPEC == 4 ? 8 : 16;
+    static constexpr int N = NPL < MAXN ? NPL : MAXN;
+};
+__device__ __forceinline__ double newton_correct(double x, double c) {
+    double r;
+    asm("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(x), "v"(c));       // fma(-x, c, 1): ONE three-source instruction, inline constant
+    return fma(r, c, c);
 }
 // fma(-a, b, c) as ONE three-source instruction: left to itself hipcc writes v_mov_b64 + v_fmac_f64 whenever c lives on
 __device__ __forceinline__ double fnma3(double a, double b, double c) {
@@ -315,19 +332,20 @@ __device__ __forceinline__ bool logistic_row(const double (&e)[NPL], double hste
         const double span = (double)NPL * fabs(hr);
         in_domain = span < 650.0;
         bool batch = false;
-        if constexpr (SPEC == 3 && NPL >= 4) batch = span < BS_SPEC3_FAST_HR;      // wave-uniform (mu, scale, h are scalars)
+        if constexpr (SPEC >= 3 && NPL >= 4) batch = span < BS_SPEC3_FAST_HR;      // wave-uniform (mu, scale, h are scalars)
         if (batch) {
-            if constexpr (SPEC == 3 && NPL >= 4) {
+            if constexpr (SPEC >= 3 && NPL >= 4) {
                 const double A = det_exp_hi(-ta, BS_SPEC3_ANCHOR_HI);
                 const double Ars = A * rs;
                 double x[NPL];
                 x[0] = 1.0 + A;
                 spec3_denoms<NPL, 1>(e, Ars, A, qb, x);
-                constexpr int NB = NPL < 16 ? NPL : 16;
+                constexpr int NB = SpecBlock<SPEC, NPL>::N;
                 c0 = prev = 0.0;
 #pragma unroll
                 for (int i0 = 0; i0 < NPL; i0 += NB)
-                    tree_inverse<NB>(x + i0, i0, [&](int i, double ci) {
+                    tree_inverse<NB>(x + i0, i0, [&](int i, double ci, double xi) {
+                        if constexpr (SPEC == 4) ci = newton_correct(xi, ci);
                         if (i == 0) {
                             c0 = ci;
                         } else {

@@ -178,9 +178,9 @@ int dispatch_layer64(int K, int spec, const double* endpoints, int64_t e_stride,
     hipLaunchKernelGGL((k_layer64<NPL, PT, SPEC, PUSH>), grid, block, 0, st, endpoints, e_stride, step, m, s, p_stride, \
                        sym_in, sym_out, centres, c_stride, centre_out, head, stack, len, cap, B, D, bits, quantbits, nb, status)
     switch (K) {
-        case 256: if (spec == 3) BS_L64(4, 3); else if (spec == 2) BS_L64(4, 2); else BS_L64(4, 1); break;
-        case 512: if (spec == 3) BS_L64(8, 3); else if (spec == 2) BS_L64(8, 2); else BS_L64(8, 1); break;
-        case 1024: if (spec == 3) BS_L64(16, 3); else if (spec == 2) BS_L64(16, 2); else BS_L64(16, 1); break;
+        case 256: if (spec == 4) BS_L64(4, 4); else if (spec == 3) BS_L64(4, 3); else if (spec == 2) BS_L64(4, 2); else BS_L64(4, 1); break;
+        case 512: if (spec == 4) BS_L64(8, 4); else if (spec == 3) BS_L64(8, 3); else if (spec == 2) BS_L64(8, 2); else BS_L64(8, 1); break;
+        case 1024: if (spec == 4) BS_L64(16, 4); else if (spec == 3) BS_L64(16, 3); else if (spec == 2) BS_L64(16, 2); else BS_L64(16, 1); break;
         default: return BS_EUNSUPPORTED;
     }
 #undef BS_L64
@@ -195,7 +195,7 @@ int bs_layer_pop64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t 
                    int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu, const void* scale, int64_t p_stride,
                    int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out, const double* centres,
                    int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
-    const int spec = cdf_spec == 1 ? 1 : ((cdf_spec == 2 || cdf_spec == 3) && bin_step) ? cdf_spec : 0;
+    const int spec = cdf_spec == 1 ? 1 : (cdf_spec >= 2 && cdf_spec <= 4 && bin_step) ? cdf_spec : 0;
     if (!spec) return BS_EINVAL;
     if (spec == 1) bin_step = nullptr;
     if (!head64 || !stack64 || !len64 || !endpoints || !mu || !scale || !sym_out || !status || B < 0 || D < 0 || cap < 0 ||
@@ -219,7 +219,7 @@ int bs_layer_push64(uint64_t* head64, uint32_t* stack64, int32_t* len64, int64_t
                     int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu, const void* scale, int64_t p_stride,
                     int param_dtype, const int32_t* sym, int B, int D, int K, int bits, int quantbits, int32_t* status,
                     void* stream) {
-    const int spec = cdf_spec == 1 ? 1 : ((cdf_spec == 2 || cdf_spec == 3) && bin_step) ? cdf_spec : 0;
+    const int spec = cdf_spec == 1 ? 1 : (cdf_spec >= 2 && cdf_spec <= 4 && bin_step) ? cdf_spec : 0;
     if (!spec) return BS_EINVAL;
     if (spec == 1) bin_step = nullptr;
     if (!head64 || !stack64 || !len64 || !endpoints || !mu || !scale || !sym || !status || B < 0 || D < 0 || cap < 0 ||

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
         const double rs_l = recip_scale((double)scale[prm]);
         const double hr_l = h_l * rs_l;
         // spec 3: which rows of the chunk take the batch inversion (logistic_row's test, one bit per row)
-        const unsigned long long batch_rows = SPEC == 3 ? __ballot((double)NPL * fabs(hr_l) < BS_SPEC3_FAST_HR) : 0ull;
+        const unsigned long long batch_rows = SPEC >= 3 ? __ballot((double)NPL * fabs(hr_l) < BS_SPEC3_FAST_HR) : 0ull;
         __syncthreads();                      // one wavefront per block: orders the LDS accesses, costs nothing
         sh_prm[lane] = make_double4(mu_l, rs_l, h_l, hr_l);
         __syncthreads();
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                 if (dl > 0) { pp -= ld2; ap -= e_stride; }
                 --dl;
                 // logistic_row, one bin per lane
-                const bool batch = SPEC == 3 && ((batch_rows >> dk) & 1ull);   // wave-uniform
+                const bool batch = SPEC >= 3 && ((batch_rows >> dk) & 1ull);   // wave-uniform
                 const double hi = batch ? BS_SPEC3_ANCHOR_HI : 700.0;
                 double A, Q;
                 if (ONE_EXP) {
@@ -485,7 +485,8 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                     if (j == K - 1) r = 0.0;                                 // the K-th, virtual endpoint: on the progression
                     const double Ars = A * rs;
                     const double x = fma(Q, fma(-Ars, r, A), 1.0);           // bi == 0: Q = 1, r = 0 -> 1 + A
-                    c = tree_inverse_lanes<(NPL < 16 ? NPL : 16)>(x);
+                    c = tree_inverse_lanes<SpecBlock<SPEC, NPL>::N>(x);       // spec 4: blocks of 8 lanes ...
+                    if constexpr (SPEC == 4) c = newton_correct(x, c);         // ... and the residual correction of logistic_row
                 } else {
                     const double eps = r * rs;
                     const double uu = fma(-A, eps, A);
@@ -616,7 +617,10 @@ int dispatch_pop_pivot(int spec, uint64_t* head, uint32_t* stack, int32_t* len, 
     const PT* s = static_cast<const PT*>(scale);
 #define BS_POPP(NPL, PF)                                                                                              \
     do {                                                                                                              \
-        if (spec == 3)                                                                                                \
+        if (spec == 4)                                                                                                \
+            hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF, 4>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, \
+                               endpoints, e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status); \
+        else if (spec == 3)                                                                                           \
             hipLaunchKernelGGL((k_rans_pop_pivot<NPL, PT, PF, 3>), grid, block, (size_t)D * 4, st, head, stack, len, cap, piv, ld, \
                                endpoints, e_stride, step, m, s, D, bits, quantbits, sym_out, centres, c_stride, centre_out, status); \
         else                                                                                                          \
@@ -676,7 +680,7 @@ int bs_rans_pop_pivot(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap
                       const double* endpoints, int64_t e_stride, const double* bin_step, int cdf_spec, const void* mu,
                       const void* scale, int param_dtype, int B, int D, int K, int bits, int quantbits, int32_t* sym_out,
                       const double* centres, int64_t c_stride, float* centre_out, int32_t* status, void* stream) {
-    if ((cdf_spec != 2 && cdf_spec != 3) || !head || !stack || !len || !pivots || !endpoints || !bin_step || !mu || !scale || !sym_out || !status || B < 0 ||
+    if (cdf_spec < 2 || cdf_spec > 4 || !head || !stack || !len || !pivots || !endpoints || !bin_step || !mu || !scale || !sym_out || !status || B < 0 ||
         D < 0 || cap < 0 || bits < 1 || bits > 31 || quantbits < 0 || quantbits >= bits || e_stride < 0 || c_stride < 0 ||
         (centres && !centre_out) || ld < 128 || ld % 2 || (reinterpret_cast<uintptr_t>(pivots) & 7u))
         return BS_EINVAL;

@@ -2,10 +2,15 @@
 // (one of the translation units of libbitswap_hip.so; shared device helpers: bitswap_dev.h; entry points: include/bitswap_hip.h)
 #include "bitswap_dev.h"
 
+// wavefronts per SIMD the spec 4 table kernels are compiled for (blocks of 8 bins: half the live tree registers of spec 3)
+#ifndef BS_SPEC4_WAVES
+#define BS_SPEC4_WAVES 5
+#endif
+
 namespace {
 
 template <int NPL, typename PT, int MODE, int SPEC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC >= 2 ? 4 : 7, 8))) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC == 4 ? BS_SPEC4_WAVES : SPEC >= 2 ? 4 : 7, 8))) void k_logistic(const double* __restrict__ endpoints, int64_t e_stride,
                                                   const double* __restrict__ step,
                                                   const PT* __restrict__ mu, const PT* __restrict__ scale,
                                                   const int32_t* __restrict__ sym, int B, int D, int bits,
@@ -247,7 +252,7 @@ int launch_logistic(int mode, int spec, const double* endpoints, int64_t e_strid
     hipLaunchKernelGGL((k_logistic<NPL, PT, MODE, SPEC>), grid, block, 0, st, endpoints, e_stride, step, m, s, sym, B, D, \
                        bits, quantbits, nb, out0, out1, ld, status)
     // specs 2 / 3 (uniform bins): host dispatch guarantees NPL >= 4; the layouts of the pop kernels need NPL >= 4 as well
-    constexpr int S2 = NPL >= 4 ? 2 : 1, S3 = NPL >= 4 ? 3 : 1;
+    constexpr int S2 = NPL >= 4 ? 2 : 1, S3 = NPL >= 4 ? 3 : 1, S4 = NPL >= 4 ? 4 : 1;
     constexpr int MP = NPL >= 4 ? M_PIVOT : M_LINEAR, MW = NPL >= 4 ? M_WAVE : M_LINEAR, MV = NPL >= 4 ? M_LINEAR_VEC : M_LINEAR;
 #define BS_BY_MODE(SPEC)                                   \
     do {                                                   \
@@ -257,7 +262,8 @@ int launch_logistic(int mode, int spec, const double* endpoints, int64_t e_strid
         else if (mode == M_ENCODE) BS_LAUNCH(M_ENCODE, SPEC); \
         else BS_LAUNCH(M_LINEAR, SPEC);                    \
     } while (0)
-    if (spec == 3) BS_BY_MODE(S3);
+    if (spec == 4) BS_BY_MODE(S4);
+    else if (spec == 3) BS_BY_MODE(S3);
     else if (spec == 2) BS_BY_MODE(S2);
     else if (mode == M_WAVE && NPL >= 4) BS_LAUNCH(MW, 1);
     else if (mode == M_LINEAR_VEC && NPL >= 4) BS_LAUNCH(MV, 1);
@@ -291,10 +297,10 @@ int dispatch_logistic(int K, int mode, int spec, const double* endpoints, int64_
 #undef BS_CASE
 }
 
-// cdf_spec argument of the C ABI -> 1 / 2 / 3, or 0 when it contradicts bin_step
+// cdf_spec argument of the C ABI -> 1 / 2 / 3 / 4, or 0 when it contradicts bin_step
 inline int checked_spec(int cdf_spec, const double* bin_step) {
     if (cdf_spec == 1) return 1;                                  // bin_step is ignored
-    if ((cdf_spec == 2 || cdf_spec == 3) && bin_step) return cdf_spec;
+    if (cdf_spec >= 2 && cdf_spec <= 4 && bin_step) return cdf_spec;
     return 0;
 }
 

@@ -102,7 +102,7 @@ class OracleBackend:
 
     def _mode(self, step):
         if step is not None and self.mode == O.MODE_DET:
-            return O.MODE_DET3 if self.cdf_spec == 3 else O.MODE_DET2
+            return {2: O.MODE_DET2, 3: O.MODE_DET3, 4: O.MODE_DET4}[self.cdf_spec]
         return self.mode
 
     @staticmethod

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 OK, UNDERFLOW, OVERFLOW, BAD_TABLE = 0, 1, 2, 3
-MODE_LIBM, MODE_DET, MODE_DET2, MODE_DET3 = 0, 1, 2, 3   # reference formula / CDF spec 1 / CDF specs 2, 3 (uniform bins)
+MODE_LIBM, MODE_DET, MODE_DET2, MODE_DET3, MODE_DET4 = 0, 1, 2, 3, 4   # reference formula / CDF spec 1 / CDF specs 2, 3, 4 (uniform bins)
+UNIFORM_MODES = (MODE_DET2, MODE_DET3, MODE_DET4)
 MODE_TORCH = 9   # backend.py only: the reference formula evaluated by torch.sigmoid itself (utils/torch/rand.py:67-68)
 
 
@@ -91,7 +92,7 @@ def logistic_pmf(endpoints, mu, scale, mode=MODE_LIBM, step=None):
     e, mu, scale = _f64(endpoints), _f64(mu), _f64(scale)
     D, Km1 = e.shape
     pmf = np.empty((D, Km1 + 1), dtype=np.float64)
-    if mode in (MODE_DET2, MODE_DET3):
+    if mode in UNIFORM_MODES:
         step = _f64(bin_step(e) if step is None else step)
         lib().orc_logistic_pmf_uniform(_ptr(e), _ptr(step), _ptr(mu), _ptr(scale), D, Km1 + 1, mode, _ptr(pmf))
     else:
@@ -161,7 +162,7 @@ def pop(st, cdf, bits=31):
 
 
 def _step_ptr(e, mode, step):
-    if mode not in (MODE_DET2, MODE_DET3):
+    if mode not in UNIFORM_MODES:
         return None, C.c_void_p(0)
     step = _f64(bin_step(e) if step is None else step)
     return step, _ptr(step)
