@@ -102,7 +102,7 @@ def parse():
     ap.add_argument("--total-chains", type=int, default=100, help="chains in total over all ranks (--scaling strong)")
     ap.add_argument("--tables-on", default="bulk", choices=["bulk", "serial"],
                     help="stream of the table kernels when groups > 1 (see BitSwapCodec.tables_on)")
-    ap.add_argument("--cdf-spec", type=int, default=3, choices=[1, 2, 3])
+    ap.add_argument("--cdf-spec", type=int, default=None, choices=[1, 2, 3, 4], help="default: bitswap_amd.meta.DEFAULT_CDF_SPEC")
     ap.add_argument("--nn-batch", type=int, default=0,
                     help="EXPERIMENT (VERDICT r5 #6, cache-resident layer chunks): run every conv stack over column chunks of this "
                          "many chains, one after the other (Model.nn_batch: fixed-shape micro-batches), so that the Winograd operands "
@@ -112,7 +112,11 @@ def parse():
     ap.add_argument("--format", default="reference", choices=["reference", "wave64"],
                     help="reference: the reference's single-state word stream (default, the headline); wave64: the opt-in "
                          "64-state format -- table + coding step fused in one launch, one stream per chain group")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.cdf_spec is None:
+        from bitswap_amd.meta import DEFAULT_CDF_SPEC
+        a.cdf_spec = DEFAULT_CDF_SPEC
+    return a
 
 
 def cpu_baseline(args, name):

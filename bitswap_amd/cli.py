@@ -97,7 +97,7 @@ def stream_name(scheme, quantbits, nz, c, wave64=False):
 
 def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndatapoints=100, decompress=False,
              synthetic=False, data=None, params=None, outdir=".", backend=None, small=None, verbose=True,
-             save_bins=False, fmt="reference", cdf_spec=3):
+             save_bins=False, fmt="reference", cdf_spec=meta.DEFAULT_CDF_SPEC):
     """One (dataset, nz, quantbits, scheme) experiment set.  Returns dict of the metric arrays on
     rank 0 (None on other ranks).  fmt "wave64": the opt-in 64-state stream format (pickles then hold 64 sub-state
     lists per experiment and carry the suffix _wave64)."""
@@ -223,7 +223,7 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
 
 
 def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=False, data=None, params=None,
-                       outdir=".", backend=None, small=None, verbose=True, cdf_spec=3):
+                       outdir=".", backend=None, small=None, verbose=True, cdf_spec=meta.DEFAULT_CDF_SPEC):
     """Receiver only (the reference decodes inside compress(), mnist_compress.py:277-358; a real receiver is another
     process): load the experiment pickles and stream_meta.json a sender wrote under `outdir`, REFUSE to decode unless this
     receiver reproduces the recorded format / CDF specification / conv route, decode every experiment, and assert the
@@ -308,7 +308,7 @@ def dataset_main(dataset, default_nz, nz_loop=None):
                    help="stream format: the reference's single-state stream, or the opt-in 64-state format")
     p.add_argument('--decompress-only', action='store_true',
                    help="receiver only: decode the pickles a previous run wrote under --outdir (checks stream_meta.json first)")
-    p.add_argument('--cdf-spec', default=3, type=int, choices=[1, 2, 3],
+    p.add_argument('--cdf-spec', default=meta.DEFAULT_CDF_SPEC, type=int, choices=list(meta.CDF_SPECS),
                    help="deterministic CDF specification (include/bitswap_hip.h) of the tables whose bins are uniform: 3 = one "
                         "reciprocal per block of bins (default since round 5), 2 = one per bin (streams of rounds 3-4), "
                         "1 = one sigmoid per endpoint everywhere (streams written before round 2)")
@@ -382,7 +382,7 @@ class ImageStreams(list):
 
 
 def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_quirk=False, setup=None, backend=None,
-                    trim=True, fmt="reference", cdf_spec=3):
+                    trim=True, fmt="reference", cdf_spec=meta.DEFAULT_CDF_SPEC):
     """images_blocks: list of [n_i, 32, 32, 3] uint8 block arrays (one per image; every image is a
     chain, imagenetcrop_compress.py:279-300).  Chains of different length run in lock-step and
     drop out as they finish.  Returns per image (state list, min_words, bits/dim); in the 64-state format the state is
@@ -413,7 +413,7 @@ def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_qui
 
 
 def decompress_image(state, nblocks, quantbits=10, nz=4, gpu=0, setup=None, backend=None, hwc_quirk=False,
-                     expect=None, expect_word=None, cdf_spec=3):
+                     expect=None, expect_word=None, cdf_spec=meta.DEFAULT_CDF_SPEC):
     """demo_decompress.decompress (:69-148): -> [nblocks, 32, 32, 3] uint8 blocks.  A state that is a list of 64
     sub-state lists (container.unpack64) is decoded in the 64-state format.  expect: the sender's fingerprint record
     (the container's sidecar) / expect_word: its CRC-32 (64-state container header): decoding is REFUSED

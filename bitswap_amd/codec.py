@@ -307,7 +307,7 @@ class BitSwapCodec:
     """
 
     def __init__(self, model, zendpoints, zcentres, quantbits=10, bitswap=True, ansbits=31, backend=None,
-                 timeline=None, cdf_spec=3):
+                 timeline=None, cdf_spec=None):
         self.backend = backend if backend is not None else HipBackend(zendpoints.device)
         self.model = model
         self.nz = model.nz
@@ -325,7 +325,9 @@ class BitSwapCodec:
         # per block of bins; 2: round 3/4 streams) on every set of uniform-width bins (all latent layers but the top one, and
         # the pixels), spec 1 elsewhere.  Which tables are uniform is a function of the bins alone, so a receiver built from
         # the same bins and the same cdf_spec makes the same choice; cdf_spec=1 forces spec 1 everywhere (round 1/2 streams).
-        assert cdf_spec in (1, 2, 3)
+        from .meta import CDF_SPECS, DEFAULT_CDF_SPEC
+        cdf_spec = DEFAULT_CDF_SPEC if cdf_spec is None else int(cdf_spec)
+        assert cdf_spec in CDF_SPECS
         self.cdf_spec = cdf_spec
         if cdf_spec >= 2:
             self.backend.cdf_spec = cdf_spec

@@ -292,8 +292,11 @@ struct SpecBlock {
 };
 __device__ __forceinline__ double newton_correct(double x, double c) {
     double r;
-    asm("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(x), "v"(c));       // fma(-x, c, 1): ONE three-source instruction, inline constant
-    return fma(r, c, c);
+    // two three-source instructions (left to itself hipcc writes v_mov_b64 + v_fmac_f64 for each: 34 extra moves per row)
+    double d;
+    asm("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(r) : "v"(x), "v"(c));       // fma(-x, c, 1)
+    asm("v_fma_f64 %0, %1, %2, %2" : "=v"(d) : "v"(r), "v"(c));         // fma(r, c, c)
+    return d;
 }
 // fma(-a, b, c) as ONE three-source instruction: left to itself hipcc writes v_mov_b64 + v_fmac_f64 whenever c lives on
 __device__ __forceinline__ double fnma3(double a, double b, double c) {
@@ -301,11 +304,25 @@ __device__ __forceinline__ double fnma3(double a, double b, double c) {
     asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
-template <int NPL, int I>
+// denominators x[I .. END) of this lane's bins (x[0] = 1 + A is the caller's: no residual, no geometric factor)
+template <int NPL, int I, int END>
 __device__ __forceinline__ void spec3_denoms(const double (&e)[NPL], double Ars, double A, double qb, double (&x)[NPL]) {
-    if constexpr (I < NPL) {
+    if constexpr (I < END) {
         x[I] = one_plus_e<NPL, I>(qb, fnma3(Ars, e[I], A));      // e[I]: the residual r_I of the stored endpoint
-        spec3_denoms<NPL, I + 1>(e, Ars, A, qb, x);
+        spec3_denoms<NPL, I + 1, END>(e, Ars, A, qb, x);
+    }
+}
+// blocks [I0, I0 + NB), [I0 + NB, ...) of a row in order: a block's denominators are built right in front of its tree, so only
+// one block's worth of them (and of tree nodes) is live at a time -- with spec 4's blocks of 8 that is what lets the table
+// kernel run 5 wavefronts per SIMD
+template <int NPL, int SPEC, int I0, typename F>
+__device__ __forceinline__ void spec3_blocks(const double (&e)[NPL], double Ars, double A, double qb, double (&x)[NPL], F&& leaf) {
+    constexpr int NB = SpecBlock<SPEC, NPL>::N;
+    if constexpr (I0 < NPL) {
+        if constexpr (I0 == 0) x[0] = 1.0 + A;
+        spec3_denoms<NPL, (I0 == 0 ? 1 : I0), I0 + NB>(e, Ars, A, qb, x);
+        tree_inverse<NB>(x + I0, I0, leaf);
+        spec3_blocks<NPL, SPEC, I0 + NB>(e, Ars, A, qb, x, leaf);
     }
 }
 
@@ -338,22 +355,17 @@ __device__ __forceinline__ bool logistic_row(const double (&e)[NPL], double hste
                 const double A = det_exp_hi(-ta, BS_SPEC3_ANCHOR_HI);
                 const double Ars = A * rs;
                 double x[NPL];
-                x[0] = 1.0 + A;
-                spec3_denoms<NPL, 1>(e, Ars, A, qb, x);
-                constexpr int NB = SpecBlock<SPEC, NPL>::N;
                 c0 = prev = 0.0;
-#pragma unroll
-                for (int i0 = 0; i0 < NPL; i0 += NB)
-                    tree_inverse<NB>(x + i0, i0, [&](int i, double ci, double xi) {
-                        if constexpr (SPEC == 4) ci = newton_correct(xi, ci);
-                        if (i == 0) {
-                            c0 = ci;
-                        } else {
-                            if (i == NPL - 1 && lane == 63) ci = 1.0;
-                            bn.t[i] = trunc_u32((ci - prev) * M);
-                        }
-                        prev = ci;
-                    });
+                spec3_blocks<NPL, SPEC, 0>(e, Ars, A, qb, x, [&](int i, double ci, double xi) {
+                    if constexpr (SPEC == 4) ci = newton_correct(xi, ci);
+                    if (i == 0) {
+                        c0 = ci;
+                    } else {
+                        if (i == NPL - 1 && lane == 63) ci = 1.0;
+                        bn.t[i] = trunc_u32((ci - prev) * M);
+                    }
+                    prev = ci;
+                });
             }
         } else {
             const double A = det_exp(-ta);

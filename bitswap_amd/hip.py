@@ -201,19 +201,20 @@ def _step(step, D):
     return step
 
 
-UNIFORM_CDF_SPEC = 3     # CDF spec of rows of uniform-width bins when the caller names none (include/bitswap_hip.h BS_CDF_SPEC)
+UNIFORM_CDF_SPECS = (2, 3, 4)
+from .meta import DEFAULT_CDF_SPEC as UNIFORM_CDF_SPEC   # CDF spec of rows of uniform-width bins when the caller names none (include/bitswap_hip.h BS_CDF_SPEC)
 
 
 def _spec(step, spec):
-    """The `cdf_spec` argument of the C ABI: 1 without bin widths; with them 2 or 3 as asked (default UNIFORM_CDF_SPEC).
+    """The `cdf_spec` argument of the C ABI: 1 without bin widths; with them 2, 3 or 4 as asked (default UNIFORM_CDF_SPEC).
     Sender and receiver must make the same choice: the codec records it in the stream fingerprint (meta.py)."""
     if step is None:
         if spec not in (None, 1):
             raise BitswapHipError(f"CDF spec {spec} needs the bin widths (step)")
         return 1
     spec = UNIFORM_CDF_SPEC if spec is None else int(spec)
-    if spec not in (2, 3):
-        raise BitswapHipError(f"CDF spec {spec} is not one of the uniform-bin specifications (2, 3)")
+    if spec not in UNIFORM_CDF_SPECS:
+        raise BitswapHipError(f"CDF spec {spec} is not one of the uniform-bin specifications {UNIFORM_CDF_SPECS}")
     return spec
 
 

@@ -16,6 +16,11 @@ on the CDF specification per table; a mismatch decodes to garbage without any er
 import json
 import zlib
 
+# CDF specification (include/bitswap_hip.h BS_CDF_SPEC) a sender uses for tables of uniform-width bins unless told otherwise: the
+# ONE place the default lives -- codec, CLIs, bench and the bindings read it.  A receiver never guesses: it builds its codec with
+# the spec the stream's fingerprint names (cli.py), or refuses.
+DEFAULT_CDF_SPEC = 3
+CDF_SPECS = (1, 2, 3, 4)
 ROUTE_REV = 3    # bump when a kernel or route change alters the float32 bits of (mu, scale) or the integer tables
 
 

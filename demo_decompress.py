@@ -16,7 +16,7 @@ if __name__ == '__main__':
     ap.add_argument('--gpu', default=None, type=int)
     ap.add_argument('--synthetic', action='store_true')
     ap.add_argument('--params', default=None)
-    ap.add_argument('--cdf-spec', default=3, type=int, choices=[1, 2, 3],
+    ap.add_argument('--cdf-spec', default=meta.DEFAULT_CDF_SPEC, type=int, choices=list(meta.CDF_SPECS),
                     help="deterministic CDF specification the stream was written with (1: streams from before round 2)")
     args = ap.parse_args()
     if args.gpu is None:

@@ -54,9 +54,13 @@ extern "C" {
  *   spec 3: spec 2's denominators 1 + E, inverted per block of min(K/64, 16) bins through a balanced product tree with ONE
  *           correctly rounded reciprocal (54 instead of 144 issue slots per 16 bins); rows with (K/64) * bin_step / scale
  *           >= 8 (peaked pixel rows) are spec 2's bit for bit.  Same domain as spec 2; the default of the codec since round 5.
- * Every table-building entry point takes `cdf_spec` (1, 2 or 3) next to `bin_step`: 1 ignores bin_step; 2 and 3 need it
- * (BS_EINVAL otherwise).  The oracle's C restatements: oracle/bitswap_oracle.c::orc_det_sigmoid / det2_row_cdf / det3_row_cdf. */
-#define BS_CDF_SPEC 3
+ *   spec 4: spec 3 with blocks of min(K/64, 8) bins and one residual correction per quotient, c <- fma(fma(-x, c, 1), c, c):
+ *           spec 2's accuracy against torch.sigmoid (the correction squares the tree's rounding error away) for 92 instead of
+ *           144 issue slots per 16 bins; same domain and the same switch to spec 2's arithmetic for peaked rows as spec 3.
+ * Every table-building entry point takes `cdf_spec` (1 .. 4) next to `bin_step`: 1 ignores bin_step; 2, 3 and 4 need it
+ * (BS_EINVAL otherwise).  The oracle's C restatements: oracle/bitswap_oracle.c::orc_det_sigmoid / det2_row_cdf / det3_row_cdf /
+ * det4_row_cdf. */
+#define BS_CDF_SPEC 4
 
 #define BS_OK 0
 #define BS_EINVAL (-1)       /* bad argument (null pointer, negative size, ld < K+1 ...)   */
@@ -117,7 +121,7 @@ int bs_table_rows_f64(const double* pmf, int64_t rows, int K, int bits, int quan
  *   bin_step:  [D] doubles, the bin width h_d = (e[d][K-2] - e[d][0]) / (K-2) of rows whose endpoints are an arithmetic
  *              progression up to rounding (every latent layer but the top one: discretization.py:81-83,105-118);
  *              required by CDF specs 2 and 3 (K >= 256), ignored (may be NULL) by spec 1.
- *   cdf_spec:  1, 2 or 3 (BS_CDF_SPEC above).  The caller decides from the bins alone, so sender and receiver agree.
+ *   cdf_spec:  1, 2, 3 or 4 (BS_CDF_SPEC above).  The caller decides from the bins alone, so sender and receiver agree.
  *   cdf_out [B,D,ld] in `layout` (BS_LAYOUT_LINEAR, BS_LAYOUT_WAVE or BS_LAYOUT_PIVOT).
  *   status [B] (nullable) receives BS_ST_BADTABLE for a chain with a non-finite mu, a scale that is not a
  *              positive finite number, or a row whose remnant drives a frequency below 1 (mnist_compress.py:46-47).
@@ -177,7 +181,7 @@ int bs_rans_pop(uint64_t* head, uint32_t* stack, int32_t* len, int64_t cap,
  * bs_rans_pop_pivot -- bs_rans_pop on BS_LAYOUT_PIVOT rows (the production pair of the batched codec for every table
  * of uniform-width bins): the same ANS.decode (mnist_compress.py:58-68), the same symbols and words; the integer row of
  * a symbol's group is rebuilt inside the kernel with the operations bs_logistic_tables spent on it (the SAME endpoints,
- * bin_step, cdf_spec (2 or 3), mu, scale, bits, quantbits must be passed), so only 64 cumulative values per row travel through HBM.
+ * bin_step, cdf_spec (2, 3 or 4), mu, scale, bits, quantbits must be passed), so only 64 cumulative values per row travel through HBM.
  * pivots [B,D,ld] as written by bs_logistic_tables(layout = BS_LAYOUT_PIVOT); D % 64 == 0, D <= BS_POP_PIVOT_MAX_D
  * (a chain's D symbols and the 2 KB parameter block of a 64-row chunk share one 64 KB LDS allocation).
  */

@@ -98,7 +98,7 @@ class OracleBackend:
         return self.uniform_step(endpoints)
 
     # CDF specification of tables of uniform-width bins (2 or 3); the codec sets it from its cdf_spec, like HipBackend's
-    cdf_spec = 3
+    cdf_spec = 3      # (a codec sets it from its own cdf_spec; 3 = what the product defaulted to when this class was written)
 
     def _mode(self, step):
         if step is not None and self.mode == O.MODE_DET:

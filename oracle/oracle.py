@@ -18,6 +18,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 OK, UNDERFLOW, OVERFLOW, BAD_TABLE = 0, 1, 2, 3
 MODE_LIBM, MODE_DET, MODE_DET2, MODE_DET3, MODE_DET4 = 0, 1, 2, 3, 4   # reference formula / CDF spec 1 / CDF specs 2, 3, 4 (uniform bins)
 UNIFORM_MODES = (MODE_DET2, MODE_DET3, MODE_DET4)
+MODE_OF_SPEC = {1: MODE_DET, 2: MODE_DET2, 3: MODE_DET3, 4: MODE_DET4}   # BS_CDF_SPEC (include/bitswap_hip.h) -> mode
 MODE_TORCH = 9   # backend.py only: the reference formula evaluated by torch.sigmoid itself (utils/torch/rand.py:67-68)
 
 

@@ -59,7 +59,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.bs_wino_gemm_bf16x3(p, p, p, 36, 256, 256, 128, 7, None) == hip.EINVAL
     assert L.bs_wino_gemm_bf16x3(p, p, p, 36, 256, 250, 128, 6, None) == hip.EUNSUPPORTED
     assert L.bs_wino_gemm_bf16x3(p, p, p, 0, 256, 256, 128, 6, None) == hip.OK          # nothing to do: no launch
-    assert L.bs_cdf_spec() == 3
+    assert L.bs_cdf_spec() == 4
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

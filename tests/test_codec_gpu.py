@@ -398,7 +398,9 @@ class _Count:
 
 @pytest.mark.parametrize("name,bitswap,n,regime,cdf_spec", [("cifar8", 1, 1, None, 3), ("imagenet4", 1, 2, None, 3), ("imagenet4", 0, 1, None, 3),
                                                             ("cifar8", 1, 2, "lowrate", 3), ("mnist2", 1, 2, None, 3), ("cifar8", 0, 1, None, 3),
-                                                            ("cifar8", 1, 1, None, 2), ("cifar8", 1, 1, "lowrate", 2)])
+                                                            ("cifar8", 1, 1, None, 2), ("cifar8", 1, 1, "lowrate", 2),
+                                                            ("cifar8", 1, 1, None, 4), ("cifar8", 1, 2, "lowrate", 4), ("imagenet4", 0, 1, None, 4),
+                                                            ("mnist2", 1, 2, None, 4)])
 def test_full_width_oracle_word_parity(name, bitswap, n, regime, cdf_spec):
     """BASELINE configs 1 (MNIST nz = 2 at its real width: reswidth 63 padded to 64, Z = 256, X = 1024,
     mnist_compress.py:85-86,107), 2, 3 and 5, and the 8-layer BB-ANS schedule (cifar_compress.py --bitswap 0: the deepest
@@ -419,7 +421,8 @@ def test_full_width_oracle_word_parity(name, bitswap, n, regime, cdf_spec):
     else:
         images = workload.synthetic_blocks(B * n, model.xs, seed=17).view(B, n, -1).to(torch.int32)
     codec = BitSwapCodec(model, zend, zcen, quantbits=10, bitswap=bool(bitswap), cdf_spec=cdf_spec)
-    assert BitSwapCodec(model, zend, zcen, quantbits=10).cdf_spec == 3       # the default since round 5
+    from bitswap_amd.meta import DEFAULT_CDF_SPEC
+    assert BitSwapCodec(model, zend, zcen, quantbits=10).cdf_spec == DEFAULT_CDF_SPEC
     assert codec.cdf_spec == cdf_spec and all(s is not None for s in codec.zstep[:-1]) and codec.zstep[-1] is None
     from bitswap_amd import hip
     # the hand-off of the bench's batch size (>= 2 GB of rows per launch: 64 cumulative values per row, the pop kernel

@@ -382,7 +382,7 @@ def test_ans_class_drop_in(golden):
 @pytest.mark.parametrize("chain", ["chain_mnist_small_bitswap", "chain_mnist_small_bbans", "chain_rgb4_small_bitswap",
                                    "chain_rgb4_small_bbans"])
 @pytest.mark.parametrize("layout", ["linear", "wave"])
-@pytest.mark.parametrize("spec", [1, 2, 3])
+@pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
     """Teacher-forced replay of the reference sender through the HIP kernels: same popped symbols,
     same per-operation state, same final word stream as the reference's Python run -- for the production kernel
@@ -427,7 +427,7 @@ def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
 
 
 @pytest.mark.parametrize("sched", ["bitswap", "bbans"])
-@pytest.mark.parametrize("spec", [1, 2, 3])
+@pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_divergence_horizon_on_the_gpu(golden, sched, spec):
     """How far the HIP kernels follow the reference's OWN word stream: BASELINE configs[0] at its real width,
     one chain of 100 blocks written by the reference's sender on CPU (tests/golden/chain_mnist_full_*.npz; torch.sigmoid
@@ -457,7 +457,7 @@ def test_divergence_horizon_on_the_gpu(golden, sched, spec):
         K = e.shape[1] + 1
         mu_d, sc_d = dev(np.tile(mu, (B, 1))), dev(np.tile(sc, (B, 1)))
         sp = None if steps[tab] is None else spec
-        mode = {2: O.MODE_DET2, 3: O.MODE_DET3}[spec] if steps[tab] is not None else O.MODE_DET
+        mode = O.MODE_OF_SPEC[spec] if steps[tab] is not None else O.MODE_DET
         e_np = xend if tab < 0 else zend[tab]
         if kind == 0:
             cdf = h.logistic_tables(e, mu_d, sc_d, 31, q, layout=h.LAYOUT_WAVE, step=steps[tab], status=st.status, spec=sp)
@@ -488,7 +488,7 @@ def test_divergence_horizon_on_the_gpu(golden, sched, spec):
 
 
 @pytest.mark.parametrize("sched", ["bitswap", "bbans"])
-@pytest.mark.parametrize("spec", [1, 2, 3])
+@pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched, spec):
     """bits/dim <= 1e-4 pinned on BASELINE configs[0] at full width, 100 blocks, per CDF spec.  The ideal code
     length of the reference's own 500 operations' symbols (tests/golden/chain_mnist_full_*.npz, written by the reference's
@@ -514,7 +514,7 @@ def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched
         f, _ = h.logistic_fc(e, dev(mu[None]), dev(sc[None]), dev(sym[None]), status, 31, q, step=steps[tab], spec=sp)
         f = f.cpu().numpy().view(np.uint32)[0]
         if nchecked[0] < 40:                                 # HIP == oracle on the first blocks' operations (the rest: horizon test)
-            mode = {2: O.MODE_DET2, 3: O.MODE_DET3}[spec] if steps_np[tab] is not None else O.MODE_DET
+            mode = O.MODE_OF_SPEC[spec] if steps_np[tab] is not None else O.MODE_DET
             e_np = np.ascontiguousarray(xend if tab < 0 else zend[tab])
             fo, _, rc = O.tables(O.logistic_pmf(e_np, mu.astype(np.float64), sc.astype(np.float64), mode, steps_np[tab]), 31, q)
             assert rc == O.OK and np.array_equal(f, fo[np.arange(len(sym)), sym])
@@ -526,7 +526,7 @@ def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched
 
 
 @pytest.mark.parametrize("layout", ["linear", "wave"])
-@pytest.mark.parametrize("spec", [1, 2, 3])
+@pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_full_size_round_trip_property(layout, spec):
     """BASELINE config sizes (D=2048, K=1024 latents; D=3072, K=256 pixels), 64 chains: bits-back
     pop followed by push of the same symbols restores every state exactly; pushing then popping
@@ -618,7 +618,7 @@ def test_wave_layout_tables_and_pop(K):
 
 @pytest.mark.parametrize("K", [256, 512, 1024, 2048])
 @pytest.mark.parametrize("ptype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("spec", [2, 3])
+@pytest.mark.parametrize("spec", [2, 3, 4])
 def test_logistic_spec2_bit_exact_vs_oracle(K, ptype, spec):
     """CDF specs 2 and 3 (uniform bins) on the GPU -- decode flavour in both layouts and encode flavour -- against the
     oracle's C restatements (oracle/bitswap_oracle.c::det2_row_cdf / det3_row_cdf), bit for bit; spec 3 on rows that take
@@ -652,7 +652,7 @@ def test_logistic_spec2_bit_exact_vs_oracle(K, ptype, spec):
     cw, piv = unpermute_wave(wav, K)
     rows = np.arange(D)
     for b in range(B):
-        pmf = O.logistic_pmf(e, mu[b].astype(np.float64), sc[b].astype(np.float64), {2: O.MODE_DET2, 3: O.MODE_DET3}[spec], step)
+        pmf = O.logistic_pmf(e, mu[b].astype(np.float64), sc[b].astype(np.float64), O.MODE_OF_SPEC[spec], step)
         _, want, rc = O.tables(pmf, 31, q)
         assert rc == O.OK
         assert np.array_equal(lin[b][:, : K + 1], want), b
@@ -666,7 +666,7 @@ def test_logistic_spec2_bit_exact_vs_oracle(K, ptype, spec):
         h.logistic_tables(dev(e64), dev(mu[:, :3]), dev(sc[:, :3]), 31, 6, step=dev(uniform_step(e64)), spec=spec)
 
 
-@pytest.mark.parametrize("spec", [1, 2, 3])
+@pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_degenerate_parameters_are_flagged(spec):
     """NaN / Inf / non-positive (mu, scale) from a broken checkpoint: the table kernels set BS_ST_BADTABLE for the
     chain (the reference would trip over its assert at mnist_compress.py:47 or code garbage), later kernels skip it,
@@ -698,7 +698,7 @@ def test_degenerate_parameters_are_flagged(spec):
                                                    (512, 64, np.float64, False), (2048, 64, np.float32, False),
                                                    (1024, 2048, np.float32, False),
                                                    (256, 15872, np.float32, True)])     # D = BS_POP_PIVOT_MAX_D: the LDS limit
-@pytest.mark.parametrize("spec", [2, 3])
+@pytest.mark.parametrize("spec", [2, 3, 4])
 def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_row, spec):
     """BS_LAYOUT_PIVOT (64 cumulative values per row; bs_rans_pop_pivot rebuilds the symbol's group of bins with the table
     kernel's arithmetic) against BS_LAYOUT_WAVE (the whole integer row in HBM) and against the oracle: same symbols, same
@@ -743,7 +743,7 @@ def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_r
     # ... and the oracle (the same CDF spec) agrees
     for bb in (0, 2, 3):
         ost = O.Stack(states[bb], cap=8000 + 2 * D)
-        osym, rc = O.layer_pop(ost, e, mu[bb].astype(np.float64), sc[bb].astype(np.float64), 31, q, {2: O.MODE_DET2, 3: O.MODE_DET3}[spec])
+        osym, rc = O.layer_pop(ost, e, mu[bb].astype(np.float64), sc[bb].astype(np.float64), 31, q, O.MODE_OF_SPEC[spec])
         assert rc == O.OK and np.array_equal(osym, b[0][bb]) and ost.tolist() == b[2][bb]
     # a degenerate chain: flagged by the table kernel, skipped by the pop, the others untouched by it
     sc2 = sc.copy()
@@ -755,7 +755,7 @@ def test_pivot_handoff_pops_the_same_symbols_as_whole_rows(K, D, ptype, shared_r
     assert np.array_equal(sym.cpu().numpy()[[0, 1, 2, 3, 5]], b[0][[0, 1, 2, 3, 5]])
 
 
-@pytest.mark.parametrize("spec", [2, 3])
+@pytest.mark.parametrize("spec", [2, 3, 4])
 def test_cdf_spec2_domain_is_flagged(spec):
     """a row whose anchors leave the +-700 domain of det_exp (scale tiny against the bin width -- reachable
     through the C ABI, never by the reference's models) is outside CDF spec 2: every flavour flags BS_ST_BADTABLE for the
@@ -792,7 +792,7 @@ def test_cdf_spec2_domain_is_flagged(spec):
 
 
 @pytest.mark.parametrize("K", [256, 512, 1024])
-@pytest.mark.parametrize("spec", [1, 2, 3])
+@pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_layer64_kernels_vs_oracle(K, spec):
     """bs_layer_pop64 / bs_layer_push64 (64 states per chain, table row + rANS step in one launch) against the
     oracle: state j of a chain codes dims j, j + 64, ... with the single-state arithmetic (ANS.decode / ANS.encode,
@@ -809,7 +809,7 @@ def test_layer64_kernels_vs_oracle(K, spec):
     step_np = uniform_step(e) if spec >= 2 else None
     step = None if step_np is None else dev(step_np)
     sp = None if step is None else spec
-    mode = {1: O.MODE_DET, 2: O.MODE_DET2, 3: O.MODE_DET3}[spec]
+    mode = O.MODE_OF_SPEC[spec]
     mu = (rng.randn(B, D) * 0.6).astype(np.float32)
     sc = rng.uniform(0.1, 1.0, (B, D)).astype(np.float32)
     cen = rng.randn(D, K)

@@ -127,7 +127,7 @@ def _uniform_rows(rng, D, K, f16=False):
 
 
 @pytest.mark.parametrize("K", [256, 1024, 2048])
-@pytest.mark.parametrize("mode2", [O.MODE_DET2, O.MODE_DET3])
+@pytest.mark.parametrize("mode2", [O.MODE_DET2, O.MODE_DET3, O.MODE_DET4])
 def test_cdf_spec2_agrees_with_spec1_and_torch(K, mode2):
     """CDF specs 2 and 3 (uniform bins: one exponential per group of K/64 bins; spec 3: one reciprocal per block of bins)
     against spec 1 and against the reference formula evaluated by torch (utils/torch/rand.py:67-68 +
@@ -155,7 +155,7 @@ def test_cdf_spec2_agrees_with_spec1_and_torch(K, mode2):
         assert d.max() <= 1 and (d > 0).mean() <= 2e-6
 
 
-@pytest.mark.parametrize("mode2,ulps", [(O.MODE_DET2, 3), (O.MODE_DET3, 6)])
+@pytest.mark.parametrize("mode2,ulps", [(O.MODE_DET2, 3), (O.MODE_DET3, 6), (O.MODE_DET4, 3)])
 def test_cdf_spec2_accuracy_vs_exact(mode2, ulps):
     import mpmath as mp
     mp.mp.prec = 200
@@ -172,7 +172,7 @@ def test_cdf_spec2_accuracy_vs_exact(mode2, ulps):
         assert err <= ulps * 2.2204460492503131e-16, (d, float(err))
 
 
-@pytest.mark.parametrize("mode2", [O.MODE_DET2, O.MODE_DET3])
+@pytest.mark.parametrize("mode2", [O.MODE_DET2, O.MODE_DET3, O.MODE_DET4])
 def test_chain_replay_spec2_matches_reference_words(golden, mode2):
     """The reference sender replayed (teacher-forced) with CDF spec 2 / 3 on every uniform-bin table still yields the
     reference's word stream on the rgb nz=4 chain: its tables equal spec 1's and torch's on these rows."""
@@ -198,7 +198,7 @@ def test_chain_replay_spec2_matches_reference_words(golden, mode2):
         assert st.tolist() == words_to_state(g["sent_words"])
 
 
-@pytest.mark.parametrize("mode2", [O.MODE_DET2, O.MODE_DET3])
+@pytest.mark.parametrize("mode2", [O.MODE_DET2, O.MODE_DET3, O.MODE_DET4])
 def test_cdf_spec2_domain_is_enforced(mode2):
     """spec 2 builds a group of bins from its anchor exp(-t_a), and det_exp clamps at +-700 -- a row with a
     scale so small against the bin width that an anchor (or the last bin of its group) lies beyond would get a cdf that
@@ -222,8 +222,9 @@ def test_cdf_spec2_domain_is_enforced(mode2):
     assert rc == O.OK
 
 
-def test_cdf_spec3_peaked_rows_and_far_tails():
-    """CDF spec 3's two special cases.  (i) Rows whose scale is tiny against the bin width ((K/64) h / scale >= 8: peaked
+@pytest.mark.parametrize("mode3", [O.MODE_DET3, O.MODE_DET4])
+def test_cdf_spec3_peaked_rows_and_far_tails(mode3):
+    """CDF spec 3's (and spec 4's) two special cases.  (i) Rows whose scale is tiny against the bin width ((K/64) h / scale >= 8: peaked
     pixel rows, e.g. the reference's floor scale 2/255/8, mnist_train.py:411) take spec 2's arithmetic: same pmf bits.
     (ii) Groups far out in the lower tail have their anchor exponent clamped at 41 so that the product of a block's 16
     denominators stays finite: their bins -- true cdf below 2^-47 -- still truncate to f = 1, and the table is a valid
@@ -231,9 +232,9 @@ def test_cdf_spec3_peaked_rows_and_far_tails():
     xe = ((np.arange(1, 256) - 127.5) / 127.5 - 1. / 255.)[None].repeat(6, 0)          # ImageBins endpoints, rand.py:134-153
     mu = np.array([-0.9, -0.2, 0.0, 0.3, 0.8, 0.99])
     sc = np.full(6, 2. / 255. / 8.)                                                   # 4 h / scale = 32 >= 8
-    assert np.array_equal(O.logistic_pmf(xe, mu, sc, O.MODE_DET3), O.logistic_pmf(xe, mu, sc, O.MODE_DET2))
+    assert np.array_equal(O.logistic_pmf(xe, mu, sc, mode3), O.logistic_pmf(xe, mu, sc, O.MODE_DET2))
     sc = np.full(6, 0.05)                                                             # 4 h / scale = 0.63: batch inversion
-    p3, p2 = O.logistic_pmf(xe, mu, sc, O.MODE_DET3), O.logistic_pmf(xe, mu, sc, O.MODE_DET2)
+    p3, p2 = O.logistic_pmf(xe, mu, sc, mode3), O.logistic_pmf(xe, mu, sc, O.MODE_DET2)
     assert not np.array_equal(p3, p2) and np.abs(p3 - p2).max() <= 4 * 2.2204460492503131e-16
     # (ii) K = 1024 rows whose lower bins lie 60 .. 300 scales below the mean
     rng = np.random.RandomState(5)
@@ -241,7 +242,7 @@ def test_cdf_spec3_peaked_rows_and_far_tails():
     e = _uniform_rows(rng, D, K)
     mu = rng.uniform(4.0, 20.0, D)
     sc = np.full(D, np.float64(np.float32(0.1)))
-    p1, p3 = O.logistic_pmf(e, mu, sc, O.MODE_DET), O.logistic_pmf(e, mu, sc, O.MODE_DET3)
+    p1, p3 = O.logistic_pmf(e, mu, sc, O.MODE_DET), O.logistic_pmf(e, mu, sc, mode3)
     assert np.isfinite(p3).all() and p3.min() > -1e-16
     f1, c1, rc1 = O.tables(p1, 31, 10)
     f3, c3, rc3 = O.tables(p3, 31, 10)
@@ -279,8 +280,10 @@ def full_chain_ops(g):
 # those low 32 bits -- one word off by one -- and the heads agree again; the reference's receiver would not decode that stream
 # past this word.  Spec 3 (one reciprocal per block of bins, 0.2 ppm) leaves the reference at the first operation of block 33
 # -- pop z_0 under q(z_0 | x), the same table in both schedules -- and never returns.
-HORIZON = {("bitswap", 1): (None, 0), ("bitswap", 2): (None, 1), ("bitswap", 3): (165, None),
-           ("bbans", 1): (None, 0), ("bbans", 2): (None, 0), ("bbans", 3): (165, None)}
+# Spec 4 (round 6: blocks of 8 bins + one Newton correction per quotient, 0.03 ppm like specs 1 and 2) is spec 2 again: all 100
+# blocks, the same single word off by one in the Bit-Swap stream.
+HORIZON = {("bitswap", 1): (None, 0), ("bitswap", 2): (None, 1), ("bitswap", 3): (165, None), ("bitswap", 4): (None, 1),
+           ("bbans", 1): (None, 0), ("bbans", 2): (None, 0), ("bbans", 3): (165, None), ("bbans", 4): (None, 0)}
 
 
 def horizon_of(g, coder, final_words=None):
@@ -299,7 +302,7 @@ def horizon_of(g, coder, final_words=None):
 
 
 @pytest.mark.parametrize("sched", ["bitswap", "bbans"])
-@pytest.mark.parametrize("spec", [1, 2, 3])
+@pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_divergence_horizon_against_the_reference_stream(golden, sched, spec):
     from bitswap_amd.bins import uniform_step
     g = golden(f"chain_mnist_full_{sched}.npz")
@@ -309,7 +312,7 @@ def test_divergence_horizon_against_the_reference_stream(golden, sched, spec):
 
     def coder(kind, tab, q, mu, sc, sym):
         e, h = (xend if tab < 0 else zend[tab]), steps[tab]
-        mode = {2: O.MODE_DET2, 3: O.MODE_DET3}[spec] if h is not None else O.MODE_DET
+        mode = O.MODE_OF_SPEC[spec] if h is not None else O.MODE_DET
         if kind == 0:
             got, rc = O.layer_pop(st, e, mu.astype(np.float64), sc.astype(np.float64), 31, q, mode, h)
         else:
@@ -323,7 +326,7 @@ def test_divergence_horizon_against_the_reference_stream(golden, sched, spec):
         assert ndiff is None or ndiff > 1000          # a fork for good: the rest of the stream is different
 
 
-SPECS = (1, 2, 3)
+SPECS = (1, 2, 3, 4)
 
 
 def ideal_bits_of_full_chain(g, freqs_of_op):
@@ -378,7 +381,7 @@ def test_bits_per_dim_of_the_full_width_reference_chain(golden, sched, spec):
 
     def freqs(tab, q, mu, sc, sym):
         e, h = (xend if tab < 0 else zend[tab]), steps[tab]
-        mode = {2: O.MODE_DET2, 3: O.MODE_DET3}[spec] if h is not None else O.MODE_DET
+        mode = O.MODE_OF_SPEC[spec] if h is not None else O.MODE_DET
         pmf = O.logistic_pmf(np.ascontiguousarray(e), mu.astype(np.float64), sc.astype(np.float64), mode, h)
         f, _, rc = O.tables(pmf, 31, q)
         assert rc == O.OK

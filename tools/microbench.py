@@ -59,7 +59,7 @@ def main():
         wcdf = torch.empty((B, D, hip.wave_ld(K)), dtype=torch.int32, device=dev)
         fo = (torch.empty((B, D), dtype=torch.int32, device=dev), torch.empty((B, D), dtype=torch.int32, device=dev))
         r = dict(B=B, D=D, K=K)
-        for spec, stp in ((1, None), (2, step), (3, step)):
+        for spec, stp in ((1, None), (2, step), (3, step), (4, step)):
             sp = None if stp is None else spec
             t_tab = timeit(lambda: hip.logistic_tables(e, mu, sc, 31, q, out=wcdf, layout=hip.LAYOUT_WAVE, step=stp,
                                                        status=st.status, spec=sp), args.iters)
