@@ -53,11 +53,12 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 # sustained float64 load the chip runs at about 4/4.9 of the nominal clock (tools/probes/instr_rate.hip), so 0.82 here is the
 # practical ceiling
 # (round 5: tools/isa_count.py --blocks, the blocks one row executes -- spec 3's loop holds two arms, a row takes one)
-VALU_SLOTS_PER_ROW = {3: 268, 2: 371, 1: 643}   # CDF spec 3 / 2 (uniform bins, BS_LAYOUT_PIVOT hand-off; +29 with whole rows) / spec 1
+# (round 6, spec 4 = blocks of 8 + one Newton correction per quotient: row head 38 + batch arm 199 + integer tail 64 + store 6)
+VALU_SLOTS_PER_ROW = {4: 307, 3: 268, 2: 371, 1: 643}   # CDF spec 4 / 3 / 2 (uniform bins, BS_LAYOUT_PIVOT hand-off; +29 with whole rows) / spec 1
 WHOLE_ROW_EXTRA_SLOTS = 29
 # float64 flops of one row (64 lanes x [2 per fma + 1 per add/mul/rcp] in that loop): SURVEY 8(d) asks for the FP64
 # utilisation next to the HBM figure.  Vector FP64 peak 78.6 TFLOP/s (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
-FP64_FLOPS_PER_ROW = {3: 229 * 64, 2: 362 * 64, 1: 763 * 64}
+FP64_FLOPS_PER_ROW = {4: 301 * 64, 3: 229 * 64, 2: 362 * 64, 1: 763 * 64}
 FP64_PEAK_TFLOPS = 78.6
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, dense, MI355X_MICROARCH.md (155 measured)
 

@@ -223,7 +223,7 @@ def compress(quantbits, nz, bitswap, gpu, dataset="mnist", experiments=100, ndat
 
 
 def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=False, data=None, params=None,
-                       outdir=".", backend=None, small=None, verbose=True, cdf_spec=meta.DEFAULT_CDF_SPEC):
+                       outdir=".", backend=None, small=None, verbose=True, cdf_spec=None):
     """Receiver only (the reference decodes inside compress(), mnist_compress.py:277-358; a real receiver is another
     process): load the experiment pickles and stream_meta.json a sender wrote under `outdir`, REFUSE to decode unless this
     receiver reproduces the recorded format / CDF specification / conv route, decode every experiment, and assert the
@@ -236,12 +236,17 @@ def decompress_streams(quantbits, nz, bitswap, gpu, dataset="mnist", synthetic=F
     sdir, scheme = stream_dir(outdir, dataset, nz, bitswap)
     written = meta.load(os.path.join(sdir, "stream_meta.json"))
     fmt = written.get("stream_format", "reference")
+    # the receiver takes the CDF spec and the conv arithmetic the record names (a sender's defaults may have moved on since the
+    # stream was written); an explicit cdf_spec argument overrides -- and is then refused by meta.check if it does not match
+    if cdf_spec is None:
+        cdf_spec = meta.receiver_settings(written)["cdf_spec"]
     experiments, ndatapoints = int(written["experiments"]), int(written["ndatapoints"])
     model = workload.synthetic_model(dataset, nz, dev, small=small) if small else load_model(dataset, nz, dev, params, synthetic)
     images = load_images(dataset, data, synthetic or bool(small), model.xs, max(experiments * ndatapoints, 512))
     bins_data = images[: min(len(images), 4096)].view((-1,) + tuple(model.xs))
     zend, zcen = discretize(nz, quantbits, torch.float64, dev, model, dataset, data=bins_data,
                             ppb=2 if (synthetic or small) else 30, cache_dir=os.path.join(outdir, "bins"), save=False)
+    meta.adopt_route(model, written)
     codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=bool(bitswap),
                          backend=_format_backend(fmt, backend, dev), cdf_spec=cdf_spec)
     # Which chains were coded together.  A batch-invariant conv route (the GPU's) does not care: everything in one call.
@@ -308,10 +313,11 @@ def dataset_main(dataset, default_nz, nz_loop=None):
                    help="stream format: the reference's single-state stream, or the opt-in 64-state format")
     p.add_argument('--decompress-only', action='store_true',
                    help="receiver only: decode the pickles a previous run wrote under --outdir (checks stream_meta.json first)")
-    p.add_argument('--cdf-spec', default=meta.DEFAULT_CDF_SPEC, type=int, choices=list(meta.CDF_SPECS),
-                   help="deterministic CDF specification (include/bitswap_hip.h) of the tables whose bins are uniform: 3 = one "
-                        "reciprocal per block of bins (default since round 5), 2 = one per bin (streams of rounds 3-4), "
-                        "1 = one sigmoid per endpoint everywhere (streams written before round 2)")
+    p.add_argument('--cdf-spec', default=None, type=int, choices=list(meta.CDF_SPECS),
+                   help="deterministic CDF specification (include/bitswap_hip.h) of the tables whose bins are uniform.  Senders: "
+                        "default 4 (round 6: blocks of 8 bins, one reciprocal + a Newton correction per quotient); 3 = round 5, "
+                        "2 = rounds 3-4, 1 = one sigmoid per endpoint everywhere (rounds 1-2).  Receivers take the spec the "
+                        "stream's record names unless this flag overrides it")
     p.add_argument('--save-bins', action='store_true',
                    help="write bins fitted on the given test images under the reference's cache names (bins/*.pt)")
     args = p.parse_args()
@@ -413,13 +419,17 @@ def compress_images(images_blocks, quantbits=10, nz=4, bitswap=1, gpu=0, hwc_qui
 
 
 def decompress_image(state, nblocks, quantbits=10, nz=4, gpu=0, setup=None, backend=None, hwc_quirk=False,
-                     expect=None, expect_word=None, cdf_spec=meta.DEFAULT_CDF_SPEC):
+                     expect=None, expect_word=None, cdf_spec=None):
     """demo_decompress.decompress (:69-148): -> [nblocks, 32, 32, 3] uint8 blocks.  A state that is a list of 64
     sub-state lists (container.unpack64) is decoded in the 64-state format.  expect: the sender's fingerprint record
     (the container's sidecar) / expect_word: its CRC-32 (64-state container header): decoding is REFUSED
     (meta.StreamMismatch) unless this receiver's codec reproduces it."""
     model, zend, zcen, dev = setup
     fmt = "wave64" if isinstance(state[0], (list, tuple)) else "reference"
+    if expect is not None:       # configure from the sender's record what a receiver can adopt (meta.receiver_settings)
+        if cdf_spec is None:
+            cdf_spec = meta.receiver_settings(expect)["cdf_spec"]
+        meta.adopt_route(model, expect)
     codec = BitSwapCodec(model, zend, zcen, quantbits=quantbits, bitswap=True, backend=_format_backend(fmt, backend, dev),
                          cdf_spec=cdf_spec)
     mine = meta.fingerprint(codec, chains_per_call=1)

@@ -321,10 +321,11 @@ class BitSwapCodec:
         self.zcen = [zcentres[i].contiguous() for i in range(self.nz)]
         xb = ImageBins(torch.float64, dev, self.X)
         self.xend, self.xcen = xb.endpoints(), xb.centres()   # expanded views, row stride 0
-        # deterministic CDF specification per table (include/bitswap_hip.h): spec `cdf_spec` (3 since round 5: one reciprocal
-        # per block of bins; 2: round 3/4 streams) on every set of uniform-width bins (all latent layers but the top one, and
-        # the pixels), spec 1 elsewhere.  Which tables are uniform is a function of the bins alone, so a receiver built from
-        # the same bins and the same cdf_spec makes the same choice; cdf_spec=1 forces spec 1 everywhere (round 1/2 streams).
+        # deterministic CDF specification per table (include/bitswap_hip.h): spec `cdf_spec` (default meta.DEFAULT_CDF_SPEC -- 4
+        # since round 6: one reciprocal per block of 8 bins + a Newton correction per quotient; 3: round 5; 2: rounds 3-4) on every
+        # set of uniform-width bins (all latent layers but the top one, and the pixels), spec 1 elsewhere.  Which tables are
+        # uniform is a function of the bins alone, so a receiver built from the same bins and the same cdf_spec makes the same
+        # choice; cdf_spec=1 forces spec 1 everywhere (round 1/2 streams).
         from .meta import CDF_SPECS, DEFAULT_CDF_SPEC
         cdf_spec = DEFAULT_CDF_SPEC if cdf_spec is None else int(cdf_spec)
         assert cdf_spec in CDF_SPECS

@@ -493,6 +493,208 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
 }
 
 
+// ---- the wave-specialised shape (round 6): ONE multiplying wavefront per SIMD, the split on wavefronts of its own.
+// What round 6 measured first (tools/probes/mfma_rate.hip, profiles/r06b_mfma_rate.txt): a loop of NOTHING but
+// v_mfma_f32_32x32x16_bf16 on limb operands sustains 1,782 TFLOP/s with one wavefront per SIMD (the chip clocks down to ~1.7 GHz
+// under that load) and only 1,330 with two (on zeros: 2,446 against 1,651 -- the loss is the interleaving of two wavefronts' MFMAs on
+// one matrix pipe, not power).  So the two shapes above were capped by their own occupancy: the o2 shape puts two multiplying
+// wavefronts on every SIMD (ceiling 226.5 GFLOP / 1,330 T = 170 us for the T36 x 256^2 x 8000 launch, measured 219), the one-wave
+// shape splits V in the multiplying wavefront itself, where nothing hides under an MFMA (6 VALU per MFMA).
+// Here a workgroup is 8 wavefronts, two per SIMD, with different jobs:
+//   wavefronts 0-3 (consumers): 64 rows x 128 columns each = 2 x 4 MFMA tiles, 128 accumulator registers.  Their loop holds MFMAs,
+//     the LDS reads of the next column tile's three limb fragments (one tile = 12 MFMAs = 384 cycles ahead: the LDS latency is
+//     always covered) and the six fragment loads of U for the next k block -- no VALU arithmetic at all;
+//   wavefronts 4-7 (producers): wavefront w splits the V stage of the k blocks s = w (mod 4): eight 16-byte loads per lane a whole
+//     ring ahead, the truncation split of the o2 shape (exact), twelve 16-byte LDS stores that leave the stage as MFMA B
+//     fragments.  One wavefront splits for the whole workgroup (the o2 shape split every stage four times), and its VALU burst
+//     runs beside the consumers' MFMAs on the other pipe.
+// A ring of four LDS stages (12 KB each), one s_barrier per k block for all eight wavefronts:
+//   the stage of k block s is written in interval s - 3 (after barrier s - 4: its slot was last read for block s - 4) and first
+//   read at the end of interval s - 1.
+// Same arithmetic as the shapes above, bit for bit: k blocks ascending, X_ORDER9 inside a block, float32 accumulation -- the
+// results do not depend on the shape (asserted by tests/test_codec_gpu.py::test_bf16x3_gemm_shapes_agree_bitwise).
+// Registers: consumers ~200, the kernel is compiled for two wavefronts per SIMD with at most 224 each, so that a 64-register
+// coder wavefront of the other chain group still fits on the SIMD (the o2 shape's 2 x 256 left no room: its GEMMs pushed the
+// serial pops out of their hiding place).
+constexpr int W_BN = 128, W_STAGE = 4 * 3 * 1024, W_NS = 4;
+template <int NPROD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224)))
+void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restrict__ V, float* __restrict__ M, int T, int Cout,
+                           int Cin, int64_t cols, int ncc, int nrt) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, g = lane >> 5;
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);  // an XCD works through a contiguous eighth of the chunk list
+    const int t = wg / (nrt * ncc), rem = wg - t * (nrt * ncc), rt = rem / ncc, cc = rem - rt * ncc;
+    const int co0 = rt * X_BM;
+    const int64_t c0 = (int64_t)cc * W_BN;
+    const int cols_left = (int)min((int64_t)W_BN, cols - c0);
+    const int nk = Cin / X_BK, nrt32 = (Cout + 31) / 32;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int w = wave - 4;
+        const float* vsrc = V + ((int64_t)t * Cin + 8 * g) * cols + c0 + (4 * l32 < cols_left ? 4 * l32 : 0);
+        f32x4 raw[8];                                  // this lane's 8 k (8 g ..) of columns 4 l32 .. + 3 of one k block
+        auto issue = [&](int s) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float* src = vsrc + ((int64_t)s * X_BK + kk) * cols;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[kk]) : "v"(src) : "memory");
+            }
+        };
+        auto write_stage = [&](int s) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the eight loads (issued a ring ago) are here
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
+            char* st = lds + (s & (W_NS - 1)) * W_STAGE + lane * 16;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                uint32_t u0[8], u1[8];
+                float r1[8], r2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u0[e] = __float_as_uint(raw[e][ni]) & 0xffff0000u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r1[e] = raw[e][ni] - __uint_as_float(u0[e]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u1[e] = __float_as_uint(r1[e]) & 0xffff0000u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(u1[e]);
+                Pack8 p0, p1, p2;
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) p0.u[kp] = __builtin_amdgcn_perm(u0[2 * kp + 1], u0[2 * kp], 0x07060302u);
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) p1.u[kp] = __builtin_amdgcn_perm(u1[2 * kp + 1], u1[2 * kp], 0x07060302u);
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) p2.u[kp] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * kp + 1]), __float_as_uint(r2[2 * kp]), 0x07060302u);
+                *reinterpret_cast<u32x4*>(st + (ni * 3 + 0) * 1024) = p0.u;
+                *reinterpret_cast<u32x4*>(st + (ni * 3 + 1) * 1024) = p1.u;
+                *reinterpret_cast<u32x4*>(st + (ni * 3 + 2) * 1024) = p2.u;
+            }
+        };
+        if (w < nk) {
+            issue(w);
+            write_stage(w);
+            if (w + W_NS < nk) issue(w + W_NS);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the stage is in LDS (the loads of the next one stay in flight)
+        __builtin_amdgcn_s_barrier();
+        for (int b = 0; b < nk; ++b) {
+            const int s = b + 3;                       // interval b: the slot of block b - 1 is free
+            if (((s & (W_NS - 1)) == w) && s >= W_NS && s < nk) {
+                write_stage(s);
+                if (s + W_NS < nk) issue(s + W_NS);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- consumers
+    const uint16_t* a_base[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r32 = min(co0 / 32 + wave * 2 + mi, nrt32 - 1);
+        a_base[mi] = Uf + (((int64_t)t * nrt32 + r32) * nk * 3 * 64 + lane) * 8;
+    }
+    bf16x8 a[2][2][3], bq[2][3];
+    auto load_a = [&](int kb, auto P) {
+        constexpr int q = decltype(P)::value;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                const uint16_t* src = a_base[mi] + ((int64_t)kb * 3 + i) * 64 * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(p.u) : "v"(src) : "memory");
+                a[q][mi][i] = p.b;
+            }
+    };
+    auto landed_a = [&](auto P) {
+        constexpr int q = decltype(P)::value;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                p.b = a[q][mi][i];
+                asm volatile("" : "+v"(p.u));
+                a[q][mi][i] = p.b;
+            }
+    };
+    auto read_tile = [&](int s, int ni, int dst) {     // the three limb fragments of column tile ni of k block s
+        const char* st = lds + (s & (W_NS - 1)) * W_STAGE + lane * 16 + ni * 3 * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            Pack8 p;
+            p.u = *reinterpret_cast<const u32x4*>(st + i * 1024);
+            bq[dst][i] = p.b;
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.0f;
+
+    load_a(0, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_s_barrier();                      // stages 0 .. 3 are in LDS
+    read_tile(0, 0, 0);
+    auto step = [&](int b, auto P) {
+        constexpr int q = decltype(P)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if (b + 1 < nk) {
+            load_a(b + 1, std::integral_constant<int, q ^ 1>{});
+            __builtin_amdgcn_s_waitcnt(0x0F76);        // vmcnt(6): all but the six just issued -> the fragments of block b are here
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        landed_a(P);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ni < 3) read_tile(b, ni + 1, (ni + 1) & 1);
+            else if (b + 1 < nk) read_tile(b + 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 9 - NPROD; p < 9; ++p)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][mi][X_ORDER9[p][0]], bq[ni & 1][X_ORDER9[p][1]], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // block b is read everywhere: its slot goes back to the producers
+    };
+    int b = 0;
+    for (; b + 1 < nk; b += 2) {
+        step(b, std::integral_constant<int, 0>{});
+        step(b + 1, std::integral_constant<int, 1>{});
+    }
+    if (b < nk) step(b, std::integral_constant<int, 0>{});
+    float* Mt = M + (int64_t)t * Cout * cols;
+    const int cl = 4 * l32;
+    if (cl < cols_left) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row0 = co0 + wave * 64 + mi * 32 + g * 4;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = row0 + (v >> 2) * 8 + (v & 3);
+                if (row < Cout) {
+                    f32x4 o = {acc[mi][0][v], acc[mi][1][v], acc[mi][2][v], acc[mi][3][v]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Mt + (int64_t)row * cols + c0 + cl));
+                }
+            }
+        }
+    }
+}
+
+
 // (A third shape -- V split ONCE per workgroup, each thread 8 floats fetched straight from global memory two steps ahead, the
 // limbs written to LDS in MFMA B-fragment layout: 44 VALU per wavefront and K step instead of 176 -- was built and measured in
 // round 4, visit N: 232-250 us against 221-239 us for the shape above on the 36 x 256 x 256 x 8000 launch, with or without a
@@ -541,7 +743,15 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     const int shape = shape_env ? atoi(shape_env) : 2;
     const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : !strcmp(diag, "stray_exit") ? 3
                    : !strcmp(diag, "noclaim_late") ? 4 : !strcmp(diag, "noclaim_plainstore") ? 5 : !strcmp(diag, "noclaim_coherent") ? 6 : -1;
-    if (dg < 0 || (shape != 1 && shape != 2) || (dg && nprod != 6) || (dg == 3 && shape != 1) || (dg >= 4 && shape != 2)) return BS_EINVAL;
+    if (dg < 0 || (shape != 1 && shape != 2 && shape != 3) || (dg && nprod != 6) || (dg && shape == 3) || (dg == 3 && shape != 1) || (dg >= 4 && shape != 2)) return BS_EINVAL;
+    if (shape == 3) {                     // wave-specialised: one multiplying wavefront per SIMD, the split on wavefronts of its own
+        const int64_t ncc3 = (cols + W_BN - 1) / W_BN, wgs3 = (int64_t)T * nrt * ncc3;
+        if (wgs3 > 0x7fffffff) return BS_EUNSUPPORTED;
+        const size_t shm3 = (size_t)W_NS * W_STAGE;
+        if (nprod == 9) hipLaunchKernelGGL(k_wino_gemm_bf16x3_ws<9>, dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt);
+        else hipLaunchKernelGGL(k_wino_gemm_bf16x3_ws<6>, dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt);
+        return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
+    }
 #define BS_X3_O2(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<NP, CL, ST>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt)
 #define BS_X3_O1(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3<NP, 0, CL, ST>), dim3((unsigned)wgs), dim3(X_NT), shm, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc, (int)nrt)
     if (shape == 2) {                     // two workgroups of 256 x 128 per CU (default)

@@ -430,6 +430,16 @@ class Model(nn.Module):
                             self._ufrags[u.data_ptr()] = (u, _hip.frags_bf16x3(u))   # the tensor itself pins the address
         return self
 
+    def set_gemm_arith(self, arith):
+        """fp32 | bf16x3 | bf16x3x9 for the ResNet products of the fused route (see __init__); rebuilds the weight fragments.
+        Receivers call it with the arithmetic the stream's fingerprint names (meta.adopt_route)."""
+        assert arith in ("fp32", "bf16x3", "bf16x3x9"), arith
+        if arith != self.gemm_arith:
+            self.gemm_arith = arith
+            if self.fused:
+                self.fuse()
+        return self
+
     @staticmethod
     def _conv_nb(m, x, padded=False):
         return F.conv2d(x, m._wp if (padded and m._wp is not None) else m._w, None, stride=m.stride, padding=m.padding)

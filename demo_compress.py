@@ -25,7 +25,7 @@ if __name__ == '__main__':
     ap.add_argument('--params', default=None)
     ap.add_argument('--format', default="reference", choices=["reference", "wave64"],
                     help="reference: the reference's stream/container; wave64: the opt-in 64-state format (own container)")
-    ap.add_argument('--cdf-spec', default=meta.DEFAULT_CDF_SPEC, type=int, choices=list(meta.CDF_SPECS), help="deterministic CDF specification (see include/bitswap_hip.h)")
+    ap.add_argument('--cdf-spec', default=None, type=int, choices=list(meta.CDF_SPECS), help="deterministic CDF specification (see include/bitswap_hip.h)")
     args = ap.parse_args()
     if args.gpu is None:
         print("Give GPU index (0, 1, 2 etc.).")

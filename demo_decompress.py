@@ -16,7 +16,7 @@ if __name__ == '__main__':
     ap.add_argument('--gpu', default=None, type=int)
     ap.add_argument('--synthetic', action='store_true')
     ap.add_argument('--params', default=None)
-    ap.add_argument('--cdf-spec', default=meta.DEFAULT_CDF_SPEC, type=int, choices=list(meta.CDF_SPECS),
+    ap.add_argument('--cdf-spec', default=None, type=int, choices=list(meta.CDF_SPECS),
                     help="deterministic CDF specification the stream was written with (1: streams from before round 2)")
     args = ap.parse_args()
     if args.gpu is None:
@@ -38,7 +38,7 @@ if __name__ == '__main__':
     expect = meta.load(side) if os.path.exists(side) else None
     if expect is None and not container.is_pack64(arr):
         print(f"no {os.path.basename(side)} next to the container (the reference writes none): decoding with this build's "
-              f"defaults, CDF spec {args.cdf_spec}; a stream written with other settings decodes to noise")
+              f"defaults, CDF spec {args.cdf_spec or meta.DEFAULT_CDF_SPEC}; a stream written with other settings decodes to noise")
     blocks, _ = cli.decompress_image(state, nblocks, quantbits=10, nz=4, gpu=args.gpu, setup=setup, expect=expect,
                                      expect_word=container.fingerprint64(arr), cdf_spec=args.cdf_spec)
     img = tiling.unextract_blocks(blocks, h, w)

@@ -98,7 +98,7 @@ class OracleBackend:
         return self.uniform_step(endpoints)
 
     # CDF specification of tables of uniform-width bins (2 or 3); the codec sets it from its cdf_spec, like HipBackend's
-    cdf_spec = 3      # (a codec sets it from its own cdf_spec; 3 = what the product defaulted to when this class was written)
+    cdf_spec = 4      # (a codec sets it from its own cdf_spec; 4 = the product's default, bitswap_amd/meta.py)
 
     def _mode(self, step):
         if step is not None and self.mode == O.MODE_DET:

@@ -215,7 +215,7 @@ def test_cli_experiment_artefacts(tmp_path):
         assert isinstance(st, list) and st[-1] >= 1 << 32
     import json
     meta = json.load(open(tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap" / "stream_meta.json"))
-    assert meta["stream_format"] == "reference" and meta["cdf_spec"] == {"z": [1, 1], "x": 3}   # latents K = 64: spec 1; pixels K = 256: the uniform-bin spec (3)
+    assert meta["stream_format"] == "reference" and meta["cdf_spec"] == {"z": [1, 1], "x": 4}   # latents K = 64: spec 1; pixels K = 256: the default uniform-bin spec (4)
     assert meta["conv_route"]["chains_per_call"] == 3 and meta["world_size"] == 1
     # net bit rate formula (:254,258): cumulative nets * xdim * ndatapoints = words added * 32
     assert np.all(r["total"] > 0) and np.isfinite(r["elbos"]).all()
@@ -580,6 +580,13 @@ def test_stream_fingerprint_is_enforced_by_receivers(tmp_path):
     with pytest.raises(meta.StreamMismatch, match="cdf_spec"):
         cli.decompress_streams(8, 2, 1, 0, dataset="mnist", outdir=str(tmp_path), backend=ob, small=8, verbose=False,
                                cdf_spec=1)
+    # a receiver that is not told a spec takes the one the record names: streams written with an older default (here: 2) decode
+    cli.compress(8, 2, 0, 0, dataset="mnist", experiments=2, ndatapoints=2, decompress=False, outdir=str(tmp_path),
+                 backend=OracleBackend(O.MODE_DET), small=8, verbose=False, cdf_spec=2)
+    old = json.load(open(tmp_path / "bitstreams" / "mnist" / "nz2" / "BB-ANS" / "stream_meta.json"))
+    assert meta.receiver_settings(old) == {"cdf_spec": 2, "gemm_arith": "fp32"} and meta.DEFAULT_CDF_SPEC != 2
+    assert cli.decompress_streams(8, 2, 0, 0, dataset="mnist", outdir=str(tmp_path), backend=OracleBackend(O.MODE_DET), small=8,
+                                  verbose=False).shape == (2, 2, 1024)
     # ... and so does any receiver if the record names another conv route or stream format
     mp = tmp_path / "bitstreams" / "mnist" / "nz2" / "Bit-Swap" / "stream_meta.json"
     good = json.load(open(mp))
