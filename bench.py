@@ -223,12 +223,18 @@ def exclusive_pass(codec, states, block, rkey, tl, dev):
         tl.reset()
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16, dense, MI355X_MICROARCH.md (sustained on limb data, one wavefront per
+#                                    SIMD, nothing but MFMAs in the loop: 1,782 -- tools/probes/mfma_rate.hip, profiles/r06b_mfma_rate.txt)
+
+
 def gemm_roofline(model, chains, dev, warm=100, reps=100):
     """The kernel that dominates the rocprof summary is not on the entropy path: the Winograd-domain batched GEMM of the
-    conv stacks (bs_wino_gemm_f32, fp32 MFMA).  Its own roofline, at the shape one chain group launches most often
-    (36 transform positions x [C x C] x [C x 16 tiles per block]), HIP events around an exclusive back-to-back loop -- 100
-    launches of warm-up first: the clock of an MI355X follows the load of the last tens of milliseconds, a handful of launches
-    measures the clock history of whatever ran before (profiles/r03b vs r03f: 93 vs 117 TFLOP/s for the same cycle count)."""
+    conv stacks.  Its own roofline, at the shape one chain group launches most often (36 transform positions x [C x C] x
+    [C x 16 tiles per block]), for the kernel the model actually runs: bs_wino_gemm_bf16x3 (default since round 6: six bf16 limb
+    products per float32 product -- `achieved` counts the limb products the matrix pipe executes, against the dense bf16 peak;
+    `fp32_equivalent_TFLOPs` the float32 products they stand for) or bs_wino_gemm_f32 (fp32 MFMA).  HIP events around an
+    exclusive back-to-back loop -- 100 launches of warm-up first: the clock of an MI355X follows the load of the last tens of
+    milliseconds (profiles/r03b vs r03f: 93 vs 117 TFLOP/s for the same cycle count)."""
     try:
         from bitswap_amd import hip
         if not (getattr(model, "fused", False) and getattr(model, "own_gemm", False)):
@@ -240,20 +246,31 @@ def gemm_roofline(model, chains, dev, warm=100, reps=100):
         if not hip.wino_gemm_supported(U, V):
             return None
         out = torch.empty(36, C, cols, device=dev)
+        arith = getattr(model, "gemm_arith", "fp32") if getattr(model, "_ufrags", None) else "fp32"
+        if arith != "fp32":
+            Uf, nprod = hip.frags_bf16x3(U), (9 if arith == "bf16x3x9" else 6)
+            fn = lambda: hip.wino_gemm_bf16x3(Uf, V, nprod, out=out)
+        else:
+            nprod, fn = 1, (lambda: hip.wino_gemm(U, V, out=out))
         for _ in range(warm):
-            hip.wino_gemm(U, V, out=out)
+            fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
         for _ in range(reps):
-            hip.wino_gemm(U, V, out=out)
+            fn()
         b.record()
         torch.cuda.synchronize()
         t = a.elapsed_time(b) / reps * 1e-3
         fl = 2.0 * 36 * C * C * cols
-        return {"kernel": "k_wino_gemm<4,2> (bs_wino_gemm_f32: v_mfma_f32_32x32x2_f32, persistent balanced tiles, LDS-DMA staging)", "bound": "mfma",
-                "shape": f"T36 x [{C}x{C}] x [{C}x{cols}]", "achieved": round(fl / t / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(t * 1e3, 4),
+        peak = MFMA_F32_PEAK_TFLOPS if arith == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        kern = ("k_wino_gemm<4,2> (bs_wino_gemm_f32: v_mfma_f32_32x32x2_f32, persistent balanced tiles, LDS-DMA staging)" if arith == "fp32" else
+                f"k_wino_gemm_bf16x3_ws<{nprod}> (bs_wino_gemm_bf16x3: {nprod} v_mfma_f32_32x32x16_bf16 limb products per float32 product, one "
+                "multiplying wavefront per SIMD, the operand split on wavefronts of its own)")
+        return {"kernel": kern, "bound": "mfma", "arith": arith,
+                "shape": f"T36 x [{C}x{C}] x [{C}x{cols}]", "achieved": round(nprod * fl / t / 1e12, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(nprod * fl / t / 1e12 / peak, 4), "fp32_equivalent_TFLOPs": round(fl / t / 1e12, 1),
+                "avg_launch_ms": round(t * 1e3, 4),
                 "launches": reps, "hbm_bytes_per_launch": int(4 * 36 * C * cols * 2 + 4 * 36 * C * C),
                 "timing": f"exclusive: HIP events around {reps} back-to-back launches on the current stream after {warm} of warm-up"}
     except Exception as e:
@@ -281,20 +298,17 @@ def strong_plan(total, world, name, steps, seed=100):
     return out
 
 
-def stream_words(stack, ln, hd):
-    """One finished chain as the words a sender ships: stack words + the 64-bit head as two (demo container order)."""
-    return np.concatenate([stack[: ln], np.array([hd & 0xffffffff, hd >> 32], dtype=np.uint32)])
-
-
-def gather_and_digest(streams, mine, total, rank):
+def gather_and_digest(parts, mine, total, rank):
     """The path's only exchange (not timed): the finished bitstreams to rank 0 (RCCL over xGMI when world > 1, a local no-op
-    otherwise).  The digest -- CRC-32 over the streams in chain order -- does not depend on how the chains were sharded
-    when the conv route is batch-invariant: the same value at 1, 2, 4 and 8 GPUs (--scaling strong)."""
+    otherwise).  parts: device-side snapshots (stack, len, head) of the chain groups; they are packed ON THE DEVICE and the
+    packed tensor goes straight into the gather (bitswap_amd.dist.gather_streams_device) -- one device-to-host copy, on rank 0.
+    The digest -- CRC-32 over the streams in chain order -- does not depend on how the chains were sharded when the conv route
+    is batch-invariant: the same value at 1, 2, 4 and 8 GPUs (--scaling strong)."""
     import zlib
     from bitswap_amd import dist as bdist
     try:
         tg = time.perf_counter()
-        got = bdist.gather_streams(streams, mine, total)
+        got = bdist.gather_streams_device(parts, mine, total)
         tg = time.perf_counter() - tg
         if rank != 0:
             return None
@@ -302,8 +316,7 @@ def gather_and_digest(streams, mine, total, rank):
         for a in got:
             crc = zlib.crc32(np.ascontiguousarray(a, dtype=np.uint32).tobytes() if a is not None else b"missing", crc)
         return {"chains": len(got), "bytes": 4 * int(sum(len(a) for a in got if a is not None)), "ms": round(tg * 1e3, 2),
-                "complete": all(a is not None for a in got),
-                "own_streams_intact": all(np.array_equal(got[c], a) for c, a in zip(mine, streams)),
+                "complete": all(a is not None for a in got), "packed_on": "device",
                 "crc32_of_streams_in_chain_order": f"{crc:08x}"}
     except Exception as e:   # never lose the bench line to the reporting exchange
         return {"error": repr(e)}
@@ -405,12 +418,8 @@ def run_workload(args, name, B, groups, K, W, dev, rank, world, dist, want_gathe
     # for bits/dim -- RCCL over xGMI when world > 1 (bitswap_amd/dist.py), a local no-op otherwise
     gather = None
     if sent is not None:
-        streams = []
-        for stack, ln, hd in sent:
-            stack, ln, hd = stack.cpu().numpy().view(np.uint32), ln.cpu().numpy(), hd.cpu().numpy().view(np.uint64)
-            streams += [stream_words(stack[b], ln[b], hd[b]) for b in range(stack.shape[0])]
         mine = list(chain_ids) if strong else [rank + world * c for c in range(B)]   # global chain ids, round-robin like shard_chains()
-        gather = gather_and_digest(streams, mine, total if strong else world * B, rank)
+        gather = gather_and_digest(sent, mine, total if strong else world * B, rank)
     if dist is not None:
         tot = torch.tensor([float(bits.sum()), float(B * K * codec.X), float(ok)], device=dev, dtype=torch.float64)
         dist.all_reduce(tot)
@@ -566,12 +575,8 @@ def run_ragged(args, name, chain_ids, lengths, total, K, W, dev, rank, world, di
     nblk = int(sum(lengths))
     bits = float(met["total"].sum())
     gather = None
-    if sent is not None:
-        stack, ln, hd = sent[0].cpu().numpy().view(np.uint32), sent[1].cpu().numpy(), sent[2].cpu().numpy().view(np.uint64)
-        streams = [None] * B
-        for k, i in enumerate(order):
-            streams[i] = stream_words(stack[k], ln[k], hd[k])
-        gather = gather_and_digest(streams, list(chain_ids), total, rank)
+    if sent is not None:      # row k of the ragged state is chain order[k] of this rank's list
+        gather = gather_and_digest(sent, [chain_ids[i] for i in order], total, rank)
     tot = torch.tensor([bits, float(nblk * codec.X), float(ok), float(nblk)], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tot)
@@ -637,12 +642,11 @@ EXTRAS = (
     dict(workload="imagenetcrop4", chains=50, scaling="strong", steps=16, share_of=2, why="configs[3]: one GPU's share (50 of 100 images) on 2 GPUs"),
     dict(workload="imagenetcrop4", chains=25, scaling="strong", steps=16, share_of=4, why="configs[3]: one GPU's share (25 of 100 images) on 4 GPUs"),
     dict(workload="cifar8", chains=1000, groups=2, regime="lowrate", why="peaked tables: a trained model's rate"),
-    dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_GEMM_ARITH": "bf16x3"},
-         why="OPT-IN conv arithmetic, not the headline: the ResNet products as three bf16 limbs per float32 operand, 6 limb products "
-             "per k block on the bf16 matrix cores, float32 accumulate (bs_wino_gemm_bf16x3; error table: profiles/r04_bf16x3_error.json)"),
-    dict(workload="cifar8", chains=100, scaling="strong", env={"BITSWAP_GEMM_ARITH": "bf16x3"},
-         why="OPT-IN conv arithmetic at the reference's own shape (100 chains, forked two-stream step): where the faster GEMM shows "
-             "(DESIGN 3.4; the forked step with it is open again since the packed-addition cause was found and removed)"),
+    dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_GEMM_ARITH": "fp32"},
+         why="the conv arithmetic of rounds 2-5, now the opt-out: the ResNet products on the fp32 matrix pipe (bs_wino_gemm_f32, "
+             "v_mfma_f32_32x32x2_f32) instead of three bf16 limbs per operand on the bf16 pipe (DESIGN 3.4)"),
+    dict(workload="cifar8", chains=100, scaling="strong", env={"BITSWAP_GEMM_ARITH": "fp32"},
+         why="the fp32-MFMA arithmetic at the reference's own shape (100 chains, forked two-stream step)"),
     dict(workload="cifar8", chains=1000, groups=2, env={"BITSWAP_SERIAL_CUS": "32", "BITSWAP_GEMM_CUS": "224"}, tag="cumask32",
          why="EXPERIMENT, a loss (DESIGN 8): CU-masked streams -- the serial pop / push streams on 32 compute units (4 per XCD), the bulk "
              "streams on the other 224 (bs_stream_create_cu_mask); more masks and the bf16x3 pairing: profiles/r05b_cu_mask_ab.txt"),
@@ -710,8 +714,9 @@ def main(args):
     Z, X = codec.Z, codec.X
     arith = getattr(model, "gemm_arith", "fp32") if getattr(model, "_ufrags", None) else "fp32"
     if arith != "fp32":
-        conv_path = conv_path.replace("(fp32;", f"(float32 activations and weights, OPT-IN {arith} arithmetic in the ResNet products: "
+        conv_path = conv_path.replace("(fp32;", f"(float32 activations and weights, {arith} arithmetic in the ResNet products: "
                                       "three bf16 limbs per operand on the bf16 matrix cores, float32 accumulate;")
+        conv_path = conv_path.replace("bs_wino_gemm_f32 (own fp32 MFMA kernel", "bs_wino_gemm_bf16x3 / bs_wino_gemm_f32 for the head products (own MFMA kernels")
     forked = bool(sum(c.forked_steps for c in getattr(codec, "codecs", [codec])))
     del codec, model
 
@@ -742,19 +747,20 @@ def main(args):
     # chains, measured above in a process of its own); the ranks never talk while coding (bitswap_amd/dist.py) and the gather
     # of the finished streams is outside the timed region, so what the prediction leaves out is box-to-box spread only.
     shapes, predicted = None, None
+    headline_dtype = "f32" if arith == "fp32" else arith
     if extra:
         def label(e):
             return (f"{e['workload']}{'' if e.get('bitswap', 1) else '_bbans'}_{e['chains_per_gpu']}"
                     + ("_wave64" if e.get("stream_format") == "wave64" else "")
                     + ("_lowrate" if e.get("regime") == "lowrate" else "")
-                    + ("_" + e["conv_dtype"] if e.get("conv_dtype") not in (None, "f32") else "") + ("_" + e["tag"] if e.get("tag") else ""))
+                    + ("_" + e["conv_dtype"] if e.get("conv_dtype") not in (None, headline_dtype) else "") + ("_" + e["tag"] if e.get("tag") else ""))
         shapes = {label(e): [round(e["value"] / 1e6, 3), e["ms_per_step"], e["lossless"]] for e in extra if "value" in e}
         predicted = {}
         for cfg, wl, bs in (("configs[1] cifar8 Bit-Swap", "cifar8", 1), ("configs[4] imagenet4 BB-ANS", "imagenet4", 0),
                             ("configs[3] imagenetcrop4 ragged", "imagenetcrop4", 1)):
             pick = lambda n: next((e["value"] for e in extra if e.get("workload") == wl and e.get("bitswap", 1) == bs and "value" in e
                                    and e.get("chains_per_gpu") == n and e.get("stream_format", "reference") == "reference"
-                                   and e.get("conv_dtype", "f32") == "f32" and e.get("regime") != "lowrate" and not e.get("tag")), None)
+                                   and e.get("conv_dtype", headline_dtype) == headline_dtype and e.get("regime") != "lowrate" and not e.get("tag")), None)
             v = {1: pick(100), 2: pick(50), 4: pick(25), 8: pick(13)}
             if v[1]:
                 predicted[cfg] = {"Mpixel_per_s": {str(n): (None if x is None else round(n * x / 1e6, 2)) for n, x in v.items()},
@@ -837,7 +843,7 @@ def headline(out, full_path=None):
                             "valu_busy_pmc": (roof.get("valu_busy_pmc") or {}).get("valu_busy"),
                             "hbm_survey_frac": roof.get("hbm_survey_frac"), "hbm_alg_frac": hb.get("frac"),
                             "hbm_traffic_frac": hb.get("traffic_frac"), "fp64_frac": (roof.get("fp64") or {}).get("frac")},
-                 "mfma": pick(mf, ("kernel", "shape", "achieved", "peak", "unit", "frac", "avg_launch_ms", "error"))}
+                 "mfma": pick(mf, ("kernel", "arith", "shape", "achieved", "peak", "unit", "frac", "fp32_equivalent_TFLOPs", "avg_launch_ms", "error"))}
         if hroof["mfma"] and "kernel" in hroof["mfma"]:
             hroof["mfma"]["kernel"] = hroof["mfma"]["kernel"].split(" (")[0]
     cpu = out.get("cpu_baseline")

@@ -735,12 +735,13 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
     }
 #endif
-    // BITSWAP_BF16X3_SHAPE=1 (the one-workgroup-per-CU shape) and BITSWAP_BF16X3_DIAG (noclaim | noclaim_strict: the kernels
+    // BITSWAP_BF16X3_SHAPE=3 (default since round 6: wave-specialised), =2 (two 256 x 128 workgroups per CU: rounds 4-5),
+    // =1 (the one-workgroup-per-CU shape) and BITSWAP_BF16X3_DIAG (noclaim | noclaim_strict: the kernels
     // WITHOUT the whole-register-share claim, with counted or with vmcnt(0) waits) exist for the co-residency diagnostics
     // only: the unclaimed shape-1 kernel gave wrong products beside a small wavefront of another kernel (LABNOTES r04/r05)
     const char* shape_env = getenv("BITSWAP_BF16X3_SHAPE");
     const char* diag = getenv("BITSWAP_BF16X3_DIAG");
-    const int shape = shape_env ? atoi(shape_env) : 2;
+    const int shape = shape_env ? atoi(shape_env) : (diag ? 2 : 3);     // default: the wave-specialised shape (diagnostics: o2)
     const int dg = !diag ? 0 : !strcmp(diag, "noclaim") ? 1 : !strcmp(diag, "noclaim_strict") ? 2 : !strcmp(diag, "stray_exit") ? 3
                    : !strcmp(diag, "noclaim_late") ? 4 : !strcmp(diag, "noclaim_plainstore") ? 5 : !strcmp(diag, "noclaim_coherent") ? 6 : -1;
     if (dg < 0 || (shape != 1 && shape != 2 && shape != 3) || (dg && nprod != 6) || (dg && shape == 3) || (dg == 3 && shape != 1) || (dg >= 4 && shape != 2)) return BS_EINVAL;

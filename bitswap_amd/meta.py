@@ -21,6 +21,12 @@ import zlib
 # the spec the stream's fingerprint names (cli.py), or refuses.
 DEFAULT_CDF_SPEC = 4      # round 6 (spec 3: round 5; spec 2: rounds 3-4; spec 1: rounds 1-2 -- all still decodable)
 CDF_SPECS = (1, 2, 3, 4)
+# Arithmetic of the conv stacks' big Winograd-domain products a sender uses unless BITSWAP_GEMM_ARITH says otherwise (model.py).
+# "bf16x3" since round 6: every float32 operand as three bf16 limbs, 6 limb products per k block on the bf16 matrix cores, float32
+# accumulate (bs_wino_gemm_bf16x3) -- error against float64 no larger than the fp32-MFMA kernel's on all four workloads
+# (profiles/r06e_bf16x3_error.json), batch-invariant like it, but other float32 bits: recorded in the fingerprint, and a receiver
+# takes the arithmetic the record names ("fp32": rounds 2-5, still decodable).
+DEFAULT_GEMM_ARITH = "bf16x3"
 ROUTE_REV = 3    # bump when a kernel or route change alters the float32 bits of (mu, scale) or the integer tables
 
 

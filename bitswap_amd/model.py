@@ -1,5 +1,6 @@
-"""Hierarchical-VAE `Model` for the compression path (PyTorch-ROCm modules; the convolutions -- the only
-MFMA-shaped work on the path -- run on MIOpen or, fused, as Winograd-domain batched GEMMs on rocBLAS/hipBLASLt/CK).
+"""Hierarchical-VAE `Model` for the compression path: PyTorch-ROCm modules whose convolutions -- the only MFMA-shaped work on
+the path -- run, fused, as Winograd-domain batched GEMMs on our own MFMA kernels between HIP transform kernels (no library call
+in the compress path since round 3; the MIOpen / BLAS routes that remain below are env-gated fallbacks for experiments).
 
 Mirrors the class surface of the reference's Model (model/mnist_train.py:17-438; the cifar /
 imagenet variants are identical, imagenetcrop_train.py:306-315,417 makes gen_std a conv):
@@ -258,14 +259,16 @@ class Model(nn.Module):
         # made a stream decodable only with the sender's chains-per-call).  BITSWAP_OWN_GEMM=0 restores the library for
         # experiments; the choice is part of the stream fingerprint (route_fingerprint()).
         self.own_gemm = os.environ.get("BITSWAP_OWN_GEMM", "1") == "1"
-        # arithmetic of those products.  "fp32" (default): v_mfma_f32_32x32x2_f32, float32 in, float32 accumulate.  OPT-IN
-        # "bf16x3" / "bf16x3x9" (round 4): every float32 operand split exactly into three bfloat16 limbs, the
-        # product assembled from 6 / 9 limb products per k block on the bf16 matrix cores (bs_wino_gemm_bf16x3), float32
-        # accumulate, one fixed order per output -- batch-invariant like the fp32 kernel, but a different rounding of
-        # (mu, scale): its own conv route in the stream fingerprint, never the default.  Taken for the products with at
-        # least 128 output channels (the ResNet convolutions: 96 of the 130 products of a block step and ~95 % of their
-        # flops); the 16- / 24-channel head products stay on the fp32 kernel.
-        self.gemm_arith = os.environ.get("BITSWAP_GEMM_ARITH", "fp32")
+        # arithmetic of those products.  "bf16x3" (default since round 6, meta.DEFAULT_GEMM_ARITH) / "bf16x3x9": every float32
+        # operand split exactly into three bfloat16 limbs, the product assembled from 6 / 9 limb products per k block on the bf16
+        # matrix cores (bs_wino_gemm_bf16x3), float32 accumulate, one fixed order per output -- batch-invariant like the fp32
+        # kernel, as accurate against float64 (profiles/r06e_bf16x3_error.json), but a different rounding of (mu, scale): the
+        # fingerprint names it and receivers adopt what the record says (meta.adopt_route).  "fp32" (rounds 2-5):
+        # v_mfma_f32_32x32x2_f32, float32 in, float32 accumulate.  The limb route is taken for the products with at least 128
+        # output channels (the ResNet convolutions: 96 of the 130 products of a block step and ~95 % of their flops); the 16- /
+        # 24-channel head products stay on the fp32 kernel.
+        from .meta import DEFAULT_GEMM_ARITH
+        self.gemm_arith = os.environ.get("BITSWAP_GEMM_ARITH") or DEFAULT_GEMM_ARITH
         assert self.gemm_arith in ("fp32", "bf16x3", "bf16x3x9"), self.gemm_arith
         self._ufrags = {}
         self._cp = reswidth

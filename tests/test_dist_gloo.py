@@ -107,6 +107,27 @@ def test_shard_chains_policies():
     assert dist.shard_chains(3, 1, 0) == [0, 1, 2]
 
 
+def _as_state_parts(streams, split=None):
+    """Word streams (stack words + the head as two words, low first) as the (stack, len, head) tensors of a RansState -- one
+    triple, or two when `split` cuts the chains into two chain groups (what bench.py snapshots on the device)."""
+    import torch
+
+    def one(ss):
+        cap = max([len(a) for a in ss] + [2])
+        stack = torch.zeros((len(ss), cap), dtype=torch.int32)
+        ln = torch.zeros(len(ss), dtype=torch.int32)
+        head = torch.zeros(len(ss), dtype=torch.int64)
+        for k, a in enumerate(ss):
+            a = np.asarray(a, dtype=np.uint32)
+            stack[k, : len(a) - 2] = torch.from_numpy(a[:-2].view(np.int32).copy())
+            ln[k] = len(a) - 2
+            head[k] = int((int(a[-1]) << 32 | int(a[-2])) - (1 << 64) if int(a[-1]) >> 31 else (int(a[-1]) << 32 | int(a[-2])))
+        return stack, ln, head
+    if split is None or not 0 < split < len(streams):
+        return one(streams)
+    return [one(streams[:split]), one(streams[split:])]
+
+
 def _bench():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
@@ -152,9 +173,9 @@ def _worker_strong(rank, world, port, outdir, total=11):
     for name in ("imagenet4", "imagenetcrop4"):
         ids, lengths = bench.strong_plan(total, world, name, 8)[rank]
         streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
-        g = bench.gather_and_digest(streams, ids, total, rank)
+        g = bench.gather_and_digest(_as_state_parts(streams, split=len(streams) // 2), ids, total, rank)
         if rank == 0:
-            assert g["complete"] and g["own_streams_intact"] and g["chains"] == total
+            assert g["complete"] and g["packed_on"] == "device" and g["chains"] == total
             with open(os.path.join(outdir, f"digest_{name}_w{world}.txt"), "w") as f:
                 f.write(g["crc32_of_streams_in_chain_order"])
         else:
@@ -171,7 +192,12 @@ def test_strong_scaling_gather_digest_is_independent_of_world_size(tmp_path):
     for name in ("imagenet4", "imagenetcrop4"):
         ids, lengths = bench.strong_plan(11, 1, name, 8)[0]
         streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
-        one = bench.gather_and_digest(streams, ids, 11, 0)
+        one = bench.gather_and_digest(_as_state_parts(streams), ids, 11, 0)
+        import zlib                                   # ... and the digest is the CRC-32 of the streams themselves, in chain order
+        crc = 0
+        for a in streams:
+            crc = zlib.crc32(a.tobytes(), crc)
+        assert one["crc32_of_streams_in_chain_order"] == f"{crc:08x}"
         assert one["crc32_of_streams_in_chain_order"] == open(tmp_path / f"digest_{name}_w2.txt").read()
 
 
@@ -186,7 +212,7 @@ def test_eight_rank_strong_plan_and_gather(tmp_path):
     for name in ("imagenet4", "imagenetcrop4"):
         ids, lengths = bench.strong_plan(100, 1, name, 8)[0]
         streams = [np.arange(5 + n, dtype=np.uint32) * (c + 1) for c, n in zip(ids, lengths)]
-        one = bench.gather_and_digest(streams, ids, 100, 0)
+        one = bench.gather_and_digest(_as_state_parts(streams), ids, 100, 0)
         assert one["crc32_of_streams_in_chain_order"] == open(tmp_path / f"digest_{name}_w8.txt").read()
 
 

@@ -34,6 +34,11 @@ WORKER = textwrap.dedent('''
     streams = [np.array(s[:-1] + [s[-1] & 0xffffffff, s[-1] >> 32], dtype=np.uint32) for s in state.to_lists()]
     got = dist.gather_streams(streams, [1, 0], 2, collective=True)          # ids out of order on purpose
     assert np.array_equal(got[1], streams[0]) and np.array_equal(got[0], streams[1])
+    # the same streams packed ON THE DEVICE and handed to RCCL as a device tensor (no host round trip in front of the gather)
+    dev = dist.gather_streams_device((state.stack, state.len, state.head), [1, 0], 2, collective=True)
+    assert np.array_equal(dev[1], streams[0]) and np.array_equal(dev[0], streams[1])
+    flat, words = dist.pack_streams_device(state.stack, state.len, state.head)
+    assert flat.is_cuda and words.cpu().tolist() == [len(a) for a in streams]
     rows = dist.gather_rows(met["cma"], [1, 0], 2, collective=True)
     assert np.array_equal(rows[1], met["cma"][0]) and np.array_equal(rows[0], met["cma"][1])
     assert dist.allreduce_sum([1.5, 2.0], collective=True) == [1.5, 2.0]
@@ -92,3 +97,22 @@ def test_bench_strong_scaling_ragged_crop_chains():
     two = _bench(base + ["--gpus", "2"], env={"BENCH_DIST_BACKEND": "gloo"})
     assert two["lossless"] and two["config"]["blocks_total"] == one["config"]["blocks_total"]
     assert two["stream_gather"]["crc32_of_streams_in_chain_order"] == one["stream_gather"]["crc32_of_streams_in_chain_order"]
+
+
+def test_bench_strong_scaling_eight_ranks_gather_on_one_device():
+    """the one collective of the design end to end at the world size north_star's curve ends at.  `bench.py --gpus 8
+    --scaling strong` (BASELINE configs[1]'s 100 chains: 13, 13, 13, 13, 12, 12, 12, 12 per rank) with BENCH_DIST_BACKEND=gloo --
+    eight ranks sharing this one device (RCCL refuses two ranks per GPU) -- codes, packs every rank's streams ON THE DEVICE
+    (dist.pack_streams_device), gathers them to rank 0 and reports the CRC-32 of all 100 streams in chain order: it must be the
+    CRC of the 1-rank run (every conv kernel is batch-invariant, inputs and initial words are functions of the global chain id)."""
+    base = ["--scaling", "strong", "--total-chains", "100", "--steps", "2", "--warmup", "1"]
+    one = _bench(base)
+    assert one["scaling"] == "strong" and one["lossless"] and one["config"]["chains_per_rank"] == [100]
+    g1 = one["stream_gather"]
+    assert g1["complete"] and g1["chains"] == 100 and g1["bytes"] > 100 * 2 * 3072
+    eight = _bench(base + ["--gpus", "8"], env={"BENCH_DIST_BACKEND": "gloo"}, timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["lossless"] and eight["rccl_ranks"] == 0
+    assert eight["config"]["chains_per_rank"] == [13, 13, 13, 13, 12, 12, 12, 12]
+    g8 = eight["stream_gather"]
+    assert g8["complete"] and g8["chains"] == 100 and g8["bytes"] == g1["bytes"]
+    assert g8["crc32_of_streams_in_chain_order"] == g1["crc32_of_streams_in_chain_order"]

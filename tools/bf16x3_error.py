@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Error table of the opt-in bf16x3 conv arithmetic (evidence before any promotion).  Full-width cifar8 model,
+"""Error table of the bf16x3 conv arithmetic (VERDICT r3 #5 / r5 #2c: evidence before any promotion).  Full-width models of ALL
+FOUR workloads (--workload cifar8 | imagenet4 | mnist2 | imagenetcrop4 | all; round 4 measured cifar8 only),
 32 blocks per call, every infer(i) / generate(i) stack: (mu, scale) of the fp32-MFMA route and of the bf16x3 route(s) against
 a float64 evaluation of the plain torch modules (same folded weights); and what the difference means for the rate -- the
 ideal code length of the same symbols under the two routes' integer tables (HIP table kernels, CDF spec 2).
-    python tools/bf16x3_error.py [out.json]"""
+    python tools/bf16x3_error.py [out.json] [--workload all]"""
 import json
 import os
 import sys
@@ -16,16 +17,30 @@ from bitswap_amd import hip, workload  # noqa: E402
 from bitswap_amd.bins import uniform_step  # noqa: E402
 
 
-def build(arith):
+def build(arith, name):
     os.environ["BITSWAP_GEMM_ARITH"] = arith
-    m, zend, zcen = workload.build("cifar8", "cuda", quantbits=10)
+    m, zend, zcen = workload.build(name, "cuda", quantbits=10)
+    assert m.gemm_arith == arith
     m.compress(True)
     return m, zend
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/bf16x3_error.json"
-    routes = {a: build(a) for a in ("fp32", "bf16x3", "bf16x3x9")}
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    out_path = args[0] if args else "/tmp/bf16x3_error.json"
+    wl = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "cifar8"
+    names = ["cifar8", "imagenet4", "mnist2", "imagenetcrop4"] if wl == "all" else [wl]
+    res = {name: one_workload(name) for name in names}
+    ok = all(r["summary"]["bf16x3"]["max_abs_ideal_bits_per_dim_delta"] <= 1e-4 for r in res.values())
+    json.dump({"what": "full width, 32 blocks per call, every stack against a float64 evaluation of the torch modules; "
+                       "ideal code length of the same symbols under each route's integer tables (default CDF spec)",
+               "bits_per_dim_within_1e-4_of_the_fp32_route_everywhere": ok, "workloads": res}, open(out_path, "w"), indent=1)
+    for name, r in res.items():
+        print(name, json.dumps(r["summary"]))
+
+
+def one_workload(name):
+    routes = {a: build(a, name) for a in ("fp32", "bf16x3", "bf16x3x9")}
     base, zend = routes["fp32"]
     # float64 reference: the same module tree in double precision, unfused
     import copy
@@ -79,9 +94,8 @@ def main():
                    "max_dscale_rel": max(r[a]["max_dscale_rel"] for r in rows),
                    "max_abs_ideal_bits_per_dim_delta": max((abs(r[a].get("ideal_bits_per_dim_minus_fp32_route", 0.0)) for r in rows), default=0.0)}
                for a in routes}
-    json.dump({"what": "cifar8 full width, 32 blocks per call, every stack against a float64 evaluation of the torch modules",
-               "summary": summary, "stacks": rows}, open(out_path, "w"), indent=1)
-    print(json.dumps(summary))
+    nfr = {a: len(m._ufrags) for a, (m, _) in routes.items()}
+    return {"summary": summary, "products_on_bf16x3": nfr, "stacks": rows}
 
 
 if __name__ == "__main__":
