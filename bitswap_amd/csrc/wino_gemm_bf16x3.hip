@@ -695,6 +695,227 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
 }
 
 
+// ---- the same, PERSISTENT: one workgroup per CU works through a contiguous range of (t, row tile, 128-column chunk) units without
+// ever draining its LDS ring.  Why: alone, the one-unit-per-workgroup kernel above runs the T36 x 256^2 x 8000 launch in 227 us --
+// 43k cycles per unit of which 24.6k are MFMA.  A workgroup of 8 x 218 registers fills the CU, so nothing overlaps its prologue
+// (the first V stages come from HBM: ~4k cycles) or its epilogue (128 KB of M per unit at the CU's share of HBM: ~9k cycles, and a
+// wavefront only retires when its stores are acknowledged).  Here the producers simply keep going -- the stage of global step
+// G = unit * nk + k block belongs to whichever unit that is -- and a consumer issues its 32 stores and carries on with the next
+// unit's first block, whose operands are already in LDS: the stores drain under the next 1,536 cycles of MFMAs.
+// Needs an even number of k blocks (the U fragments are double-buffered by block parity); otherwise the kernel above runs.
+// Same arithmetic, same bits.
+struct WsUnit {
+    int t, rt, cc;
+};
+__device__ __forceinline__ WsUnit ws_unit(int u, int nrt, int ncc) {
+    WsUnit r;
+    r.t = u / (nrt * ncc);
+    const int rem = u - r.t * (nrt * ncc);
+    r.rt = rem / ncc;
+    r.cc = rem - r.rt * ncc;
+    return r;
+}
+template <int NPROD>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224)))
+void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __restrict__ V, float* __restrict__ M, int T, int Cout,
+                            int Cin, int64_t cols, int ncc, int nrt, int nunits) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, g = lane >> 5;
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);  // an XCD works through a contiguous eighth of the unit list
+    const int u0 = (int)(((int64_t)wg * nunits) / nwg), u1 = (int)(((int64_t)(wg + 1) * nunits) / nwg);
+    const int nk = Cin / X_BK, nrt32 = (Cout + 31) / 32;
+    const int gtot = (u1 - u0) * nk;                   // global steps of this workgroup
+    if (gtot == 0) return;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int w = wave - 4;
+        f32x4 raw[8];
+        auto issue = [&](int G) {
+            const int du = G / nk, kb = G - du * nk;
+            const WsUnit un = ws_unit(u0 + du, nrt, ncc);
+            const int64_t c0 = (int64_t)un.cc * W_BN;
+            const int cols_left = (int)min((int64_t)W_BN, cols - c0);
+            const float* src0 = V + ((int64_t)un.t * Cin + (int64_t)kb * X_BK + 8 * g) * cols + c0 + (4 * l32 < cols_left ? 4 * l32 : 0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float* src = src0 + (int64_t)kk * cols;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[kk]) : "v"(src) : "memory");
+            }
+        };
+        auto write_stage = [&](int G) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the eight loads (issued a ring ago) are here
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
+            char* st = lds + (G & (W_NS - 1)) * W_STAGE + lane * 16;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                uint32_t u0_[8], u1_[8];
+                float r1[8], r2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u0_[e] = __float_as_uint(raw[e][ni]) & 0xffff0000u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r1[e] = raw[e][ni] - __uint_as_float(u0_[e]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u1_[e] = __float_as_uint(r1[e]) & 0xffff0000u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(u1_[e]);
+                Pack8 p0, p1, p2;
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) p0.u[kp] = __builtin_amdgcn_perm(u0_[2 * kp + 1], u0_[2 * kp], 0x07060302u);
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) p1.u[kp] = __builtin_amdgcn_perm(u1_[2 * kp + 1], u1_[2 * kp], 0x07060302u);
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) p2.u[kp] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * kp + 1]), __float_as_uint(r2[2 * kp]), 0x07060302u);
+                *reinterpret_cast<u32x4*>(st + (ni * 3 + 0) * 1024) = p0.u;
+                *reinterpret_cast<u32x4*>(st + (ni * 3 + 1) * 1024) = p1.u;
+                *reinterpret_cast<u32x4*>(st + (ni * 3 + 2) * 1024) = p2.u;
+            }
+        };
+        if (w < gtot) {
+            issue(w);
+            write_stage(w);
+            if (w + W_NS < gtot) issue(w + W_NS);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the stage is in LDS (the loads of the next one stay in flight)
+        __builtin_amdgcn_s_barrier();
+        for (int G = 0; G < gtot; ++G) {
+            const int s = G + 3;                       // interval G: the slot of global step G - 1 is free
+            if (((s & (W_NS - 1)) == w) && s >= W_NS && s < gtot) {
+                write_stage(s);
+                if (s + W_NS < gtot) issue(s + W_NS);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- consumers
+    const uint16_t* a_base[2];
+    auto set_a_base = [&](const WsUnit& un) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int r32 = min(un.rt * (X_BM / 32) + wave * 2 + mi, nrt32 - 1);
+            a_base[mi] = Uf + (((int64_t)un.t * nrt32 + r32) * nk * 3 * 64 + lane) * 8;
+        }
+    };
+    bf16x8 a[2][2][3], bq[2][3];
+    auto load_a = [&](int kb, auto P) {
+        constexpr int q = decltype(P)::value;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                const uint16_t* src = a_base[mi] + ((int64_t)kb * 3 + i) * 64 * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(p.u) : "v"(src) : "memory");
+                a[q][mi][i] = p.b;
+            }
+    };
+    auto landed_a = [&](auto P) {
+        constexpr int q = decltype(P)::value;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pack8 p;
+                p.b = a[q][mi][i];
+                asm volatile("" : "+v"(p.u));
+                a[q][mi][i] = p.b;
+            }
+    };
+    auto read_tile = [&](int G, int ni, int dst) {     // the three limb fragments of column tile ni of global step G
+        const char* st = lds + (G & (W_NS - 1)) * W_STAGE + lane * 16 + ni * 3 * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            Pack8 p;
+            p.u = *reinterpret_cast<const u32x4*>(st + i * 1024);
+            bq[dst][i] = p.b;
+        }
+    };
+    f32x16 acc[2][4];
+    WsUnit un = ws_unit(u0, nrt, ncc);
+    set_a_base(un);
+    load_a(0, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_s_barrier();                      // stages 0 .. 3 are in LDS
+    read_tile(0, 0, 0);
+    // One k block.  P: parity of the block (which fragment buffer).  after_store (wave-uniform): the block right behind the 32
+    // stores of the previous unit -- the wait for this block's fragments must not wait for those stores as well (they drain under
+    // this block's MFMAs): vmcnt(38) = all but the newest 6 loads + 32 stores, instead of vmcnt(6).
+    auto step = [&](int G, int kb_next, bool more, bool after_store, auto P) {
+        constexpr int q = decltype(P)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            load_a(kb_next, std::integral_constant<int, q ^ 1>{});
+            if (after_store) __builtin_amdgcn_s_waitcnt(0x8F76);            // vmcnt(38) = 0b100110: [15:14] = 2, [3:0] = 6
+            else __builtin_amdgcn_s_waitcnt(0x0F76);                        // vmcnt(6)
+        } else {
+            if (after_store) __builtin_amdgcn_s_waitcnt(0x8F70);            // vmcnt(32): behind the stores, nothing newer
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        landed_a(P);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ni < 3) read_tile(G, ni + 1, (ni + 1) & 1);
+            else if (G + 1 < gtot) read_tile(G + 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 9 - NPROD; p < 9; ++p)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][mi][X_ORDER9[p][0]], bq[ni & 1][X_ORDER9[p][1]], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // the block is read everywhere: its slot goes back to the producers
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    int G = 0;
+    for (int u = u0; u < u1; ++u) {
+        const bool last_unit = u + 1 == u1;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[mi][ni][v] = 0.0f;
+        for (int b = 0; b < nk; b += 2) {               // blocks b (even), b + 1 (odd): nk is even
+            step(G, b + 1, true, b == 0 && u != u0, C0{});
+            ++G;
+            const bool tail = b + 2 == nk;              // the unit's last block: its prefetch is block 0 of the NEXT unit
+            if (tail) set_a_base(ws_unit(last_unit ? u : u + 1, nrt, ncc));
+            step(G, tail ? 0 : b + 2, !(tail && last_unit), false, C1{});
+            ++G;
+        }
+        const int co0 = un.rt * X_BM;
+        const int64_t c0 = (int64_t)un.cc * W_BN;
+        const int cols_left = (int)min((int64_t)W_BN, cols - c0);
+        float* Mt = M + (int64_t)un.t * Cout * cols;
+        const int cl = 4 * l32;
+        if (cl < cols_left) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row0 = co0 + wave * 64 + mi * 32 + g * 4;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = row0 + (v >> 2) * 8 + (v & 3);
+                    if (row < Cout) {
+                        f32x4 o = {acc[mi][0][v], acc[mi][1][v], acc[mi][2][v], acc[mi][3][v]};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(Mt + (int64_t)row * cols + c0 + cl));
+                    }
+                }
+            }
+        }
+        if (!last_unit) un = ws_unit(u + 1, nrt, ncc);
+    }
+}
+
+
 // (A third shape -- V split ONCE per workgroup, each thread 8 floats fetched straight from global memory two steps ahead, the
 // limbs written to LDS in MFMA B-fragment layout: 44 VALU per wavefront and K step instead of 176 -- was built and measured in
 // round 4, visit N: 232-250 us against 221-239 us for the shape above on the 36 x 256 x 256 x 8000 launch, with or without a
@@ -749,6 +970,20 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         const int64_t ncc3 = (cols + W_BN - 1) / W_BN, wgs3 = (int64_t)T * nrt * ncc3;
         if (wgs3 > 0x7fffffff) return BS_EUNSUPPORTED;
         const size_t shm3 = (size_t)W_NS * W_STAGE;
+        const int nk3 = Cin / X_BK;
+        const char* pe = getenv("BITSWAP_BF16X3_PERSISTENT");     // (read per launch, like the shape: tests flip it)
+        const int persistent = pe ? atoi(pe) : 1;
+        if (persistent && nk3 >= 2 && nk3 % 2 == 0) {      // persistent workgroups: one per CU, a contiguous range of units each
+            static const int cus = [] {
+                int dev = 0, n = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                return n > 0 ? n : 256;
+            }();
+            const int nwg = (int)(wgs3 < cus ? wgs3 : cus);
+            if (nprod == 9) hipLaunchKernelGGL(k_wino_gemm_bf16x3_wsp<9>, dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3);
+            else hipLaunchKernelGGL(k_wino_gemm_bf16x3_wsp<6>, dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3);
+            return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
+        }
         if (nprod == 9) hipLaunchKernelGGL(k_wino_gemm_bf16x3_ws<9>, dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt);
         else hipLaunchKernelGGL(k_wino_gemm_bf16x3_ws<6>, dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt);
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;

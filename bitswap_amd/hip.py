@@ -12,7 +12,7 @@ import torch
 
 from . import build as _build
 
-ABI_VERSION = 6   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
+ABI_VERSION = 7   # include/bitswap_hip.h BS_ABI_VERSION this binding was written against
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 ST_OK, ST_UNDERFLOW, ST_OVERFLOW, ST_BADTABLE, ST_BADSYMBOL = 0, 1, 2, 3, 4
 PARAM_F32, PARAM_F64 = 0, 1

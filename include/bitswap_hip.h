@@ -42,8 +42,10 @@ extern "C" {
  * 3: bin_step (CDF spec 2) and status arguments of bs_logistic_tables / bs_logistic_fc; bs_layer_pop64 / _push64
  * 4: BS_LAYOUT_PIVOT and bs_rans_pop_pivot (64 cumulative values per row instead of the whole row)
  * 6: explicit cdf_spec argument (after bin_step) of bs_logistic_tables / _fc, bs_rans_pop_pivot, bs_layer_pop64 / _push64;
- *    CDF spec 3 */
-#define BS_ABI_VERSION 6
+ *    CDF spec 3
+ * 7: CDF spec 4 accepted wherever a cdf_spec is taken; BS_POP_PIVOT_MAX_D (the pivot pop's documented D limit is what its LDS
+ *    allows); bs_wino_gemm_bf16x3 launches its wave-specialised shape by default (same products, same bits) */
+#define BS_ABI_VERSION 7
 /* highest version of the deterministic logistic-CDF specification this library implements;
  * a stream written with one CDF spec can only be decoded with the same one.
  *   spec 1: one float64 sigmoid per bin endpoint; any bins.

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.bs_abi_version.restype = ctypes.c_int
     from bitswap_amd import hip
-    assert lib.bs_abi_version() == hip.ABI_VERSION == 6
+    assert lib.bs_abi_version() == hip.ABI_VERSION == 7
     lib.bs_strerror.restype = ctypes.c_char_p
     assert b"underflow" in lib.bs_strerror(1)
 

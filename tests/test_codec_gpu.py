@@ -997,7 +997,8 @@ def test_bf16x3_gemm_error_and_batch_invariance(T, Cout, Cin, cols, nprod):
 
 @pytest.mark.parametrize("nprod", [6, 9])
 @pytest.mark.parametrize("T,Cout,Cin,cols", [(36, 256, 256, 1600), (64, 256, 256, 644), (36, 128, 64, 208), (3, 96, 48, 100),
-                                              (2, 300, 32, 132), (5, 64, 16, 36), (2, 512, 80, 260), (36, 256, 256, 8000)])
+                                              (2, 300, 32, 132), (5, 64, 16, 36), (2, 512, 80, 260), (36, 256, 256, 8000), (64, 256, 256, 4100),
+                                              (7, 700, 64, 40000)])
 def test_bf16x3_gemm_shapes_agree_bitwise(T, Cout, Cin, cols, nprod, monkeypatch):
     """The three launch shapes of bs_wino_gemm_bf16x3 -- one 256 x 256 workgroup per CU, two 256 x 128 workgroups per CU, and the
     wave-specialised shape of round 6 (four multiplying wavefronts + four splitting wavefronts per workgroup, a ring of four LDS
@@ -1011,16 +1012,18 @@ def test_bf16x3_gemm_shapes_agree_bitwise(T, Cout, Cin, cols, nprod, monkeypatch
     V = (torch.randn((T, Cin, cols), generator=g) * torch.exp(0.5 * torch.randn((T, Cin, 1), generator=g))).to(DEV)
     Uf = hip.frags_bf16x3(U)
     got = {}
-    for shape in ("1", "2", "3"):
-        monkeypatch.setenv("BITSWAP_BF16X3_SHAPE", shape)
+    for shape in ("1", "2", "3", "3p"):       # 3: one unit per workgroup; 3p (default): persistent workgroups, a range of units each
+        monkeypatch.setenv("BITSWAP_BF16X3_SHAPE", shape[0])
+        monkeypatch.setenv("BITSWAP_BF16X3_PERSISTENT", "1" if shape == "3p" else "0")
         out = torch.full((T, Cout, cols), float("nan"), device=DEV)
         got[shape] = hip.wino_gemm_bf16x3(Uf, V, nprod, out=out).clone()
         assert torch.isfinite(got[shape]).all()
         assert torch.equal(hip.wino_gemm_bf16x3(Uf, V, nprod), got[shape])                 # repeatable
-    assert torch.equal(got["3"], got["2"]) and torch.equal(got["3"], got["1"])
+    assert torch.equal(got["3"], got["2"]) and torch.equal(got["3"], got["1"]) and torch.equal(got["3p"], got["3"])
     sub = cols // 2 // 4 * 4
-    monkeypatch.setenv("BITSWAP_BF16X3_SHAPE", "3")
-    assert torch.equal(hip.wino_gemm_bf16x3(Uf, V[:, :, :sub].contiguous(), nprod), got["3"][:, :, :sub])   # batch-invariant
+    monkeypatch.delenv("BITSWAP_BF16X3_SHAPE")
+    monkeypatch.delenv("BITSWAP_BF16X3_PERSISTENT")
+    assert torch.equal(hip.wino_gemm_bf16x3(Uf, V[:, :, :sub].contiguous(), nprod), got["3"][:, :, :sub])   # the default; batch-invariant
 
 
 def test_bf16x3_route_is_fingerprinted_and_lossless(monkeypatch):
