@@ -843,19 +843,19 @@ void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __rest
     load_a(0, std::integral_constant<int, 0>{});
     __builtin_amdgcn_s_barrier();                      // stages 0 .. 3 are in LDS
     read_tile(0, 0, 0);
-    // One k block.  P: parity of the block (which fragment buffer).  after_store (wave-uniform): the block right behind the 32
-    // stores of the previous unit -- the wait for this block's fragments must not wait for those stores as well (they drain under
-    // this block's MFMAs): vmcnt(38) = all but the newest 6 loads + 32 stores, instead of vmcnt(6).
-    auto step = [&](int G, int kb_next, bool more, bool after_store, auto P) {
+    // One k block.  P: parity of the block (which fragment buffer).  waited (wave-uniform): the block right behind the stores
+    // of the previous unit -- its fragments were waited for BEFORE those stores were issued (see the unit loop), so that the
+    // wait here does not have to reach across them.  (The first version counted: vmcnt(38) = the newest 6 loads + 32 stores.  A
+    // wavefront whose rows or columns lie partly outside the matrix issues FEWER than 32 stores -- T7 x 700 x 64 x 40000: the
+    // unit behind (t, row tile 2) multiplied fragments that had not landed.  Counting instructions that may not be issued is
+    // not a wait.)
+    auto step = [&](int G, int kb_next, bool more, bool waited, auto P) {
         constexpr int q = decltype(P)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            load_a(kb_next, std::integral_constant<int, q ^ 1>{});
-            if (after_store) __builtin_amdgcn_s_waitcnt(0x8F76);            // vmcnt(38) = 0b100110: [15:14] = 2, [3:0] = 6
-            else __builtin_amdgcn_s_waitcnt(0x0F76);                        // vmcnt(6)
-        } else {
-            if (after_store) __builtin_amdgcn_s_waitcnt(0x8F70);            // vmcnt(32): behind the stores, nothing newer
-            else __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (more) load_a(kb_next, std::integral_constant<int, q ^ 1>{});
+        if (!waited) {
+            if (more) __builtin_amdgcn_s_waitcnt(0x0F76);                   // vmcnt(6): all but the six just issued
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0)
         }
         landed_a(P);
 #pragma unroll
@@ -891,6 +891,10 @@ void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __rest
             if (tail) set_a_base(ws_unit(last_unit ? u : u + 1, nrt, ncc));
             step(G, tail ? 0 : b + 2, !(tail && last_unit), false, C1{});
             ++G;
+        }
+        if (!last_unit) {       // block 0 of the next unit: requested a whole block ago -- wait for it HERE, in front of the stores
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            landed_a(C0{});
         }
         const int co0 = un.rt * X_BM;
         const int64_t c0 = (int64_t)un.cc * W_BN;
@@ -971,14 +975,20 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         if (wgs3 > 0x7fffffff) return BS_EUNSUPPORTED;
         const size_t shm3 = (size_t)W_NS * W_STAGE;
         const int nk3 = Cin / X_BK;
-        const char* pe = getenv("BITSWAP_BF16X3_PERSISTENT");     // (read per launch, like the shape: tests flip it)
-        const int persistent = pe ? atoi(pe) : 1;
-        if (persistent && nk3 >= 2 && nk3 % 2 == 0) {      // persistent workgroups: one per CU, a contiguous range of units each
-            static const int cus = [] {
-                int dev = 0, n = 256;
-                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-                return n > 0 ? n : 256;
-            }();
+        static const int cus = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        // Persistent workgroups (one per CU, a contiguous range of units each) or one unit per workgroup?  Alone the persistent
+        // kernel is 3-5 % faster at every size (profiles/r06f_gemm_times.txt); in the two-group pipeline of 1000 chains it is
+        // SLOWER (161-165 ms per step against 159: a persistent grid holds every CU for the whole launch, the other chain group's
+        // table and transform kernels -- which do not fit beside it -- wait for its end instead of slipping in between
+        // 16-microsecond workgroups), at 100 chains per call faster (21.9 against 22.4 ms).  So: persistent up to four units per
+        // CU.  BITSWAP_BF16X3_PERSISTENT = 0 / 1 forces either (read per launch: tests flip it).  Same bits either way.
+        const char* pe = getenv("BITSWAP_BF16X3_PERSISTENT");
+        const int persistent = pe ? atoi(pe) : (wgs3 <= 4 * (int64_t)cus);
+        if (persistent && nk3 >= 2 && nk3 % 2 == 0) {
             const int nwg = (int)(wgs3 < cus ? wgs3 : cus);
             if (nprod == 9) hipLaunchKernelGGL(k_wino_gemm_bf16x3_wsp<9>, dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3);
             else hipLaunchKernelGGL(k_wino_gemm_bf16x3_wsp<6>, dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3);

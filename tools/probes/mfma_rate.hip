@@ -57,6 +57,35 @@ __global__ __launch_bounds__(256, WPS) void k_bf16(const u32x4* __restrict__ ops
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// the same multiplies with only NACC accumulator tiles in rotation: consecutive MFMAs on the same accumulator are NACC issues apart
+// (the wave-specialised GEMM of round 6 first rotated 2: is a dependent v_mfma_f32_32x32x16_bf16 ready after 64 cycles?)
+template <int NACC>
+__global__ __launch_bounds__(256, 1) void k_bf16_rot(const u32x4* __restrict__ ops, float* __restrict__ out, int iters) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a[2][3], b[4][3];
+    const u32x4* p = ops + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) % 64 * 18 * 64;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { Pack8 q; q.u = p[i * 64 + lane]; a[i / 3][i % 3] = q.b; }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { Pack8 q; q.u = p[(6 + i) * 64 + lane]; b[i / 3][i % 3] = q.b; }
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[k][v] = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 48; ++m)
+            acc[m % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m & 1][(m >> 1) % 3], b[(m >> 2) & 3][(m >> 4) % 3], acc[m % NACC], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s += acc[k][v];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <int WPS>
 __global__ __launch_bounds__(256, WPS) void k_f32(const float* __restrict__ ops, float* __restrict__ out, int iters) {
     const int lane = threadIdx.x & 63;
@@ -160,6 +189,26 @@ int main() {
             const double cyc = (double)ms * 1e-3 / ((double)reps * iters * 64 * wps);
             printf("f32  32x32x2 , %d wave(s)/SIMD, %-24s: %7.1f us/launch, %7.1f TFLOP/s, %.1f ns per MFMA per SIMD = %.2f GHz-equivalent at 64 cycles\n",
                    wps, "random float32", ms * 1e3 / reps, fl / (ms * 1e-3) / 1e12, cyc * 1e9, 64.0 / (cyc * 1e9));
+        }
+    }
+    {   // accumulators in rotation, one wavefront per SIMD, limb operands (the last operand set uploaded above is "limbs")
+        const int iters = 400, blocks = cus, warm = 40, reps = 40;
+        for (int nacc = 1; nacc <= 8; nacc *= 2) {
+            auto launch = [&]() {
+                if (nacc == 1) hipLaunchKernelGGL(k_bf16_rot<1>, dim3(blocks), dim3(256), 0, 0, d_ops, d_out, iters);
+                else if (nacc == 2) hipLaunchKernelGGL(k_bf16_rot<2>, dim3(blocks), dim3(256), 0, 0, d_ops, d_out, iters);
+                else if (nacc == 4) hipLaunchKernelGGL(k_bf16_rot<4>, dim3(blocks), dim3(256), 0, 0, d_ops, d_out, iters);
+                else hipLaunchKernelGGL(k_bf16_rot<8>, dim3(blocks), dim3(256), 0, 0, d_ops, d_out, iters);
+            };
+            for (int i = 0; i < warm; ++i) launch();
+            hipEventRecord(e0);
+            for (int i = 0; i < reps; ++i) launch();
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double nm = (double)reps * blocks * 4 * iters * 48, fl = nm * 2.0 * 32 * 32 * 16;
+            const double sec = (double)ms * 1e-3 / ((double)reps * iters * 48);
+            printf("bf16 32x32x16, 1 wave/SIMD, limbs, %d accumulator tile(s) in rotation: %7.1f TFLOP/s, %.1f ns per MFMA per SIMD\n",
+                   nacc, fl / (ms * 1e-3) / 1e12, sec * 1e9);
         }
     }
     // what the numbers mean for the conv GEMM's big launch: T36 x [256 x 256] x [256 x 8000], 6 limb products

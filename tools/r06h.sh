@@ -1,0 +1,33 @@
+#!/bin/bash
+# round 6, visit h: (1) MFMA rate by number of accumulator tiles in rotation; (2) which launch shape of bs_wino_gemm_bf16x3 is not
+# repeatable at T7 x 700 x 64 x 40000 (r06f: one assertion of test_bf16x3_gemm_shapes_agree_bitwise)
+TAG=${1:-r06h}
+OUT=$PWD/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_rate tools/probes/mfma_rate.hip && timeout 200 /tmp/mfma_rate > $OUT/${TAG}_mfma_rate.txt 2>&1; cat $OUT/${TAG}_mfma_rate.txt
+python - > $OUT/${TAG}_repeat.txt 2>&1 <<'PY'
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from bitswap_amd import hip
+for (T, Cout, Cin, cols) in [(7, 700, 64, 40000), (7, 700, 64, 4000), (7, 256, 64, 40000), (7, 700, 256, 40000), (36, 256, 256, 8000), (2, 512, 80, 260)]:
+    g = torch.Generator().manual_seed(7 * T + cols)
+    U = ((torch.randn((T, Cout, Cin), generator=g) * torch.exp(torch.randn((T, 1, Cin), generator=g))) / Cin ** 0.5).cuda()
+    V = (torch.randn((T, Cin, cols), generator=g) * torch.exp(0.5 * torch.randn((T, Cin, 1), generator=g))).cuda()
+    Uf = hip.frags_bf16x3(U)
+    ref64 = torch.bmm(U.double(), V.double())
+    base = None
+    for name, shape, pers in (("shape1", "1", "0"), ("o2", "2", "0"), ("ws", "3", "0"), ("ws_persistent", "3", "1")):
+        os.environ["BITSWAP_BF16X3_SHAPE"], os.environ["BITSWAP_BF16X3_PERSISTENT"] = shape, pers
+        first = hip.wino_gemm_bf16x3(Uf, V, 6).clone()
+        base = first if base is None else base
+        nd, worst, where = 0, 0, None
+        for rep in range(12):
+            m = hip.wino_gemm_bf16x3(Uf, V, 6)
+            d = (m != first)
+            if bool(d.any()):
+                nd += 1
+                idx = d.nonzero()
+                where = (idx[:, 0].unique().tolist()[:6], int(idx[:, 1].min()), int(idx[:, 1].max()), int(idx[:, 2].min()), int(idx[:, 2].max()), int(d.sum()))
+        err = float((first.double() - ref64).abs().max() / ref64.abs().max())
+        print(f"T{T} {Cout}x{Cin}x{cols} {name:14s}: {nd}/12 repeats differ, equals shape1: {bool(torch.equal(first, base))}, max err/range {err:.2e}, where (t, rows, cols, n) {where}", flush=True)
+PY
+cat $OUT/${TAG}_repeat.txt
