@@ -517,8 +517,104 @@ __global__ __launch_bounds__(X_NT, 2) void k_wino_gemm_bf16x3_o2(const uint16_t*
 // coder wavefront of the other chain group still fits on the SIMD (the o2 shape's 2 x 256 left no room: its GEMMs pushed the
 // serial pops out of their hiding place).
 constexpr int W_BN = 128, W_STAGE = 4 * 3 * 1024, W_NS = 4;
-template <int NPROD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224)))
+// The producers' half of both wave-specialised kernels.  Producer w (0 .. 3) owns the global steps G = w (mod 4) of its workgroup;
+// src_of(G) = this lane's first 16 bytes of the step's V rows (row kk of its eight at + kk * cols).  NS = ring stages (4 or 8):
+// NS / 4 load sets per producer are in flight, each requested NS steps before its stage is read.  Step G is written right after
+// barrier G - NS (its slot was last read for step G - NS), i.e. in interval G - NS + 1.  Barriers: one before the loop + one per
+// global step, in every wavefront of the workgroup.
+// LAB (lab builds): 1 = load nothing, 8 = neither split nor write, 32 = no barrier in the loop.
+template <int NS, int LAB, typename SrcOf>
+__device__ __forceinline__ void ws_produce(char* lds, int lane, int w, int gtot, int64_t cols, SrcOf&& src_of) {
+    constexpr int DEPTH = NS / 4;
+    static_assert(DEPTH == 1 || DEPTH == 2, "ring of 4 or 8 stages");
+    f32x4 set0[8], set1[8];                          // (set1 is dead code with a ring of 4)
+    auto issue = [&](int G, f32x4 (&raw)[8]) {
+        if constexpr (LAB & 1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
+            return;
+        }
+        const float* src0 = src_of(G);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float* src = src0 + (int64_t)kk * cols;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[kk]) : "v"(src) : "memory");
+        }
+    };
+    auto write_stage = [&](int G, f32x4 (&raw)[8]) {
+        if constexpr (LAB & 8) return;
+        // the set's eight loads are here once everything but the NEWER set (requested behind it, if there is one) has landed
+        if (DEPTH == 2 && G + 4 < gtot) __builtin_amdgcn_s_waitcnt(0x0F78);    // vmcnt(8)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
+        char* st = lds + (G & (NS - 1)) * W_STAGE + lane * 16;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {            // truncation split into three bf16 limbs: exact (as the o2 shape's split_pair)
+            uint32_t u0[8], u1[8];
+            float r1[8], r2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u0[e] = __float_as_uint(raw[e][ni]) & 0xffff0000u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r1[e] = raw[e][ni] - __uint_as_float(u0[e]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u1[e] = __float_as_uint(r1[e]) & 0xffff0000u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(u1[e]);
+            Pack8 p0, p1, p2;
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p0.u[kp] = __builtin_amdgcn_perm(u0[2 * kp + 1], u0[2 * kp], 0x07060302u);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p1.u[kp] = __builtin_amdgcn_perm(u1[2 * kp + 1], u1[2 * kp], 0x07060302u);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) p2.u[kp] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * kp + 1]), __float_as_uint(r2[2 * kp]), 0x07060302u);
+            *reinterpret_cast<u32x4*>(st + (ni * 3 + 0) * 1024) = p0.u;
+            *reinterpret_cast<u32x4*>(st + (ni * 3 + 1) * 1024) = p1.u;
+            *reinterpret_cast<u32x4*>(st + (ni * 3 + 2) * 1024) = p2.u;
+        }
+    };
+    auto barrier = [&]() {
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): what this wavefront wrote is in LDS (its loads stay in flight)
+        __builtin_amdgcn_s_barrier();
+    };
+    // the first NS steps: requested together, written as they land
+    if (w < gtot) issue(w, set0);
+    if (DEPTH == 2 && w + 4 < gtot) issue(w + 4, set1);
+    if (w < gtot) {
+        write_stage(w, set0);
+        if (w + NS < gtot) issue(w + NS, set0);
+    }
+    if (DEPTH == 2 && w + 4 < gtot) {
+        write_stage(w + 4, set1);
+        if (w + 4 + NS < gtot) issue(w + 4 + NS, set1);
+    }
+    barrier();
+    int passed = 0;                                    // loop barriers this wavefront has gone through
+    auto upto = [&](int b) {
+        while (passed < b) {
+            if constexpr (LAB & 32) __builtin_amdgcn_s_waitcnt(0xC07F);
+            else barrier();
+            ++passed;
+        }
+    };
+    for (int G = w + NS; G < gtot; G += 4 * DEPTH) {
+        upto(G - NS + 1);
+        write_stage(G, set0);
+        if (G + NS < gtot) issue(G + NS, set0);
+        if (DEPTH == 2 && G + 4 < gtot) {
+            upto(G + 4 - NS + 1);
+            write_stage(G + 4, set1);
+            if (G + 4 + NS < gtot) issue(G + 4 + NS, set1);
+        }
+    }
+    upto(gtot);
+}
+
+// LAB != 0 (-DBS_GEMM_LAB builds only; WRONG results, timing experiments): 1 = the producers load nothing (they split what is in
+// their registers), 2 = the consumers store nothing, 4 = the consumers load no U fragments, 8 = the producers neither split nor
+// write LDS, 16 = one MFMA per tile instead of 12, 32 = no s_barrier inside the loop
+template <int NPROD, int LAB = 0, int NS = W_NS>
+__global__ __launch_bounds__(512)
 void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restrict__ V, float* __restrict__ M, int T, int Cout,
                            int Cin, int64_t cols, int ncc, int nrt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
@@ -536,61 +632,8 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
-        const int w = wave - 4;
         const float* vsrc = V + ((int64_t)t * Cin + 8 * g) * cols + c0 + (4 * l32 < cols_left ? 4 * l32 : 0);
-        f32x4 raw[8];                                  // this lane's 8 k (8 g ..) of columns 4 l32 .. + 3 of one k block
-        auto issue = [&](int s) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const float* src = vsrc + ((int64_t)s * X_BK + kk) * cols;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[kk]) : "v"(src) : "memory");
-            }
-        };
-        auto write_stage = [&](int s) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the eight loads (issued a ring ago) are here
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
-            char* st = lds + (s & (W_NS - 1)) * W_STAGE + lane * 16;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                uint32_t u0[8], u1[8];
-                float r1[8], r2[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) u0[e] = __float_as_uint(raw[e][ni]) & 0xffff0000u;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r1[e] = raw[e][ni] - __uint_as_float(u0[e]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) u1[e] = __float_as_uint(r1[e]) & 0xffff0000u;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(u1[e]);
-                Pack8 p0, p1, p2;
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) p0.u[kp] = __builtin_amdgcn_perm(u0[2 * kp + 1], u0[2 * kp], 0x07060302u);
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) p1.u[kp] = __builtin_amdgcn_perm(u1[2 * kp + 1], u1[2 * kp], 0x07060302u);
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) p2.u[kp] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * kp + 1]), __float_as_uint(r2[2 * kp]), 0x07060302u);
-                *reinterpret_cast<u32x4*>(st + (ni * 3 + 0) * 1024) = p0.u;
-                *reinterpret_cast<u32x4*>(st + (ni * 3 + 1) * 1024) = p1.u;
-                *reinterpret_cast<u32x4*>(st + (ni * 3 + 2) * 1024) = p2.u;
-            }
-        };
-        if (w < nk) {
-            issue(w);
-            write_stage(w);
-            if (w + W_NS < nk) issue(w + W_NS);
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the stage is in LDS (the loads of the next one stay in flight)
-        __builtin_amdgcn_s_barrier();
-        for (int b = 0; b < nk; ++b) {
-            const int s = b + 3;                       // interval b: the slot of block b - 1 is free
-            if (((s & (W_NS - 1)) == w) && s >= W_NS && s < nk) {
-                write_stage(s);
-                if (s + W_NS < nk) issue(s + W_NS);
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();
-        }
+        ws_produce<NS, LAB>(lds, lane, wave - 4, nk, cols, [&](int s) { return vsrc + (int64_t)s * X_BK * cols; });
         return;
     }
     // ---------------------------------------------------------------------- consumers
@@ -626,7 +669,7 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
             }
     };
     auto read_tile = [&](int s, int ni, int dst) {     // the three limb fragments of column tile ni of k block s
-        const char* st = lds + (s & (W_NS - 1)) * W_STAGE + lane * 16 + ni * 3 * 1024;
+        const char* st = lds + (s & (NS - 1)) * W_STAGE + lane * 16 + ni * 3 * 1024;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             Pack8 p;
@@ -648,7 +691,7 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
     auto step = [&](int b, auto P) {
         constexpr int q = decltype(P)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if (b + 1 < nk) {
+        if (b + 1 < nk && !(LAB & 4)) {
             load_a(b + 1, std::integral_constant<int, q ^ 1>{});
             __builtin_amdgcn_s_waitcnt(0x0F76);        // vmcnt(6): all but the six just issued -> the fragments of block b are here
         } else {
@@ -662,13 +705,13 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
             else if (b + 1 < nk) read_tile(b + 1, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 9 - NPROD; p < 9; ++p)
+            for (int p = ((LAB & 16) ? 8 : 9 - NPROD); p < 9; ++p)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < ((LAB & 16) ? 1 : 2); ++mi)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][mi][X_ORDER9[p][0]], bq[ni & 1][X_ORDER9[p][1]], acc[mi][ni], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                  // block b is read everywhere: its slot goes back to the producers
+        if constexpr (!(LAB & 32)) __builtin_amdgcn_s_barrier();   // block b is read everywhere: its slot goes back to the producers
     };
     int b = 0;
     for (; b + 1 < nk; b += 2) {
@@ -678,6 +721,7 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
     if (b < nk) step(b, std::integral_constant<int, 0>{});
     float* Mt = M + (int64_t)t * Cout * cols;
     const int cl = 4 * l32;
+    if ((LAB & 2) && acc[0][0][0] != 12345.678f) return;
     if (cl < cols_left) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -715,8 +759,8 @@ __device__ __forceinline__ WsUnit ws_unit(int u, int nrt, int ncc) {
     r.cc = rem - r.rt * ncc;
     return r;
 }
-template <int NPROD>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224)))
+template <int NPROD, int NS = W_NS>
+__global__ __launch_bounds__(512)
 void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __restrict__ V, float* __restrict__ M, int T, int Cout,
                             int Cin, int64_t cols, int ncc, int nrt, int nunits) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
@@ -733,65 +777,13 @@ void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __rest
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
-        const int w = wave - 4;
-        f32x4 raw[8];
-        auto issue = [&](int G) {
+        ws_produce<NS, 0>(lds, lane, wave - 4, gtot, cols, [&](int G) {
             const int du = G / nk, kb = G - du * nk;
             const WsUnit un = ws_unit(u0 + du, nrt, ncc);
             const int64_t c0 = (int64_t)un.cc * W_BN;
             const int cols_left = (int)min((int64_t)W_BN, cols - c0);
-            const float* src0 = V + ((int64_t)un.t * Cin + (int64_t)kb * X_BK + 8 * g) * cols + c0 + (4 * l32 < cols_left ? 4 * l32 : 0);
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const float* src = src0 + (int64_t)kk * cols;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[kk]) : "v"(src) : "memory");
-            }
-        };
-        auto write_stage = [&](int G) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the eight loads (issued a ring ago) are here
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
-            char* st = lds + (G & (W_NS - 1)) * W_STAGE + lane * 16;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                uint32_t u0_[8], u1_[8];
-                float r1[8], r2[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) u0_[e] = __float_as_uint(raw[e][ni]) & 0xffff0000u;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r1[e] = raw[e][ni] - __uint_as_float(u0_[e]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) u1_[e] = __float_as_uint(r1[e]) & 0xffff0000u;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r2[e] = r1[e] - __uint_as_float(u1_[e]);
-                Pack8 p0, p1, p2;
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) p0.u[kp] = __builtin_amdgcn_perm(u0_[2 * kp + 1], u0_[2 * kp], 0x07060302u);
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) p1.u[kp] = __builtin_amdgcn_perm(u1_[2 * kp + 1], u1_[2 * kp], 0x07060302u);
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) p2.u[kp] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * kp + 1]), __float_as_uint(r2[2 * kp]), 0x07060302u);
-                *reinterpret_cast<u32x4*>(st + (ni * 3 + 0) * 1024) = p0.u;
-                *reinterpret_cast<u32x4*>(st + (ni * 3 + 1) * 1024) = p1.u;
-                *reinterpret_cast<u32x4*>(st + (ni * 3 + 2) * 1024) = p2.u;
-            }
-        };
-        if (w < gtot) {
-            issue(w);
-            write_stage(w);
-            if (w + W_NS < gtot) issue(w + W_NS);
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the stage is in LDS (the loads of the next one stay in flight)
-        __builtin_amdgcn_s_barrier();
-        for (int G = 0; G < gtot; ++G) {
-            const int s = G + 3;                       // interval G: the slot of global step G - 1 is free
-            if (((s & (W_NS - 1)) == w) && s >= W_NS && s < gtot) {
-                write_stage(s);
-                if (s + W_NS < gtot) issue(s + W_NS);
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();
-        }
+            return V + ((int64_t)un.t * Cin + (int64_t)kb * X_BK + 8 * g) * cols + c0 + (4 * l32 < cols_left ? 4 * l32 : 0);
+        });
         return;
     }
     // ---------------------------------------------------------------------- consumers
@@ -829,7 +821,7 @@ void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __rest
             }
     };
     auto read_tile = [&](int G, int ni, int dst) {     // the three limb fragments of column tile ni of global step G
-        const char* st = lds + (G & (W_NS - 1)) * W_STAGE + lane * 16 + ni * 3 * 1024;
+        const char* st = lds + (G & (NS - 1)) * W_STAGE + lane * 16 + ni * 3 * 1024;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             Pack8 p;
@@ -973,8 +965,34 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
     if (shape == 3) {                     // wave-specialised: one multiplying wavefront per SIMD, the split on wavefronts of its own
         const int64_t ncc3 = (cols + W_BN - 1) / W_BN, wgs3 = (int64_t)T * nrt * ncc3;
         if (wgs3 > 0x7fffffff) return BS_EUNSUPPORTED;
-        const size_t shm3 = (size_t)W_NS * W_STAGE;
+        // ring stages: 4 (48 KB) or 8 (96 KB: two load sets per producer in flight, each requested 8 k blocks ahead)
+        const char* re = getenv("BITSWAP_BF16X3_RING");
+        const int ring = re ? atoi(re) : W_NS;
+        if (ring != 4 && ring != 8) return BS_EINVAL;
+        const size_t shm3 = (size_t)ring * W_STAGE;
+        if (ring == 8) {
+            static bool raised3 = false;
+            if (!raised3) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3_ws<6, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3_ws<9, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3_wsp<6, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_bf16x3_wsp<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised3 = true;
+            }
+        }
         const int nk3 = Cin / X_BK;
+#ifdef BS_GEMM_LAB
+        if (const char* e = getenv("BITSWAP_BF16X3_WSLAB")) {
+            const int lab = atoi(e);
+#define BS_WSLAB(L) case L: hipLaunchKernelGGL((k_wino_gemm_bf16x3_ws<6, L>), dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt); break;
+            switch (lab) {
+                BS_WSLAB(0) BS_WSLAB(1) BS_WSLAB(2) BS_WSLAB(3) BS_WSLAB(4) BS_WSLAB(7) BS_WSLAB(8) BS_WSLAB(9) BS_WSLAB(15) BS_WSLAB(16) BS_WSLAB(23) BS_WSLAB(32) BS_WSLAB(47)
+                default: return BS_EINVAL;
+            }
+#undef BS_WSLAB
+            return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
+        }
+#endif
         static const int cus = [] {
             int dev = 0, n = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -990,12 +1008,16 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         const int persistent = pe ? atoi(pe) : (wgs3 <= 4 * (int64_t)cus);
         if (persistent && nk3 >= 2 && nk3 % 2 == 0) {
             const int nwg = (int)(wgs3 < cus ? wgs3 : cus);
-            if (nprod == 9) hipLaunchKernelGGL(k_wino_gemm_bf16x3_wsp<9>, dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3);
-            else hipLaunchKernelGGL(k_wino_gemm_bf16x3_wsp<6>, dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3);
+#define BS_WSP(NP, RING) hipLaunchKernelGGL((k_wino_gemm_bf16x3_wsp<NP, RING>), dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3)
+            if (nprod == 9) { if (ring == 8) BS_WSP(9, 8); else BS_WSP(9, 4); }
+            else { if (ring == 8) BS_WSP(6, 8); else BS_WSP(6, 4); }
+#undef BS_WSP
             return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
         }
-        if (nprod == 9) hipLaunchKernelGGL(k_wino_gemm_bf16x3_ws<9>, dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt);
-        else hipLaunchKernelGGL(k_wino_gemm_bf16x3_ws<6>, dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt);
+#define BS_WS(NP, RING) hipLaunchKernelGGL((k_wino_gemm_bf16x3_ws<NP, 0, RING>), dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt)
+        if (nprod == 9) { if (ring == 8) BS_WS(9, 8); else BS_WS(9, 4); }
+        else { if (ring == 8) BS_WS(6, 8); else BS_WS(6, 4); }
+#undef BS_WS
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
     }
 #define BS_X3_O2(NP, CL, ST) hipLaunchKernelGGL((k_wino_gemm_bf16x3_o2<NP, CL, ST>), dim3((unsigned)wgs2), dim3(X_NT), shm2, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc2, (int)nrt)
