@@ -534,20 +534,19 @@ __device__ __forceinline__ void ws_produce(char* lds, int lane, int w, int gtot,
             for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
             return;
         }
+        // ORDINARY loads, waited for by the compiler's own s_waitcnt in front of their first use (write_stage, an LDS ring
+        // later).  The first version used asynchronous inline-asm loads with hand-counted waits, like the consumers' fragment
+        // loads: once the producers' control flow grew a second register set and a loop of barriers, the compiler -- which
+        // cannot see that such a register is not written yet -- copied the "results" through a phi right behind the asm
+        // (v_mov of a register whose load had not landed) and the data arrived in registers that by then held addresses:
+        // memory faults on every launch (r06l).  s_barrier and the "memory" asm below keep these loads where they are issued.
         const float* src0 = src_of(G);
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const float* src = src0 + (int64_t)kk * cols;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[kk]) : "v"(src) : "memory");
-        }
+        for (int kk = 0; kk < 8; ++kk) raw[kk] = *reinterpret_cast<const f32x4*>(src0 + (int64_t)kk * cols);
+        asm volatile("" ::: "memory");
     };
     auto write_stage = [&](int G, f32x4 (&raw)[8]) {
         if constexpr (LAB & 8) return;
-        // the set's eight loads are here once everything but the NEWER set (requested behind it, if there is one) has landed
-        if (DEPTH == 2 && G + 4 < gtot) __builtin_amdgcn_s_waitcnt(0x0F78);    // vmcnt(8)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(raw[kk]));
         char* st = lds + (G & (NS - 1)) * W_STAGE + lane * 16;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {            // truncation split into three bf16 limbs: exact (as the o2 shape's split_pair)
