@@ -341,6 +341,9 @@ __device__ __forceinline__ void lds_window(const float* mine, int LW, float (&p)
 // Alone at 400 blocks x 256 channels: <6,6> 114 -> 105 us (5.6 TB/s), with the residual sum 137 -> 113, <8,8> 179 -> 158
 // (6.0 TB/s), tools/probes/fused_probe.py, round 3
 constexpr bool FUSED_NT = true;
+// (Round 6, r06o: the <6,6> flavour capped at 64 registers -- amdgpu_waves_per_eu(8): no spill -- fits beside a workgroup of the
+// bf16x3 GEMM (2 x 224 of a SIMD's 512 registers), its natural 66 do not: 160.0 against 159.0 ms per step.  Co-residency with the
+// GEMM is not what this kernel lacks; not kept.)
 template <int TS_IN, int TS_OUT>
 __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ src, const float* __restrict__ bias,
                                                     const float* __restrict__ res, float* __restrict__ sum_out,
@@ -761,14 +764,32 @@ int bs_wino_fused_f32(const float* src, int ts_in, const float* bias, const floa
     if (N == 0) return BS_OK;
     const int IMG = 256 / T;
     dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
-    const size_t shm = ts_out ? (size_t)IMG * fused_lp(H, W) * sizeof(float) : 0;
+    size_t shm = ts_out ? (size_t)IMG * fused_lp(H, W) * sizeof(float) : 0;
+    // Footprint: this kernel is HBM-bound -- two workgroups per CU already saturate its share of the memory system, six (what its
+    // 26 KB of LDS and 66 registers allow) only take wavefront slots and registers from the OTHER chain group's GEMM / table kernels
+    // running beside it.  Launches big enough to fill the chip therefore claim 64 KB of LDS per workgroup (at most two per CU):
+    // 1000-chain step 161.7 -> 157.3 ms on one box, 161.0 -> 160.0 on another; one per CU is a loss (164.6 .. 183)
+    // (profiles/r06p_fused_footprint_ab.txt, r06q_*).  BITSWAP_FUSED_LDS_MIN = bytes overrides (0: no claim).  Same bits.
+    size_t want = ((int64_t)grid.x * grid.y >= 4096) ? (size_t)64 * 1024 : 0;
+    if (const char* e = getenv("BITSWAP_FUSED_LDS_MIN")) want = (size_t)atol(e);
+    if (want > shm && want <= 160 * 1024) shm = want;
     act &= 3;
     if (const char* e = getenv("BITSWAP_FUSED_PLAIN")) {      // diagnostics: ordinary instead of nontemporal loads of M / stores of V
         if (atoi(e)) act |= 4;
     }
 #define BS_WF(TI, TO)                                                                                             \
-    hipLaunchKernelGGL((k_wino_fused<TI, TO>), grid, block, shm, S(stream), src, bias, res, sum_out, act_out, V, N, C, H, \
-                       W, act)
+    do {                                                                                                          \
+        if (shm > 64 * 1024) {                                                                                    \
+            static bool raised = false;                                                                           \
+            if (!raised) {                                                                                        \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_fused<TI, TO>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+                raised = true;                                                                                    \
+            }                                                                                                     \
+        }                                                                                                         \
+        hipLaunchKernelGGL((k_wino_fused<TI, TO>), grid, block, shm, S(stream), src, bias, res, sum_out, act_out, V, N, C, \
+                           H, W, act);                                                                            \
+    } while (0)
     switch (ts_in * 10 + ts_out) {
         case 6: BS_WF(0, 6); break;
         case 8: BS_WF(0, 8); break;

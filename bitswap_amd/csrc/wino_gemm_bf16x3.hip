@@ -523,10 +523,13 @@ constexpr int W_BN = 128, W_STAGE = 4 * 3 * 1024, W_NS = 4;
 // barrier G - NS (its slot was last read for step G - NS), i.e. in interval G - NS + 1.  Barriers: one before the loop + one per
 // global step, in every wavefront of the workgroup.
 // LAB (lab builds): 1 = load nothing, 8 = neither split nor write, 32 = no barrier in the loop.
-template <int NS, int LAB, typename SrcOf>
+template <int NS, int LAB, int NP, typename SrcOf>
 __device__ __forceinline__ void ws_produce(char* lds, int lane, int w, int gtot, int64_t cols, SrcOf&& src_of) {
-    constexpr int DEPTH = NS / 4;
-    static_assert(DEPTH == 1 || DEPTH == 2, "ring of 4 or 8 stages");
+    // NP producer wavefronts per workgroup (4, 2 or 1): producer w owns the steps G = w (mod NP) and keeps NS / NP (1 or 2) load
+    // sets in flight.  Fewer producers = fewer 224-register wavefronts that only need 90: a SIMD without one has 288 registers
+    // left for the other chain group's table / transform wavefronts (the allocation of a kernel is uniform over its wavefronts)
+    constexpr int DEPTH = NS / NP;
+    static_assert(DEPTH == 1 || DEPTH == 2, "one or two load sets per producer");
     f32x4 set0[8], set1[8];                          // (set1 is dead code with a ring of 4)
     auto issue = [&](int G, f32x4 (&raw)[8]) {
         if constexpr (LAB & 1) {
@@ -578,14 +581,14 @@ __device__ __forceinline__ void ws_produce(char* lds, int lane, int w, int gtot,
     };
     // the first NS steps: requested together, written as they land
     if (w < gtot) issue(w, set0);
-    if (DEPTH == 2 && w + 4 < gtot) issue(w + 4, set1);
+    if (DEPTH == 2 && w + NP < gtot) issue(w + NP, set1);
     if (w < gtot) {
         write_stage(w, set0);
         if (w + NS < gtot) issue(w + NS, set0);
     }
-    if (DEPTH == 2 && w + 4 < gtot) {
-        write_stage(w + 4, set1);
-        if (w + 4 + NS < gtot) issue(w + 4 + NS, set1);
+    if (DEPTH == 2 && w + NP < gtot) {
+        write_stage(w + NP, set1);
+        if (w + NP + NS < gtot) issue(w + NP + NS, set1);
     }
     barrier();
     int passed = 0;                                    // loop barriers this wavefront has gone through
@@ -596,14 +599,14 @@ __device__ __forceinline__ void ws_produce(char* lds, int lane, int w, int gtot,
             ++passed;
         }
     };
-    for (int G = w + NS; G < gtot; G += 4 * DEPTH) {
+    for (int G = w + NS; G < gtot; G += NP * DEPTH) {
         upto(G - NS + 1);
         write_stage(G, set0);
         if (G + NS < gtot) issue(G + NS, set0);
-        if (DEPTH == 2 && G + 4 < gtot) {
-            upto(G + 4 - NS + 1);
-            write_stage(G + 4, set1);
-            if (G + 4 + NS < gtot) issue(G + 4 + NS, set1);
+        if (DEPTH == 2 && G + NP < gtot) {
+            upto(G + NP - NS + 1);
+            write_stage(G + NP, set1);
+            if (G + NP + NS < gtot) issue(G + NP + NS, set1);
         }
     }
     upto(gtot);
@@ -612,8 +615,8 @@ __device__ __forceinline__ void ws_produce(char* lds, int lane, int w, int gtot,
 // LAB != 0 (-DBS_GEMM_LAB builds only; WRONG results, timing experiments): 1 = the producers load nothing (they split what is in
 // their registers), 2 = the consumers store nothing, 4 = the consumers load no U fragments, 8 = the producers neither split nor
 // write LDS, 16 = one MFMA per tile instead of 12, 32 = no s_barrier inside the loop
-template <int NPROD, int LAB = 0, int NS = W_NS>
-__global__ __launch_bounds__(512)
+template <int NPROD, int LAB = 0, int NS = W_NS, int NP = 4>
+__global__ __launch_bounds__(256 + 64 * NP)
 void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restrict__ V, float* __restrict__ M, int T, int Cout,
                            int Cin, int64_t cols, int ncc, int nrt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
@@ -632,7 +635,7 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
         const float* vsrc = V + ((int64_t)t * Cin + 8 * g) * cols + c0 + (4 * l32 < cols_left ? 4 * l32 : 0);
-        ws_produce<NS, LAB>(lds, lane, wave - 4, nk, cols, [&](int s) { return vsrc + (int64_t)s * X_BK * cols; });
+        ws_produce<NS, LAB, NP>(lds, lane, wave - 4, nk, cols, [&](int s) { return vsrc + (int64_t)s * X_BK * cols; });
         return;
     }
     // ---------------------------------------------------------------------- consumers
@@ -758,8 +761,8 @@ __device__ __forceinline__ WsUnit ws_unit(int u, int nrt, int ncc) {
     r.cc = rem - r.rt * ncc;
     return r;
 }
-template <int NPROD, int NS = W_NS>
-__global__ __launch_bounds__(512)
+template <int NPROD, int NS = W_NS, int NP = 4>
+__global__ __launch_bounds__(256 + 64 * NP)
 void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __restrict__ V, float* __restrict__ M, int T, int Cout,
                             int Cin, int64_t cols, int ncc, int nrt, int nunits) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
@@ -776,7 +779,7 @@ void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __rest
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
-        ws_produce<NS, 0>(lds, lane, wave - 4, gtot, cols, [&](int G) {
+        ws_produce<NS, 0, NP>(lds, lane, wave - 4, gtot, cols, [&](int G) {
             const int du = G / nk, kb = G - du * nk;
             const WsUnit un = ws_unit(u0 + du, nrt, ncc);
             const int64_t c0 = (int64_t)un.cc * W_BN;
@@ -980,6 +983,10 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
             }
         }
         const int nk3 = Cin / X_BK;
+        // producer wavefronts per workgroup: 4 (one per SIMD) or 2 (nprod 6, ring of 4 only) -- BITSWAP_BF16X3_PRODUCERS
+        const char* npe = getenv("BITSWAP_BF16X3_PRODUCERS");
+        const int nprw = npe ? atoi(npe) : 4;
+        if (nprw != 4 && nprw != 2) return BS_EINVAL;
 #ifdef BS_GEMM_LAB
         if (const char* e = getenv("BITSWAP_BF16X3_WSLAB")) {
             const int lab = atoi(e);
@@ -1007,15 +1014,19 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
         const int persistent = pe ? atoi(pe) : (wgs3 <= 4 * (int64_t)cus);
         if (persistent && nk3 >= 2 && nk3 % 2 == 0) {
             const int nwg = (int)(wgs3 < cus ? wgs3 : cus);
-#define BS_WSP(NP, RING) hipLaunchKernelGGL((k_wino_gemm_bf16x3_wsp<NP, RING>), dim3((unsigned)nwg), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3)
-            if (nprod == 9) { if (ring == 8) BS_WSP(9, 8); else BS_WSP(9, 4); }
-            else { if (ring == 8) BS_WSP(6, 8); else BS_WSP(6, 4); }
+#define BS_WSP(NPR, RING, NPW) hipLaunchKernelGGL((k_wino_gemm_bf16x3_wsp<NPR, RING, NPW>), dim3((unsigned)nwg), dim3(256 + 64 * NPW), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3)
+            if (nprod == 9) { if (ring == 8) BS_WSP(9, 8, 4); else BS_WSP(9, 4, 4); }
+            else if (ring == 8) BS_WSP(6, 8, 4);
+            else if (nprw == 2) BS_WSP(6, 4, 2);
+            else BS_WSP(6, 4, 4);
 #undef BS_WSP
             return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
         }
-#define BS_WS(NP, RING) hipLaunchKernelGGL((k_wino_gemm_bf16x3_ws<NP, 0, RING>), dim3((unsigned)wgs3), dim3(512), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt)
-        if (nprod == 9) { if (ring == 8) BS_WS(9, 8); else BS_WS(9, 4); }
-        else { if (ring == 8) BS_WS(6, 8); else BS_WS(6, 4); }
+#define BS_WS(NPR, RING, NPW) hipLaunchKernelGGL((k_wino_gemm_bf16x3_ws<NPR, 0, RING, NPW>), dim3((unsigned)wgs3), dim3(256 + 64 * NPW), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt)
+        if (nprod == 9) { if (ring == 8) BS_WS(9, 8, 4); else BS_WS(9, 4, 4); }
+        else if (ring == 8) BS_WS(6, 8, 4);
+        else if (nprw == 2) BS_WS(6, 4, 2);
+        else BS_WS(6, 4, 4);
 #undef BS_WS
         return hipGetLastError() == hipSuccess ? BS_OK : BS_ELAUNCH;
     }

@@ -1013,20 +1013,24 @@ def test_bf16x3_gemm_shapes_agree_bitwise(T, Cout, Cin, cols, nprod, monkeypatch
     Uf = hip.frags_bf16x3(U)
     got = {}
     # 3: one unit per workgroup; 3p: persistent workgroups, a range of units each; r8: a ring of 8 LDS stages instead of 4
-    for shape in ("1", "2", "3", "3p", "3r8", "3pr8"):
+    # n2: two producer wavefronts per workgroup instead of four (nprod 6 only)
+    for shape in ("1", "2", "3", "3p", "3r8", "3pr8") + (("3n2", "3pn2") if nprod == 6 else ()):
         monkeypatch.setenv("BITSWAP_BF16X3_SHAPE", shape[0])
         monkeypatch.setenv("BITSWAP_BF16X3_PERSISTENT", "1" if "p" in shape else "0")
         monkeypatch.setenv("BITSWAP_BF16X3_RING", "8" if shape.endswith("r8") else "4")
+        monkeypatch.setenv("BITSWAP_BF16X3_PRODUCERS", "2" if shape.endswith("n2") else "4")
         out = torch.full((T, Cout, cols), float("nan"), device=DEV)
         got[shape] = hip.wino_gemm_bf16x3(Uf, V, nprod, out=out).clone()
         assert torch.isfinite(got[shape]).all()
         assert torch.equal(hip.wino_gemm_bf16x3(Uf, V, nprod), got[shape])                 # repeatable
     assert torch.equal(got["3"], got["2"]) and torch.equal(got["3"], got["1"]) and torch.equal(got["3p"], got["3"])
     assert torch.equal(got["3r8"], got["3"]) and torch.equal(got["3pr8"], got["3"])
+    assert all(torch.equal(got[k], got["3"]) for k in got)
     sub = cols // 2 // 4 * 4
     monkeypatch.delenv("BITSWAP_BF16X3_SHAPE")
     monkeypatch.delenv("BITSWAP_BF16X3_PERSISTENT")
     monkeypatch.delenv("BITSWAP_BF16X3_RING")
+    monkeypatch.delenv("BITSWAP_BF16X3_PRODUCERS")
     assert torch.equal(hip.wino_gemm_bf16x3(Uf, V[:, :, :sub].contiguous(), nprod), got["3"][:, :, :sub])   # the default; batch-invariant
 
 
