@@ -765,13 +765,17 @@ int bs_wino_fused_f32(const float* src, int ts_in, const float* bias, const floa
     const int IMG = 256 / T;
     dim3 grid((unsigned)C, (unsigned)((N + IMG - 1) / IMG)), block(256);
     size_t shm = ts_out ? (size_t)IMG * fused_lp(H, W) * sizeof(float) : 0;
-    // Footprint: this kernel is HBM-bound -- two workgroups per CU already saturate its share of the memory system, six (what its
-    // 26 KB of LDS and 66 registers allow) only take wavefront slots and registers from the OTHER chain group's GEMM / table kernels
-    // running beside it.  Launches big enough to fill the chip therefore claim 64 KB of LDS per workgroup (at most two per CU):
-    // 1000-chain step 161.7 -> 157.3 ms on one box, 161.0 -> 160.0 on another; one per CU is a loss (164.6 .. 183)
-    // (profiles/r06p_fused_footprint_ab.txt, r06q_*).  BITSWAP_FUSED_LDS_MIN = bytes overrides (0: no claim).  Same bits.
-    size_t want = ((int64_t)grid.x * grid.y >= 4096) ? (size_t)64 * 1024 : 0;
+    // BITSWAP_FUSED_LDS_MIN = bytes (experiment, round 6; default: no claim): claim at least that much LDS per workgroup, i.e. fewer
+    // workgroups of this HBM-bound kernel per CU (160 KB / claim) beside the other chain group's GEMM / table kernels.  Measured
+    // with 64 KB (two per CU) on four boxes (profiles/r06p .. r06s): cifar8 at 1000 chains 161.7 -> 157.3, 161.0 -> 160.0,
+    // 160.2 -> 152.7, 162.4 -> 161.3 ms per step; imagenet4 120.7 -> 122.8, 122.6 -> 126.6 (worse); cifar8 at 1500 chains
+    // 222.6 -> 234.3, 233.8 -> 239.4 (worse); one workgroup per CU 164.6 .. 183.  A gain for one mix of kernels on some boxes,
+    // a loss for the others: not a default.  BITSWAP_FUSED_LDS_WHICH = 66 | 88 restricts the claim to one flavour.  Same bits.
+    size_t want = 0;
     if (const char* e = getenv("BITSWAP_FUSED_LDS_MIN")) want = (size_t)atol(e);
+    if (const char* e = getenv("BITSWAP_FUSED_LDS_WHICH")) {
+        if (atoi(e) != ts_in * 10 + ts_out) want = 0;
+    }
     if (want > shm && want <= 160 * 1024) shm = want;
     act &= 3;
     if (const char* e = getenv("BITSWAP_FUSED_PLAIN")) {      // diagnostics: ordinary instead of nontemporal loads of M / stores of V

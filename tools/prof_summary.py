@@ -188,16 +188,19 @@ def traffic(fetch_json, write_json, workload, out, rows_per_launch):
     (k_logistic<16, float, 3, ...>: BS_LAYOUT_WAVE) and 64 cumulative values per row (<16, float, 4, ...>: BS_LAYOUT_PIVOT),
     and the pop kernels that read them back."""
     def per(path, counter, prefix):
+        """The flavour with the most dispatches among the kernels whose name starts with `prefix` (the CDF spec is the last
+        template argument of k_logistic: whichever spec the run used -- 4 since round 6, 3 in round 5 -- is the one counted)."""
         d = json.load(open(path))
-        for k, v in d.items():
-            if k.startswith(prefix):
-                return v[f"{counter}_per_dispatch"] * 1024.0, v["dispatches"]
-        return None, 0
+        hits = [(v["dispatches"], v[f"{counter}_per_dispatch"] * 1024.0) for k, v in d.items() if k.startswith(prefix)]
+        if not hits:
+            return None, 0
+        n, val = max(hits)
+        return val, n
     res = json.load(open(out)) if os.path.exists(out) else {}
     rows = float(rows_per_launch)
     entry = res.get(workload, {})
     entry.update({"rows_per_launch": int(rows), "fetch_correction": 2.0, "source": [os.path.basename(fetch_json), os.path.basename(write_json)]})
-    for tag, prefix in (("decode", "void k_logistic<16, float, 3, 3"), ("pivot", "void k_logistic<16, float, 4, 3"),
+    for tag, prefix in (("decode", "void k_logistic<16, float, 3, "), ("pivot", "void k_logistic<16, float, 4, "),
                         ("pop_wave", "void k_rans_pop_wave<16"), ("pop_pivot", "void k_rans_pop_pivot<16")):
         f, nf = per(fetch_json, "FETCH_SIZE", prefix)
         w, nw = per(write_json, "WRITE_SIZE", prefix)
