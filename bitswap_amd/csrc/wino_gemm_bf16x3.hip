@@ -645,6 +645,11 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
         const int r32 = min(co0 / 32 + wave * 2 + mi, nrt32 - 1);
         a_base[mi] = Uf + (((int64_t)t * nrt32 + r32) * nk * 3 * 64 + lane) * 8;
     }
+    // The consumers' fragment loads stay asynchronous inline-asm loads with hand-placed waits (load_a / landed_a), unlike the
+    // producers' (see ws_produce): with ordinary loads the compiler's own s_waitcnt is exact in the first block of the unrolled pair
+    // (vmcnt(11) .. vmcnt(6)) but conservative in the second (vmcnt(5) .. vmcnt(0): it waits for the six loads it has just issued,
+    // ~500 cycles per pair of blocks; round 6, measured on the ISA).  There is no phi on this path -- the double buffer is indexed
+    // at compile time -- and every build is held to bitwise equality with the other launch shapes by the GPU suite.
     bf16x8 a[2][2][3], bq[2][3];
     auto load_a = [&](int kb, auto P) {
         constexpr int q = decltype(P)::value;

@@ -642,7 +642,7 @@ class _SymbolForced:
 @pytest.mark.parametrize("sched", ["bitswap", "bbans"])
 def test_gpu_bits_per_dim_matches_reference(golden, sched):
     """north_star: bits/dim within 1e-4 of the reference, with the GPU Model (fused epilogues, Winograd-domain convs
-    forced on by gemm_min_batch = 1) and the production HIP kernels (wave layout, CDF spec 2) in the loop, on the
+    forced on by gemm_min_batch = 1) and the production HIP kernels (wave layout, the default CDF spec) in the loop, on the
     reference's own chain (weights, bins, images, symbols and bit accounting produced by the reference code,
     tests/golden/make_golden.py; accounting = mnist_compress.py:253-261).
 
@@ -793,7 +793,7 @@ def test_wave64_hip_words_equal_oracle(name, q, bitswap):
 
 
 def test_wave64_full_width_and_container_on_gpu():
-    """64-state format at full ImageNet32 width (Z = 2048, X = 3072, K = 1024 / 256, CDF spec 2), 26 chains: words equal
+    """64-state format at full ImageNet32 width (Z = 2048, X = 3072, K = 1024 / 256, the default CDF spec), 26 chains: words equal
     the oracle's, lossless; then the demo path with the 64-state container on a small crop model."""
     from oracle.backend import Oracle64Backend
     from bitswap_amd.codec import Hip64Backend
