@@ -313,10 +313,12 @@ int bs_sigmoid_f64(const double* t, int64_t n, double* out, void* stream);
  *   Cin alone (bitswap_amd/csrc/wino_gemm_bf16x3.hip).  U_frags [T, ceil(Cout/32), Cin/16, 3, 64, 8] bfloat16 bit patterns:
  *   the three limbs of U (U = limb0 + limb1 + limb2 exactly), split and tiled once by the caller as MFMA A fragments --
  *   entry [t, r, kb, i, l, e] = limb i of U[t, 32 r + l % 32, 16 kb + 8 (l / 32) + e], rows beyond Cout zero
- *   (bitswap_amd.hip.frags_bf16x3); V float32 as above, split in registers.  OPT-IN
- *   (BITSWAP_GEMM_ARITH): a different rounding of (mu, scale) than bs_wino_gemm_f32, hence its own conv route in the stream
- *   fingerprint -- sender and receiver must both take it.  No reference counterpart (the reference's convolutions are cuDNN
- *   float32, utils/torch/modules.py:233-241).  Cin % 16 == 0, cols % 4 == 0, 16-byte aligned operands.
+ *   (bitswap_amd.hip.frags_bf16x3); V float32 as above, split inside the kernel -- by producer wavefronts of its own in the
+ *   default launch shape (one multiplying wavefront per SIMD; bitswap_amd/csrc/wino_gemm_bf16x3.hip), every launch shape adding
+ *   the same products in the same order.  The DEFAULT arithmetic of the conv stacks' big products since round 6
+ *   (BITSWAP_GEMM_ARITH=fp32 opts out): a different rounding of (mu, scale) than bs_wino_gemm_f32, hence named in the stream
+ *   fingerprint -- a receiver takes the arithmetic the record names.  No reference counterpart (the reference's convolutions are
+ *   cuDNN float32, utils/torch/modules.py:233-241).  Cin % 16 == 0, cols % 4 == 0, 16-byte aligned operands.
  *
  * bs_small_k_gemm_f32 -- M [T, Cout, cols] = U [T, Cout, Cin] x V [T, Cin, cols] for small Cin (<= 64): the batched product
  *   of the INPUT convolutions of the stacks in the Winograd domain (Cin = zchannels or 4 x image channels); a write of M
