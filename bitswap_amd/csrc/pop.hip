@@ -514,6 +514,13 @@ __global__ __launch_bounds__(64) void k_rans_pop_pivot(uint64_t* __restrict__ he
                 const uint32_t cs = pos == 1 ? piv_L : cs_r;
                 const uint32_t fs = pos == 1 ? f0 : fs_r;
                 mysym = (lane == dk) ? (uint32_t)(L * NPL + pos - 1) : mysym;
+#ifdef BS_POP_PAD     /* sensitivity experiment (round 6): BS_POP_PAD extra float64 VALU instructions per symbol, results unused */
+                {
+                    double pad_ = c;
+#pragma unroll
+                    for (int pi_ = 0; pi_ < BS_POP_PAD; ++pi_) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(pad_));
+                }
+#endif
                 h = (uint64_t)fs * (h >> bits) + (uint64_t)(m - cs);
                 uint32_t hhi = (uint32_t)(h >> 32);
 #if !__has_feature(address_sanitizer)
