@@ -25,6 +25,16 @@
 
 #include "../../include/bitswap_hip.h"
 
+// Issue priority of the transform kernels' wavefronts (k_wino_fused, k_conv3_wino).  In the two-group pipeline such a kernel of
+// one chain group starts beside an OLDER table kernel or GEMM of the other group, and a SIMD picks the wavefront to issue by
+// priority, then age: at equal priority these short memory-bound kernels wait behind long VALU-bound ones.  One step above the
+// default lets them through -- shortest job first: 1000 chains 161.8 -> 158.6 ms per step (three repetitions, 1 / 2 / 3 the same),
+// the other shapes -0.5 % (profiles/r06v_priority_ab.txt); the same knob on the GEMM's wavefronts moves nothing
+// (profiles/r06u_priority_ab.txt).  Scheduling only: no result bit depends on it.  The serial coder kernels run at 3.
+#ifndef BS_XFORM_PRIO
+#define BS_XFORM_PRIO 1
+#endif
+
 namespace {
 
 __device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expm1f(v); }
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(256) void k_wino_fused(const float* __restrict__ sr
                                                     const float* __restrict__ res, float* __restrict__ sum_out,
                                                     float* __restrict__ act_out, float* __restrict__ V, int64_t N,
                                                     int C, int H, int W, int act) {
+    if (BS_XFORM_PRIO) __builtin_amdgcn_s_setprio(BS_XFORM_PRIO);
     // LDS planes as in k_conv3_wino (round 4, visit Y): rows W + 4 apart -- a row's right halo IS the next row's left halo -- and
     // the window cut out with three aligned 16-byte reads per row.  Round 3 read it dword by dword from rows W + 8 apart: the 32
     // lanes of a ds_read_b32 group then sit 4 dwords apart on rows and planes that are multiples of 32 dwords apart, i.e. on 4 of
@@ -528,6 +539,7 @@ __global__ __launch_bounds__(256) void k_conv3_wino(const float* __restrict__ x,
                                                     const float* __restrict__ bias, float* __restrict__ act_out,
                                                     float* __restrict__ V, int64_t N, int Cin, int C, int H, int W, int act,
                                                     int cpb) {
+    if (BS_XFORM_PRIO) __builtin_amdgcn_s_setprio(BS_XFORM_PRIO);
     extern __shared__ float lds[];
     const int ntx = W / 4, T = (H / 4) * ntx;
     const int IMG = 64 / T;                          // images of one wavefront = images of the block
@@ -641,6 +653,164 @@ __global__ __launch_bounds__(256) void k_small_k_gemm(const float* __restrict__ 
         }
 }
 
+#ifdef BS_CONV3_MFMA
+// LAB BUILD ONLY (-DBS_CONV3_MFMA; VERDICT r3 #6 / r5 #5, visit r06w): round 3's matrix-core version of the input convolution
+// (profiles/archive/conv3_mfma.hip.txt), spliced back in to be measured in today's pipeline.  Sums in k pairs, so its bits differ
+// from k_conv3_wino's ci -> ky -> kx chain: a stream written by such a build is not a stream of the product route.
+
+// ------------------------------------------------------------------------------------------
+// k_conv3_mfma<CIN>: the same fused input convolution with its 9 CIN-deep products on the matrix cores, for the shape the
+// conv stacks have (16 x 16 planes, F(4x4,3x3) behind it, C a multiple of 32).  k_conv3_wino does 2 x 72 FMAs per output on
+// the fp32 VALU: 177-200 us per 500-block launch against a write floor of 85 (h 131 MB + V 295 MB), +79 % beside a serial
+// coder kernel.  Here a wavefront owns ONE image of the block's four and 32 output channels at a time:
+//   GEMM   [32 channels x 72] x [72 x 256 pixels]: v_mfma_f32_32x32x2_f32, A = the weights (lane: channel l % 32,
+//          k = 2s + l / 32: 36 registers per 32-channel block), B = the im2col of the image's zero-haloed planes read
+//          straight from LDS (lane: pixel 32t + l % 32 of tile-row pair t, tap k = ci 9 + ky 3 + kx: one ds_read_b32
+//          per MFMA), 8 accumulator tiles = the whole plane of 32 channels in 128 registers;
+//   tail   four channels at a time (a half-wave's registers 4j .. 4j+3): + bias, ELU, scattered into four haloed LDS
+//          planes of the wavefront; h leaves from there as four contiguous 1-KB planes (16-byte stores); lane = (plane,
+//          tile) cuts its 6 x 6 window, ELU again, B^T d B, 36 stores (64-byte runs per plane and position; the three
+//          other wavefronts of the block write the neighbouring runs of the same 256-byte row).
+// Sum per output: k ascending in pairs (2s, 2s + 1) -- fixed, independent of the batch.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void k_conv3_mfma(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ act_out,
+                                                       float* __restrict__ V, int64_t N, int C, int act, int cpb) {
+    constexpr int H = 16, W = 16, LW = W + 4, LP = (H + 4) * LW, T = 16, KS = CIN * 9 / 2;
+    static_assert((CIN * 9) % 2 == 0, "k pairs");
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, g = lane >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * 4;
+    constexpr int nin = 4 * CIN * LP + 4, nscr = 4 * LP + 4;
+    for (int k = tid * 4; k < nin + 4 * nscr; k += 1024) *reinterpret_cast<float4*>(lds + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    {   // x[n0 .. n0+4) is one contiguous run of 4*CIN*H*W floats
+        constexpr int w4 = W / 4, per_plane4 = H * w4;
+        const int64_t avail = (N - n0 < 4 ? N - n0 : 4) * (int64_t)CIN * per_plane4;
+        const float4* xs = reinterpret_cast<const float4*>(x + n0 * CIN * (int64_t)H * W);
+        for (int k = tid; k < avail; k += 256) {
+            const int pl = k / per_plane4, rem = k - pl * per_plane4;
+            const int row = rem / w4, c4 = rem - row * w4;
+            *reinterpret_cast<float4*>(lds + pl * LP + (row + 2) * LW + 4 + c4 * 4) = xs[k];
+        }
+    }
+    __syncthreads();
+    const int64_t n = n0 + wave;
+    if (n >= N) return;                              // (no block barrier below: the wavefronts are on their own from here)
+    // im2col: pixel (y, x) = (2t + l32 / 16, l32 % 16) of tile-row pair t, tap (ci, ky, kx) -> plane ci, row y + ky + 1,
+    // column x + kx + 3 of the haloed layout (interior at row + 2, column + 4)
+    const float* xin = lds + wave * CIN * LP + ((l32 >> 4) + 1) * LW + (l32 & 15) + 3;
+    float* scr = lds + nin + wave * nscr;
+    const int64_t ncols = N * T, tstride = (int64_t)C * ncols;
+    const int cbase = blockIdx.y * cpb;
+    const int cend = cbase + cpb < C ? cbase + cpb : C;
+    // transform role of this lane: plane q = lane / 16 of a round, tile = lane % 16
+    const int tq = lane >> 4, tile = lane & 15, ty = tile >> 2, tx = tile & 3;
+    const float* smine = scr + tq * LP + (ty * 4 + 2) * LW + tx * 4 + 4;
+    for (int cb = cbase; cb < cend; cb += 32) {
+        float wreg[KS];
+        {
+            const float* wr = w + (int64_t)(cb + l32) * (CIN * 9) + g;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) wreg[s2] = wr[2 * s2];
+        }
+        f32x16_t acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
+        float b[2][8];
+        auto tap = [&](int s2) {                      // LDS offset of tap k = 2 s2 + g against xin (s2 is a compile-time value)
+            const int k0 = 2 * s2, k1 = 2 * s2 + 1;
+            const int o0 = (k0 / 9) * LP + ((k0 % 9) / 3) * LW + (k0 % 3), o1 = (k1 / 9) * LP + ((k1 % 9) / 3) * LW + (k1 % 3);
+            return g ? o1 : o0;
+        };
+        {
+            const float* p = xin + tap(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b[0][t] = p[t * 2 * LW];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) asm volatile("" ::"v"(b[s2 & 1][t]));        // (the compiler's wait lands before the next reads)
+            __builtin_amdgcn_sched_barrier(0);
+            if (s2 + 1 < KS) {
+                const float* p = xin + tap(s2 + 1);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) b[(s2 + 1) & 1][t] = p[t * 2 * LW];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[s2], b[s2 & 1][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // register v of lane l: channel cb + (v/4)*8 + (l/32)*4 + v%4, pixel 32 t + l%32
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int c0 = cb + 8 * j + 4 * gg;          // the round's four channels c0 .. c0 + 3 (wave-uniform)
+                if (g == gg) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float bq = bias ? bias[c0 + q] : 0.0f;
+                        float* pl = scr + q * LP + ((l32 >> 4) + 2) * LW + 4 + (l32 & 15);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            float v = acc[t][4 * j + q] + bq;
+                            if (act & 1) v = elu1(v);
+                            pl[t * 2 * LW] = v;
+                        }
+                    }
+                }
+                lds_wave_sync();
+                if (act_out) {                           // four contiguous 1-KB planes: lane -> row lane / 4, columns 4 (lane % 4) ..
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 hv = *reinterpret_cast<const float4*>(scr + q * LP + ((lane >> 2) + 2) * LW + 4 + (lane & 3) * 4);
+                        *reinterpret_cast<float4*>(act_out + ((n * C + c0 + q) * (int64_t)(H * W)) + lane * 4) = hv;
+                    }
+                }
+                float d[6][6], t1[6][6];
+                lds_window<6, false>(smine, LW, d);
+                lds_wave_sync();                         // the planes may be overwritten by the next round from here on
+                if (act & 2) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) d[r][q] = elu1(d[r][q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {            // B^T d, column by column
+                    float colv[6], o[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) colv[r] = d[r][q];
+                    wino_bt<6>(colv, o);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) t1[r][q] = o[r];
+                }
+                float* vout = V + (int64_t)(c0 + tq) * ncols + n * T + tile;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    float o[6];
+                    wino_bt<6>(t1[r], o);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) vout[(int64_t)(r * 6 + q) * tstride] = o[q];
+                }
+            }
+        }
+    }
+}
+
+
+#endif
+
 template <int TS_OUT>
 int launch_conv3(const float* x, const float* w, const float* bias, int act, float* act_out, float* V, int64_t N, int Cin,
                  int C, int H, int W, int cpb, dim3 grid, size_t shm, hipStream_t st) {
@@ -707,6 +877,18 @@ int bs_conv3_wino_f32(const float* x, const float* w, const float* bias, int act
     int cpb = 64;
     while (cpb > 8 && groups * ((C + cpb - 1) / cpb) < 1536) cpb /= 2;
     if (forced >= 8 && forced % 8 == 0) cpb = forced;
+#ifdef BS_CONV3_MFMA
+    if (ts_out == 6 && H == 16 && W == 16 && Cin == 8 && C % 32 == 0) {
+        static const bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_mfma<8>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess; }();
+        (void)once;
+        const int cpm = cpb < 32 ? 32 : cpb;
+        const size_t shm_m = ((size_t)4 * 8 * LP + 4 + 4 * (4 * LP + 4)) * sizeof(float);
+        hipLaunchKernelGGL((k_conv3_mfma<8>), dim3((unsigned)((N + 3) / 4), (unsigned)((C + cpm - 1) / cpm)), dim3(256), shm_m, S(stream),
+                           x, w, bias, act_out, V, N, C, act, cpm);
+        return launch_rc();
+    }
+#endif
     dim3 grid((unsigned)groups, (unsigned)((C + cpb - 1) / cpb));
     if (ts_out == 6) return launch_conv3<6>(x, w, bias, act, act_out, V, N, Cin, C, H, W, cpb, grid, shm, S(stream));
     return launch_conv3<8>(x, w, bias, act, act_out, V, N, Cin, C, H, W, cpb, grid, shm, S(stream));

@@ -612,6 +612,23 @@ __device__ __forceinline__ void ws_produce(char* lds, int lane, int w, int gtot,
     upto(gtot);
 }
 
+// Issue priority of the wave-specialised kernels' wavefronts (s_setprio: priority first, then age, decides which wavefront of
+// a SIMD issues).  In the pipeline a GEMM of one chain group starts beside a table or transform kernel of the other group that is
+// OLDER, so at equal priority it gets the issue slots those leave.  BS_GEMM_PRIO_CONS / BS_GEMM_PRIO_PROD (0..3; the serial coder
+// kernels run at 3) are build-time knobs for that experiment (visit r06u).
+#ifndef BS_GEMM_PRIO_CONS
+#define BS_GEMM_PRIO_CONS 0
+#endif
+#ifndef BS_GEMM_PRIO_PROD
+#define BS_GEMM_PRIO_PROD 0
+#endif
+__device__ __forceinline__ void ws_priority(int wave) {
+    if (BS_GEMM_PRIO_CONS == BS_GEMM_PRIO_PROD) {
+        if (BS_GEMM_PRIO_CONS) __builtin_amdgcn_s_setprio(BS_GEMM_PRIO_CONS);
+    } else if (wave < 4) __builtin_amdgcn_s_setprio(BS_GEMM_PRIO_CONS);
+    else __builtin_amdgcn_s_setprio(BS_GEMM_PRIO_PROD);
+}
+
 // LAB != 0 (-DBS_GEMM_LAB builds only; WRONG results, timing experiments): 1 = the producers load nothing (they split what is in
 // their registers), 2 = the consumers store nothing, 4 = the consumers load no U fragments, 8 = the producers neither split nor
 // write LDS, 16 = one MFMA per tile instead of 12, 32 = no s_barrier inside the loop
@@ -622,6 +639,7 @@ void k_wino_gemm_bf16x3_ws(const uint16_t* __restrict__ Uf, const float* __restr
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ws_priority(wave);
     const int l32 = lane & 31, g = lane >> 5;
     const int nwg = gridDim.x;
     int wg = blockIdx.x;
@@ -773,6 +791,7 @@ void k_wino_gemm_bf16x3_wsp(const uint16_t* __restrict__ Uf, const float* __rest
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [W_NS][4 tiles][3 limbs][64 lanes][16 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ws_priority(wave);
     const int l32 = lane & 31, g = lane >> 5;
     const int nwg = gridDim.x;
     int wg = blockIdx.x;
