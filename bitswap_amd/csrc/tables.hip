@@ -17,6 +17,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC == 4 ?
                                                   int quantbits, int nb, uint32_t* __restrict__ out0,
                                                   uint32_t* __restrict__ out1, int64_t ld,
                                                   int32_t* __restrict__ status) {
+#ifdef BS_TABLE_PRIO
+    __builtin_amdgcn_s_setprio(BS_TABLE_PRIO);       // build-time experiment knob (visit r06y); default: priority 0
+#endif
     constexpr int K = NPL * 64;
     constexpr bool UNI = SPEC >= 2;      // CDF specs 2 and 3: rows of uniform-width bins
     __shared__ uint32_t stage[MODE == M_WAVE ? 4 * 64 * (NPL + 1) : 1];   // (M_PIVOT needs no transpose)

@@ -357,10 +357,18 @@ __device__ __forceinline__ void run_chunk_p(Stager<NW, MI>& sg, float* lds, floa
     }
 }
 
+// Issue priority: since the bf16x3 route took the ResNet products, this kernel only runs the heads' and the small products -- short
+// launches (75 us alone) that start beside older, longer kernels of the other chain group.  Like the transform kernels
+// (net_epilogue.hip, BS_XFORM_PRIO) they go one step above the table kernels and the big GEMM: 156.0 against 156.8 ms per step at
+// 1000 chains, three repetitions each (profiles/r06y_priority_ab.txt; the table kernels at 1 or 2: +1.7 % / +3 %).  Scheduling only.
+#ifndef BS_GEMM32_PRIO
+#define BS_GEMM32_PRIO 1
+#endif
 template <int NW, int MI, int PIPE, int NS>
 __global__ __launch_bounds__(64 * NW, 2) void k_wino_gemm(const float* __restrict__ U, const float* __restrict__ V,
                                                           float* __restrict__ M, int Cout, int Cin, int64_t cols,
                                                           int ncb, int nrt, int units, int even_ranges) {
+    if (BS_GEMM32_PRIO) __builtin_amdgcn_s_setprio(BS_GEMM32_PRIO);
     constexpr int BM = 32 * MI * NW;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [NS][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
