@@ -243,8 +243,10 @@ int launch_logistic(int mode, int spec, const double* endpoints, int64_t e_strid
     // launch is bound by them), but keep ~8 wavefronts per SIMD in flight.  Round 4, visit W (alone, us, z layer; nb = 1 / 4 / 16):
     // 13 chains 34.3 / 27.5 / - (encode flavour), 40.0 / 29.2 / - (rows); 500 chains - / 792 / 714 and - / 790 / 748 (pivot).
     // In the two-group pipeline of 1000 chains (same box, ms per step): nb = 4 / 8 / 16 = 180.1 / 178.3 / 183.7 -- sixteen rows per
-    // wavefront make the launch's tail too coarse when it shares the chip.
-    int nb = 8;
+    // wavefront make the launch's tail too coarse when it shares the chip.  Round 6, with the spec 4 kernel at five wavefronts per
+    // SIMD (profiles/r06I_table_nb.txt, three repetitions): 1000 chains nb = 8 / 12 / 16 / 32 = 156.7 / 155.9 / 154.8 / 154.8 ms, 100 chains
+    // nb = 2 / 4 / 8 / 16 = 23.3 / 22.6 / 22.2 / 22.0 -- sixteen; the rule below still shrinks it for few chains (13 chains: 4).
+    int nb = 16;
     while (nb > 1 && (int64_t)((D + 3) / 4) * ((B + nb - 1) / nb) < 2048) nb >>= 1;
     const char* nb_env = getenv("BITSWAP_TABLE_NB");   // tuning only; read per launch (tools flip it between launches)
     if (nb_env && atoi(nb_env) > 0) nb = atoi(nb_env);
