@@ -265,8 +265,9 @@ def gemm_roofline(model, chains, dev, warm=100, reps=100):
         fl = 2.0 * 36 * C * C * cols
         peak = MFMA_F32_PEAK_TFLOPS if arith == "fp32" else BF16_MFMA_PEAK_TFLOPS
         kern = ("k_wino_gemm<4,2> (bs_wino_gemm_f32: v_mfma_f32_32x32x2_f32, persistent balanced tiles, LDS-DMA staging)" if arith == "fp32" else
-                f"k_wino_gemm_bf16x3_ws<{nprod}> (bs_wino_gemm_bf16x3: {nprod} v_mfma_f32_32x32x16_bf16 limb products per float32 product, one "
-                "multiplying wavefront per SIMD, the operand split on wavefronts of its own)")
+                f"k_wino_gemm_bf16x3_wsp<{nprod}> (bs_wino_gemm_bf16x3: {nprod} v_mfma_f32_32x32x16_bf16 limb products per float32 product, one "
+                "multiplying wavefront per SIMD, the operand split on wavefronts of its own; at this size workgroups of two consecutive "
+                "256 x 128 units -- the pipeline's choice, alone a few percent slower than one workgroup per CU)")
         return {"kernel": kern, "bound": "mfma", "arith": arith,
                 "shape": f"T36 x [{C}x{C}] x [{C}x{cols}]", "achieved": round(nprod * fl / t / 1e12, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(nprod * fl / t / 1e12 / peak, 4), "fp32_equivalent_TFLOPs": round(fl / t / 1e12, 1),

@@ -1028,16 +1028,35 @@ extern "C" int bs_wino_gemm_bf16x3(const uint16_t* U_frags, const float* V, floa
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
             return n > 0 ? n : 256;
         }();
-        // Persistent workgroups (one per CU, a contiguous range of units each) or one unit per workgroup?  Alone the persistent
-        // kernel is 3-5 % faster at every size (profiles/r06f_gemm_times.txt); in the two-group pipeline of 1000 chains it is
-        // SLOWER (161-165 ms per step against 159: a persistent grid holds every CU for the whole launch, the other chain group's
-        // table and transform kernels -- which do not fit beside it -- wait for its end instead of slipping in between
-        // 16-microsecond workgroups), at 100 chains per call faster (21.9 against 22.4 ms).  So: persistent up to four units per
-        // CU.  BITSWAP_BF16X3_PERSISTENT = 0 / 1 forces either (read per launch: tests flip it).  Same bits either way.
+        // Persistent workgroups (one per CU, a contiguous range of units each), one unit per workgroup, or something between?  Alone
+        // the persistent kernel is 3-5 % faster at every size (profiles/r06f_gemm_times.txt); in the two-group pipeline of 1000 chains
+        // it is SLOWER (161-165 ms per step against 159: a persistent grid holds every CU for the whole launch, the other chain
+        // group's table and transform kernels -- which do not fit beside it -- wait for its end instead of slipping in between
+        // 16-microsecond workgroups), at 100 chains per call faster (21.9 against 22.4 ms).  Between the two: workgroups of TWO
+        // consecutive units (the persistent kernel on wgs / 2 workgroups) -- every second prologue is hidden behind the ring, the
+        // grid still has thousands of workgroups to slip in between: alone no faster than one unit per workgroup (ragged tail), in
+        // the pipeline 150.5 against 152.9 ms per step at 1000 chains, imagenet4 119.1 against 120.5; three and four units the same,
+        // a fixed 2 .. 6 workgroups per CU -0.5 % (profiles/r06M_*, r06N_*).  So: one workgroup per CU up to four units per CU, two
+        // units per workgroup above.  BITSWAP_BF16X3_PERSISTENT = 0 / 1 forces one unit per workgroup / one workgroup per CU,
+        // BITSWAP_BF16X3_UNITS = k forces k units per workgroup (a multiple of 8 workgroups keeps the XCD mapping),
+        // BITSWAP_BF16X3_WGS_PER_CU = r forces r workgroups per CU in all (read per launch: tests flip them).  Same bits every way.
         const char* pe = getenv("BITSWAP_BF16X3_PERSISTENT");
-        const int persistent = pe ? atoi(pe) : (wgs3 <= 4 * (int64_t)cus);
+        const char* ke = getenv("BITSWAP_BF16X3_UNITS");
+        const char* re2 = getenv("BITSWAP_BF16X3_WGS_PER_CU");
+        const int per_cu = re2 ? atoi(re2) : 0;
+        const bool small = wgs3 <= 4 * (int64_t)cus;
+        const int kunits = ke ? atoi(ke) : (pe || per_cu > 0 || small) ? 0 : 2;
+        const int persistent = (kunits > 1 || per_cu > 0) ? 1 : pe ? atoi(pe) : small;
         if (persistent && nk3 >= 2 && nk3 % 2 == 0) {
-            const int nwg = (int)(wgs3 < cus ? wgs3 : cus);
+            int nwg = (int)(wgs3 < cus ? wgs3 : cus);
+            if (kunits > 1) {
+                const int64_t want = (wgs3 + kunits - 1) / kunits;
+                nwg = (int)(want < 8 ? want : (want + 7) / 8 * 8);
+                if (nwg > wgs3) nwg = (int)wgs3;
+            } else if (per_cu > 0) {
+                const int64_t want = (int64_t)cus * per_cu;
+                nwg = (int)(want < wgs3 ? want : wgs3);
+            }
 #define BS_WSP(NPR, RING, NPW) hipLaunchKernelGGL((k_wino_gemm_bf16x3_wsp<NPR, RING, NPW>), dim3((unsigned)nwg), dim3(256 + 64 * NPW), shm3, st, U_frags, V, M, T, Cout, Cin, cols, (int)ncc3, (int)nrt, (int)wgs3)
             if (nprod == 9) { if (ring == 8) BS_WSP(9, 8, 4); else BS_WSP(9, 4, 4); }
             else if (ring == 8) BS_WSP(6, 8, 4);

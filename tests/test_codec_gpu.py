@@ -1014,9 +1014,15 @@ def test_bf16x3_gemm_shapes_agree_bitwise(T, Cout, Cin, cols, nprod, monkeypatch
     got = {}
     # 3: one unit per workgroup; 3p: persistent workgroups, a range of units each; r8: a ring of 8 LDS stages instead of 4
     # n2: two producer wavefronts per workgroup instead of four (nprod 6 only)
-    for shape in ("1", "2", "3", "3p", "3r8", "3pr8") + (("3n2", "3pn2") if nprod == 6 else ()):
+    # k2 / k3: workgroups of two / three consecutive units (k2: the default above four units per CU); c4: four workgroups per CU in all
+    for shape in ("1", "2", "3", "3p", "3r8", "3pr8", "3k2", "3k3", "3c4") + (("3n2", "3pn2") if nprod == 6 else ()):
         monkeypatch.setenv("BITSWAP_BF16X3_SHAPE", shape[0])
         monkeypatch.setenv("BITSWAP_BF16X3_PERSISTENT", "1" if "p" in shape else "0")
+        for var, tag in (("BITSWAP_BF16X3_UNITS", "k"), ("BITSWAP_BF16X3_WGS_PER_CU", "c")):
+            if tag in shape:
+                monkeypatch.setenv(var, shape[-1])
+            else:
+                monkeypatch.delenv(var, raising=False)
         monkeypatch.setenv("BITSWAP_BF16X3_RING", "8" if shape.endswith("r8") else "4")
         monkeypatch.setenv("BITSWAP_BF16X3_PRODUCERS", "2" if shape.endswith("n2") else "4")
         out = torch.full((T, Cout, cols), float("nan"), device=DEV)
@@ -1031,6 +1037,8 @@ def test_bf16x3_gemm_shapes_agree_bitwise(T, Cout, Cin, cols, nprod, monkeypatch
     monkeypatch.delenv("BITSWAP_BF16X3_PERSISTENT")
     monkeypatch.delenv("BITSWAP_BF16X3_RING")
     monkeypatch.delenv("BITSWAP_BF16X3_PRODUCERS")
+    monkeypatch.delenv("BITSWAP_BF16X3_UNITS", raising=False)
+    monkeypatch.delenv("BITSWAP_BF16X3_WGS_PER_CU", raising=False)
     assert torch.equal(hip.wino_gemm_bf16x3(Uf, V[:, :, :sub].contiguous(), nprod), got["3"][:, :, :sub])   # the default; batch-invariant
 
 
