@@ -675,12 +675,23 @@ def make_mnist_full_chain(nblocks=100):
     before such an entry forks it.  Stored compactly: per op (mu, scale) float32 as the reference's net emitted
     them, the symbols, the word count and the head after the op; the pixel scale is a parameter (mnist_train.py:411), stored
     once; the prior ops carry no arrays (mu 0, scale 1)."""
-    torch.manual_seed(55)
-    rng = np.random.RandomState(15)
-    nz, quantbits = 2, 10
-    xs, zch = (1, 32, 32), 1
-    cfg = [xs[0], nz, zch, 4, 3, 8, 63]
-    model = RefModel(xs=xs, nz=nz, zchannels=zch, nprocessing=4, kernel_size=3, resdepth=8, reswidth=63, root_process=False)
+    _full_chain("mnist", (1, 32, 32), 2, 1, 63, nblocks, 55, 15)
+
+
+def make_cifar_full_chain(nblocks=6):
+    """BASELINE configs[1] -- the bench headline's model -- at its REAL width (cifar_compress.py:80-81,106: nz 8, zchannels 8,
+    reswidth 252, resdepth 8, nprocessing 4; model/cifar_train.py's Model is mnist_train.py's class with another log directory),
+    ONE Bit-Swap / BB-ANS chain of `nblocks` blocks through the reference's sender on CPU: 2048-dim latent rows with 1024 bins
+    and 3072-dim pixel rows, the launch shapes of the headline.  Same compact layout as the MNIST chains."""
+    _full_chain("cifar", (3, 32, 32), 8, 8, 252, nblocks, 56, 16)
+
+
+def _full_chain(tag, xs, nz, zch, reswidth, nblocks, tseed, nseed):
+    torch.manual_seed(tseed)
+    rng = np.random.RandomState(nseed)
+    quantbits = 10
+    cfg = [xs[0], nz, zch, 4, 3, 8, reswidth]
+    model = RefModel(xs=xs, nz=nz, zchannels=zch, nprocessing=4, kernel_size=3, resdepth=8, reswidth=reswidth, root_process=False)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.endswith(".b") or n.endswith("gen_std"):
@@ -689,7 +700,7 @@ def make_mnist_full_chain(nblocks=100):
                 p.add_(torch.randn_like(p) * 0.2)
     model.eval()
     xdim, zdim = int(np.prod(xs)), zch * 16 * 16
-    images = synth_images(rng, 128, xs)
+    images = synth_images(rng, 128 if tag == "mnist" else 32, xs)
     zend, zcen, mins, maxs = synth_bins(model, nz, zdim, quantbits, images, rng)
     for bitswap in (1, 0):
         ops, sent, restbits, nets, cma = replay_chain(model, zend, zcen, images[:nblocks], nz, bitswap, quantbits, xdim, zdim,
@@ -715,7 +726,7 @@ def make_mnist_full_chain(nblocks=100):
             "x_mu": np.stack([p["mu"] for p in xops]), "x_scale": xops[0]["scale"],
             "x_sym": np.stack([p["sym"] for p in xops]).astype(np.uint8),
         }
-        name = f"chain_mnist_full_{'bitswap' if bitswap else 'bbans'}.npz"
+        name = f"chain_{tag}_full_{'bitswap' if bitswap else 'bbans'}.npz"
         np.savez_compressed(os.path.join(OUT, name), **o)
         print(name, "ops", len(ops), "words", len(sent), "cma", cma[-1])
 
@@ -748,6 +759,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mnist_full":
         make_mnist_full_chain()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cifar_full":
+        make_cifar_full_chain()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "draws":
         make_draws_fixture()
         sys.exit(0)
@@ -772,3 +786,4 @@ if __name__ == "__main__":
     make_discretize_fixture()
     make_draws_fixture()
     make_mnist_full_chain()
+    make_cifar_full_chain()

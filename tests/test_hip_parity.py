@@ -426,9 +426,9 @@ def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
     assert st.to_lists() == [words_to_state(g["sent_words"])] * B
 
 
-@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
+@pytest.mark.parametrize("data,sched", [("mnist", "bitswap"), ("mnist", "bbans"), ("cifar", "bitswap"), ("cifar", "bbans")])
 @pytest.mark.parametrize("spec", [1, 2, 3, 4])
-def test_divergence_horizon_on_the_gpu(golden, sched, spec):
+def test_divergence_horizon_on_the_gpu(golden, sched, spec, data):
     """How far the HIP kernels follow the reference's OWN word stream: BASELINE configs[0] at its real width,
     one chain of 100 blocks written by the reference's sender on CPU (tests/golden/chain_mnist_full_*.npz; torch.sigmoid
     tables), replayed teacher-forced -- the reference's (mu, scale) and pushed symbols in -- through k_logistic +
@@ -436,11 +436,14 @@ def test_divergence_horizon_on_the_gpu(golden, sched, spec):
     replayed on the CPU beside it): bit-exact HIP == oracle along 500 operations and ~50,000 words, also past the point
     where both have left the reference.  And the distance to the reference is the recorded one (tests/test_oracle.py::HORIZON):
     specs 1 and 2 keep the reference's state through all 100 blocks (spec 2's Bit-Swap stream with one word off by one),
-    spec 3 leaves it at operation 165 = block 33.  Two chains side by side: both see the same thing."""
+    spec 3 leaves it at operation 165 = block 33.  Two chains side by side: both see the same thing.
+    data = cifar: BASELINE configs[1], the headline's model at its real width -- 6 blocks = 102 operations of 2048 x 1024-bin rows
+    (tests/golden/chain_cifar_full_*.npz): HIP == oracle word for word all the way, and the reference is left inside the first
+    block by every spec (one table entry in 34 M: test_oracle.py::HORIZON_CIFAR)."""
     from bitswap_amd.bins import uniform_step
-    from test_oracle import HORIZON, full_chain_ops
+    from test_oracle import HORIZONS, full_chain_ops
     h = hip()
-    g = golden(f"chain_mnist_full_{sched}.npz")
+    g = golden(f"chain_{data}_full_{sched}.npz")
     zend, xend, zcen = chain_tables(g)
     zend_d = [dev(z) for z in zend]
     xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)
@@ -480,25 +483,26 @@ def test_divergence_horizon_on_the_gpu(golden, sched, spec):
     st.check()
     got = st.to_lists()
     assert got == [ost.tolist()] * B                          # every word, not just the heads
-    want_first, want_ndiff = HORIZON[(sched, spec)]
+    want_first, want_ndiff = HORIZONS[data][(sched, spec)]
     assert first == want_first
     if want_ndiff is not None:
         ref = words_to_state(g["sent_words"])
         assert len(got[0]) == len(ref) and sum(x != y for x, y in zip(got[0], ref)) == want_ndiff
 
 
-@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
+@pytest.mark.parametrize("data,sched", [("mnist", "bitswap"), ("mnist", "bbans"), ("cifar", "bitswap"), ("cifar", "bbans")])
 @pytest.mark.parametrize("spec", [1, 2, 3, 4])
-def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched, spec):
+def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched, spec, data):
     """bits/dim <= 1e-4 pinned on BASELINE configs[0] at full width, 100 blocks, per CDF spec.  The ideal code
     length of the reference's own 500 operations' symbols (tests/golden/chain_mnist_full_*.npz, written by the reference's
     sender: mnist_compress.py:176-251) under the frequencies the HIP table kernel builds from the teacher-forced (mu, scale)
     against the same under the reference's torch.sigmoid tables -- per operation and in total -- and the total against the
-    fixture's `nets` (mnist_compress.py:253-261).  The frequencies must also be the oracle's, symbol for symbol."""
+    fixture's `nets` (mnist_compress.py:253-261).  The frequencies must also be the oracle's, symbol for symbol.
+    data = cifar: the same on BASELINE configs[1] at its real width (the bench headline's model), 6 blocks = 102 operations."""
     from bitswap_amd.bins import uniform_step
     from test_oracle import check_rate_against_reference, ideal_bits_of_full_chain, torch_table_bits
     h = hip()
-    g = golden(f"chain_mnist_full_{sched}.npz")
+    g = golden(f"chain_{data}_full_{sched}.npz")
     zend, xend, _ = chain_tables(g)
     zend_d = [dev(z) for z in zend]
     xend_d = dev(xend[0]).unsqueeze(0).expand(xend.shape[0], -1)
@@ -522,7 +526,7 @@ def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched
         return f
     got = ideal_bits_of_full_chain(g, freqs)
     assert int(status.item()) == 0
-    check_rate_against_reference(g, got, torch_table_bits(g), f"HIP spec {spec} {sched}")
+    check_rate_against_reference(g, got, torch_table_bits(g), f"HIP spec {spec} {data} {sched}")
 
 
 @pytest.mark.parametrize("layout", ["linear", "wave"])

@@ -286,6 +286,19 @@ HORIZON = {("bitswap", 1): (None, 0), ("bitswap", 2): (None, 1), ("bitswap", 3):
            ("bbans", 1): (None, 0), ("bbans", 2): (None, 0), ("bbans", 3): (165, None), ("bbans", 4): (None, 0)}
 
 
+# The same on BASELINE configs[1] -- the bench headline's model, cifar8 at its real width: 6 blocks = 102 operations of 2048 rows x
+# 1024 bins (and 3072 x 256 pixel rows), tests/golden/chain_cifar_full_*.npz.  34 M table entries per block: at 0.03-0.06 ppm
+# of entries off torch's no routine but torch's own sigmoid binary follows the reference's words through even ONE block -- in the
+# first block exactly one bin of 34,340,864 differs (row 1559 of the push of z_3: bin 494 one lower, the argmax bin 530 one
+# higher, the coded symbol 515 in between), for spec 1's correctly rounded quotient as for the others.  Word-level agreement
+# with the reference is a property of the table entries the stream happens to touch, not of the routine; what a port CAN hold
+# at this size is the rate (bits/dim <= 1e-4: test_bits_per_dim_of_the_full_width_reference_chain) and bit-exactness against
+# its own oracle (tests/test_hip_parity.py).  None: the streams differ in length.
+HORIZON_CIFAR = {("bitswap", 1): (10, None), ("bitswap", 2): (10, None), ("bitswap", 3): (10, None), ("bitswap", 4): (10, None),
+                 ("bbans", 1): (53, None), ("bbans", 2): (53, None), ("bbans", 3): (19, None), ("bbans", 4): (53, None)}
+HORIZONS = {"mnist": HORIZON, "cifar": HORIZON_CIFAR}
+
+
 def horizon_of(g, coder, final_words=None):
     """coder(kind, tab, q, mu, sc, sym) applies one op and returns (nwords, head) after it.  -> (first op whose state differs
     from the reference's | None, number of differing words in the finished stream | None when the lengths differ)."""
@@ -301,11 +314,11 @@ def horizon_of(g, coder, final_words=None):
     return first, ndiff
 
 
-@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
-@pytest.mark.parametrize("spec", [1, 2, 3, 4])
-def test_divergence_horizon_against_the_reference_stream(golden, sched, spec):
+@pytest.mark.parametrize("data,sched,spec", [("mnist", sc, sp) for sc in ("bitswap", "bbans") for sp in (1, 2, 3, 4)]
+                         + [("cifar", "bitswap", sp) for sp in (1, 2, 3, 4)] + [("cifar", "bbans", 3), ("cifar", "bbans", 4)])
+def test_divergence_horizon_against_the_reference_stream(golden, sched, spec, data):
     from bitswap_amd.bins import uniform_step
-    g = golden(f"chain_mnist_full_{sched}.npz")
+    g = golden(f"chain_{data}_full_{sched}.npz")
     zend, xend, _ = chain_tables(g)
     steps = {tab: (uniform_step(e) if spec >= 2 else None) for tab, e in list(enumerate(zend)) + [(-1, xend)]}
     st = O.Stack(reference_init_state(), cap=80000)
@@ -320,7 +333,7 @@ def test_divergence_horizon_against_the_reference_stream(golden, sched, spec):
         assert rc == O.OK
         return int(st.len[0]) + 1, int(st.head[0])
     first, ndiff = horizon_of(g, coder, st.tolist)
-    want_first, want_ndiff = HORIZON[(sched, spec)]
+    want_first, want_ndiff = HORIZONS[data][(sched, spec)]
     assert first == want_first and (want_ndiff is None or ndiff == want_ndiff)
     if want_first is not None:
         assert ndiff is None or ndiff > 1000          # a fork for good: the rest of the stream is different
@@ -340,8 +353,19 @@ def ideal_bits_of_full_chain(g, freqs_of_op):
     return np.array(out)
 
 
+_TORCH_BITS = {}
+
+
 def torch_table_bits(g):
-    """The same under the reference's own tables (torch.sigmoid, utils/torch/rand.py:67-68 + ANS.__init__)."""
+    """The same under the reference's own tables (torch.sigmoid, utils/torch/rand.py:67-68 + ANS.__init__).  Computed once per
+    fixture (the four CDF specs of a chain are compared with the same array)."""
+    key = tuple(int(v) for v in g["cfg"])
+    if key not in _TORCH_BITS:
+        _TORCH_BITS[key] = _torch_table_bits(g)
+    return _TORCH_BITS[key]
+
+
+def _torch_table_bits(g):
     from oracle.backend import OracleBackend
     zend, xend, _ = chain_tables(g)
 
@@ -363,19 +387,25 @@ def check_rate_against_reference(g, got_bits, ref_bits, label):
     print(f"{label}: rate difference per op {per_op:.3e}, total {total:.3e} bits/dim over {nblocks} blocks "
           f"(reference net {g['nets'].sum() / nblocks:.5f}, ideal {got_bits.sum() / (X * nblocks):.5f})")
     assert per_op <= 1e-4 and total <= 1e-4
-    assert abs(got_bits.sum() / (X * nblocks) - g["nets"].sum() / nblocks) <= 1e-4 + 96 / (X * nblocks)
+    # realised against ideal: the head's own content (up to 32 bits either way), a word of granularity, and the coder's
+    # redundancy -- the reference renormalises to heads >= 2^32 with 31-bit frequencies (mnist_compress.py:23,52), so head // f can
+    # be as small as 2: measured 2.5e-4 bits per symbol on the MNIST chains (51 bits over 204,800 symbols), 6.4e-4 on the cifar8
+    # chain (138 over 215,040); allowed 1e-3.  The HIP coder is this coder, word for word.
+    nsym = sum(len(op[5]) for op in full_chain_ops(g))
+    assert abs(got_bits.sum() / (X * nblocks) - g["nets"].sum() / nblocks) <= 1e-4 + (96 + 1e-3 * nsym) / (X * nblocks)
     return per_op, total
 
 
-@pytest.mark.parametrize("sched", ["bitswap", "bbans"])
-@pytest.mark.parametrize("spec", SPECS)
-def test_bits_per_dim_of_the_full_width_reference_chain(golden, sched, spec):
+@pytest.mark.parametrize("data,sched,spec", [("mnist", sc, sp) for sc in ("bitswap", "bbans") for sp in SPECS]
+                         + [("cifar", "bitswap", 1), ("cifar", "bitswap", 4)])
+def test_bits_per_dim_of_the_full_width_reference_chain(golden, sched, spec, data):
     """VERDICT r5 #3, host twin: BASELINE configs[0] at its real width, 100 blocks = 500 coding operations written by the
     reference's sender.  Ideal code length of the reference's own symbols under the tables of each CDF spec
     (teacher-forced (mu, scale)) against the same under the reference's torch tables: <= 1e-4 bits/dim per operation and in
-    total, and the total against the fixture's `nets`.  tests/test_hip_parity.py holds the HIP kernels to the same."""
+    total, and the total against the fixture's `nets`.  tests/test_hip_parity.py holds the HIP kernels to the same.
+    data = cifar: configs[1], the headline's model at its real width (nz 8, 2048-dim latent rows), 6 blocks = 102 operations."""
     from bitswap_amd.bins import uniform_step
-    g = golden(f"chain_mnist_full_{sched}.npz")
+    g = golden(f"chain_{data}_full_{sched}.npz")
     zend, xend, _ = chain_tables(g)
     steps = {tab: (uniform_step(e) if spec >= 2 else None) for tab, e in list(enumerate(zend)) + [(-1, xend)]}
 
@@ -386,14 +416,17 @@ def test_bits_per_dim_of_the_full_width_reference_chain(golden, sched, spec):
         f, _, rc = O.tables(pmf, 31, q)
         assert rc == O.OK
         return f[np.arange(len(sym)), sym]
-    check_rate_against_reference(g, ideal_bits_of_full_chain(g, freqs), torch_table_bits(g), f"oracle spec {spec} {sched}")
+    check_rate_against_reference(g, ideal_bits_of_full_chain(g, freqs), torch_table_bits(g), f"oracle spec {spec} {data} {sched}")
 
 
-def test_reference_arithmetic_reproduces_the_full_chain(golden):
+@pytest.mark.parametrize("data", ["mnist", "cifar"])
+def test_reference_arithmetic_reproduces_the_full_chain(golden, data):
     """The same replay with the reference formula evaluated by libm / by this torch build: the fixtures are the reference's
-    output on THIS torch build, so MODE_TORCH must follow them to the last word (the libm restatement need not)."""
+    output on THIS torch build, so MODE_TORCH must follow them to the last word (the libm restatement need not) -- also on
+    the cifar8 chain, where every deterministic routine forks inside the first block (HORIZON_CIFAR): the fork is the
+    sigmoid's last bit, not the integer half."""
     from oracle.backend import OracleBackend
-    g = golden("chain_mnist_full_bitswap.npz")
+    g = golden(f"chain_{data}_full_bitswap.npz")
     zend, xend, _ = chain_tables(g)
     st = O.Stack(reference_init_state(), cap=80000)
 
@@ -426,8 +459,8 @@ def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
     code = ("import sys; sys.path.insert(0, %r); import make_golden as mg; mg.OUT = %r; "
             "mg.make_tables_and_rans(); mg.make_bins(); mg.make_model_and_chains(); mg.make_rgb4_chain(); "
             "mg.make_bits_fixture(); mg.make_surface_fixture(); mg.make_discretize_fixture(); mg.make_draws_fixture(); "
-            "mg.make_mnist_full_chain()") % (gold, str(tmp_path))
-    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            "mg.make_mnist_full_chain(); mg.make_cifar_full_chain()") % (gold, str(tmp_path))
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
     committed = sorted(f for f in os.listdir(gold) if f.endswith(".npz"))
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == committed
     for name in committed:
