@@ -686,6 +686,12 @@ def make_cifar_full_chain(nblocks=6):
     _full_chain("cifar", (3, 32, 32), 8, 8, 252, nblocks, 56, 16)
 
 
+def make_imagenet_full_chain(nblocks=4):
+    """BASELINE configs[2] / [4] -- north_star's target shape -- at its REAL width (imagenet_compress.py:83-84: nz 4, zchannels 8,
+    reswidth 254; model/imagenet_train.py's Model is the same class again): one Bit-Swap and one BB-ANS chain of `nblocks` blocks."""
+    _full_chain("imagenet", (3, 32, 32), 4, 8, 254, nblocks, 57, 17)
+
+
 def _full_chain(tag, xs, nz, zch, reswidth, nblocks, tseed, nseed):
     torch.manual_seed(tseed)
     rng = np.random.RandomState(nseed)
@@ -762,6 +768,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cifar_full":
         make_cifar_full_chain()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "imagenet_full":
+        make_imagenet_full_chain()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "draws":
         make_draws_fixture()
         sys.exit(0)
@@ -787,3 +796,4 @@ if __name__ == "__main__":
     make_draws_fixture()
     make_mnist_full_chain()
     make_cifar_full_chain()
+    make_imagenet_full_chain()

@@ -426,7 +426,8 @@ def test_chain_replay_matches_reference_words(golden, chain, layout, spec):
     assert st.to_lists() == [words_to_state(g["sent_words"])] * B
 
 
-@pytest.mark.parametrize("data,sched", [("mnist", "bitswap"), ("mnist", "bbans"), ("cifar", "bitswap"), ("cifar", "bbans")])
+@pytest.mark.parametrize("data,sched", [("mnist", "bitswap"), ("mnist", "bbans"), ("cifar", "bitswap"), ("cifar", "bbans"),
+                                        ("imagenet", "bitswap"), ("imagenet", "bbans")])
 @pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_divergence_horizon_on_the_gpu(golden, sched, spec, data):
     """How far the HIP kernels follow the reference's OWN word stream: BASELINE configs[0] at its real width,
@@ -490,7 +491,8 @@ def test_divergence_horizon_on_the_gpu(golden, sched, spec, data):
         assert len(got[0]) == len(ref) and sum(x != y for x, y in zip(got[0], ref)) == want_ndiff
 
 
-@pytest.mark.parametrize("data,sched", [("mnist", "bitswap"), ("mnist", "bbans"), ("cifar", "bitswap"), ("cifar", "bbans")])
+@pytest.mark.parametrize("data,sched", [("mnist", "bitswap"), ("mnist", "bbans"), ("cifar", "bitswap"), ("cifar", "bbans"),
+                                        ("imagenet", "bitswap"), ("imagenet", "bbans")])
 @pytest.mark.parametrize("spec", [1, 2, 3, 4])
 def test_bits_per_dim_of_the_full_width_reference_chain_on_the_gpu(golden, sched, spec, data):
     """bits/dim <= 1e-4 pinned on BASELINE configs[0] at full width, 100 blocks, per CDF spec.  The ideal code

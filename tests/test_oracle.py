@@ -296,7 +296,12 @@ HORIZON = {("bitswap", 1): (None, 0), ("bitswap", 2): (None, 1), ("bitswap", 3):
 # its own oracle (tests/test_hip_parity.py).  None: the streams differ in length.
 HORIZON_CIFAR = {("bitswap", 1): (10, None), ("bitswap", 2): (10, None), ("bitswap", 3): (10, None), ("bitswap", 4): (10, None),
                  ("bbans", 1): (53, None), ("bbans", 2): (53, None), ("bbans", 3): (19, None), ("bbans", 4): (53, None)}
-HORIZONS = {"mnist": HORIZON, "cifar": HORIZON_CIFAR}
+# BASELINE configs[2] / [4] at their real width (north_star's target shape: imagenet nz 4, reswidth 254), 4 blocks = 36 operations,
+# chain_imagenet_full_*.npz: spec 1 follows the reference to the last word in both schedules, specs 2 and 4 in the Bit-Swap
+# schedule; their BB-ANS stream forks at operation 12, spec 3 at 27 / 2.
+HORIZON_IMAGENET = {("bitswap", 1): (None, 0), ("bitswap", 2): (None, 0), ("bitswap", 3): (27, None), ("bitswap", 4): (None, 0),
+                    ("bbans", 1): (None, 0), ("bbans", 2): (12, None), ("bbans", 3): (2, None), ("bbans", 4): (12, None)}
+HORIZONS = {"mnist": HORIZON, "cifar": HORIZON_CIFAR, "imagenet": HORIZON_IMAGENET}
 
 
 def horizon_of(g, coder, final_words=None):
@@ -315,7 +320,8 @@ def horizon_of(g, coder, final_words=None):
 
 
 @pytest.mark.parametrize("data,sched,spec", [("mnist", sc, sp) for sc in ("bitswap", "bbans") for sp in (1, 2, 3, 4)]
-                         + [("cifar", "bitswap", sp) for sp in (1, 2, 3, 4)] + [("cifar", "bbans", 3), ("cifar", "bbans", 4)])
+                         + [("cifar", "bitswap", sp) for sp in (1, 2, 3, 4)] + [("cifar", "bbans", 3), ("cifar", "bbans", 4)]
+                         + [("imagenet", "bitswap", sp) for sp in (1, 2, 3, 4)] + [("imagenet", "bbans", 1), ("imagenet", "bbans", 4)])
 def test_divergence_horizon_against_the_reference_stream(golden, sched, spec, data):
     from bitswap_amd.bins import uniform_step
     g = golden(f"chain_{data}_full_{sched}.npz")
@@ -397,7 +403,7 @@ def check_rate_against_reference(g, got_bits, ref_bits, label):
 
 
 @pytest.mark.parametrize("data,sched,spec", [("mnist", sc, sp) for sc in ("bitswap", "bbans") for sp in SPECS]
-                         + [("cifar", "bitswap", 1), ("cifar", "bitswap", 4)])
+                         + [("cifar", "bitswap", 1), ("cifar", "bitswap", 4), ("imagenet", "bbans", 4)])
 def test_bits_per_dim_of_the_full_width_reference_chain(golden, sched, spec, data):
     """VERDICT r5 #3, host twin: BASELINE configs[0] at its real width, 100 blocks = 500 coding operations written by the
     reference's sender.  Ideal code length of the reference's own symbols under the tables of each CDF spec
@@ -459,8 +465,8 @@ def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
     code = ("import sys; sys.path.insert(0, %r); import make_golden as mg; mg.OUT = %r; "
             "mg.make_tables_and_rans(); mg.make_bins(); mg.make_model_and_chains(); mg.make_rgb4_chain(); "
             "mg.make_bits_fixture(); mg.make_surface_fixture(); mg.make_discretize_fixture(); mg.make_draws_fixture(); "
-            "mg.make_mnist_full_chain(); mg.make_cifar_full_chain()") % (gold, str(tmp_path))
-    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+            "mg.make_mnist_full_chain(); mg.make_cifar_full_chain(); mg.make_imagenet_full_chain()") % (gold, str(tmp_path))
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=2000)
     committed = sorted(f for f in os.listdir(gold) if f.endswith(".npz"))
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == committed
     for name in committed:
