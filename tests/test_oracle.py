@@ -462,12 +462,19 @@ def test_committed_fixtures_are_what_the_reference_produces_here(tmp_path):
     if not os.path.isdir(ref):
         pytest.skip("reference not present on this host")
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    # The full-width cifar8 / imagenet chains (round 6) take two more minutes of the reference's CPU convolutions: regenerated and
+    # compared as well with BITSWAP_REGEN_RGB_FULL=1 (done when they were committed; default thread counts -- the reference's CPU
+    # convolutions sum in an order that depends on torch's thread count); without it they are checked by the tests that replay them.
+    rgb_full = os.environ.get("BITSWAP_REGEN_RGB_FULL") == "1"
     code = ("import sys; sys.path.insert(0, %r); import make_golden as mg; mg.OUT = %r; "
             "mg.make_tables_and_rans(); mg.make_bins(); mg.make_model_and_chains(); mg.make_rgb4_chain(); "
             "mg.make_bits_fixture(); mg.make_surface_fixture(); mg.make_discretize_fixture(); mg.make_draws_fixture(); "
-            "mg.make_mnist_full_chain(); mg.make_cifar_full_chain(); mg.make_imagenet_full_chain()") % (gold, str(tmp_path))
+            "mg.make_mnist_full_chain()") % (gold, str(tmp_path))
+    if rgb_full:
+        code += "; mg.make_cifar_full_chain(); mg.make_imagenet_full_chain()"
     subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=2000)
-    committed = sorted(f for f in os.listdir(gold) if f.endswith(".npz"))
+    committed = sorted(f for f in os.listdir(gold) if f.endswith(".npz")
+                       and (rgb_full or not f.startswith(("chain_cifar_full", "chain_imagenet_full"))))
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == committed
     for name in committed:
         new, old = np.load(tmp_path / name, allow_pickle=True), np.load(os.path.join(gold, name), allow_pickle=True)
