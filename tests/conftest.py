@@ -85,6 +85,31 @@ def linear_to_wave(cdf, K, bits=31, pad_rows_to=64):
     return out
 
 
+# seeds of tests/golden/make_golden.py::_full_chain (torch.manual_seed before the model is built)
+FULL_CHAIN_SEEDS = {"mnist": 55, "cifar": 56, "imagenet": 57}
+
+
+def seeded_full_model(g, data, device="cpu", **kw):
+    """The reference Model of a chain_<data>_full fixture rebuilt from its SEED instead of a stored state dict (179 MB at the
+    cifar8 width): bitswap_amd.model.Model draws its parameters with the reference's calls in the reference's order, so
+    torch.manual_seed(s) + the same perturbation of biases, gains and gen_std as make_golden.py gives the reference's tensors
+    -- tests/test_host_cpu.py holds that against the imported reference where it is present; a wrong weight would also show as
+    (mu, scale) far from the fixture's in the tests that use this."""
+    import torch
+    from bitswap_amd.model import Model
+    cfg = g["cfg"]
+    torch.manual_seed(FULL_CHAIN_SEEDS[data])
+    m = Model(xs=(int(cfg[0]), 32, 32), nz=int(cfg[1]), zchannels=int(cfg[2]), nprocessing=int(cfg[3]),
+              kernel_size=int(cfg[4]), resdepth=int(cfg[5]), reswidth=int(cfg[6]), root_process=False, **kw)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith(".b") or n.endswith("gen_std"):
+                p.add_(torch.randn_like(p) * 0.3)
+            if n.endswith(".gain"):
+                p.add_(torch.randn_like(p) * 0.2)
+    return m.to(device).eval()
+
+
 def load_golden_model(g, device="cpu", **kw):
     """bitswap_amd Model with the weights of a reference-generated model fixture (tests/golden/model_*.npz)."""
     import torch

@@ -708,6 +708,66 @@ def test_gpu_bits_per_dim_matches_reference(golden, sched):
     assert torch.equal(out.cpu(), imgs) and state.to_lists() == init
 
 
+@pytest.mark.parametrize("data,sched,arith,nblocks", [("cifar", "bitswap", "bf16x3", 6), ("cifar", "bbans", "bf16x3", 3),
+                                                      ("cifar", "bitswap", "fp32", 3), ("imagenet", "bitswap", "bf16x3", 4),
+                                                      ("imagenet", "bbans", "bf16x3", 4), ("mnist", "bitswap", "bf16x3", 12)])
+def test_full_width_gpu_model_rate_matches_the_reference_nets(golden, data, sched, arith, nblocks):
+    """north_star end to end at the BASELINE models' real width: the reference's own sender (its Model on CPU, its ANS) wrote
+    tests/golden/chain_<data>_full_*.npz; here the SAME weights (rebuilt from the seed: conftest.seeded_full_model), folded and fused,
+    run on the GPU kernels of the product route -- Winograd-domain GEMMs in `arith`, fused transforms -- symbol-forced through
+    the reference's trajectory, and the tables come from the HIP table kernel (default CDF spec).  (a) the GPU Model's (mu, scale)
+    stay close to the reference's CPU float32 ones at every operation; (b) the ideal code length of the reference's symbols under
+    the product's tables-from-GPU-(mu, scale) against the same under the reference's (mu, scale): <= 1e-4 bits/dim per operation
+    and in total (the bar of north_star).  cifar: configs[1] -- the bench headline's model; imagenet: configs[2] / [4]; mnist:
+    configs[0] (first 12 of its 100 blocks)."""
+    from test_oracle import full_chain_ops
+    from conftest import seeded_full_model
+    from bitswap_amd import hip
+    from bitswap_amd.codec import HipBackend
+    g = golden(f"chain_{data}_full_{sched}.npz")
+    cfg = g["cfg"]
+    q, bitswap = int(cfg[7]), bool(cfg[8])
+    assert nblocks <= int(cfg[9])
+    model = seeded_full_model(g, data, DEV)
+    model.set_gemm_arith(arith)
+    model = model.fold().fuse()
+    model.gemm_min_batch = 1
+    zend, xend, zcen = chain_tables(g)
+    zend_d, zcen_d = torch.from_numpy(zend).to(DEV), torch.from_numpy(zcen).to(DEV)
+    X, B = model.xdim, 2
+    per_block = 2 * model.nz + 1
+    allops = list(full_chain_ops(g))[: nblocks * per_block]
+    imgs = torch.from_numpy(g["images"][:nblocks].astype(np.int32)).view(1, nblocks, -1).expand(B, -1, -1).contiguous()
+    forced = _SymbolForced(HipBackend(DEV), [(k, sym) for k, _, _, _, _, sym in allops], B, zend_d[-1])
+    codec = BitSwapCodec(model, zend_d, zcen_d, quantbits=q, bitswap=bitswap, backend=forced)
+    state = HipBackend(DEV).new_state([reference_init_state()] * B, 60000)
+    with _Count("wino_gemm_bf16x3") as wx, _Count("wino_gemm") as wg, _Count("wino_fused") as wf:
+        for xi in range(nblocks):
+            codec.encode_block(state, imgs[:, xi].to(DEV))
+    assert wf.n > 0 and wg.n + wx.n > 0 and len(forced.bits) == len(allops)      # the product route, not a library conv
+    if arith == "bf16x3" and data != "mnist":
+        assert wx.n > 0
+    st = HipBackend(DEV).new_state([reference_init_state()], 1000)
+    ref_bits, dmu, dsc = [], 0.0, 0.0
+    for i, (kind, tab, qq, mu, sc, sym) in enumerate(allops):
+        e = (torch.from_numpy(xend[0]).to(DEV).unsqueeze(0).expand(X, -1) if tab < 0 else zend_d[tab])
+        f, _ = hip.logistic_fc(e, torch.from_numpy(mu[None]).to(DEV), torch.from_numpy(sc[None]).to(DEV),
+                               torch.from_numpy(sym[None]).to(DEV), st.status, 31, qq)
+        f = f.cpu().numpy().view(np.uint32).astype(np.float64)
+        ref_bits.append((-1.0 if kind == 0 else 1.0) * (31.0 - np.log2(f)).sum())
+        if not (kind == 1 and tab == model.nz - 1 and i % per_block == per_block - 1):      # (the prior op carries no net output)
+            dmu = max(dmu, float(np.abs(forced.params[i][0] - mu).max()))
+            dsc = max(dsc, float(np.abs(forced.params[i][1] / sc - 1).max()))
+    ref_bits = np.array(ref_bits)
+    got_bits = np.stack(forced.bits)
+    per_op = np.abs(got_bits - ref_bits[:, None]).max() / X
+    total = np.abs(got_bits.sum(0) - ref_bits.sum()).max() / (X * nblocks)
+    print(f"{data} {sched} {arith}: max |mu - mu_ref| {dmu:.2e}, max |scale/scale_ref - 1| {dsc:.2e}; "
+          f"rate difference per op {per_op:.2e}, total {total:.2e} bits/dim over {nblocks} blocks")
+    assert dmu < 5e-3 and dsc < 5e-3                       # the seeded weights ARE the reference's (a wrong tensor gives O(1))
+    assert per_op <= 1e-4 and total <= 1e-4
+
+
 def test_demo_container_against_reference_file_on_gpu(golden):
     """The crop/demo path on the GPU against the container the reference's own demo_compress.compress wrote
     (tests/golden/demo_surface.npz): same blocks, same trailer, a length within sampling noise of the reference's (the

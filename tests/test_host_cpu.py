@@ -903,3 +903,39 @@ def test_bench_headline_line_is_compact_and_complete():
     bare["config"] = dict(full["config"], measured_shapes=None, predicted_scaling=None)
     hb = json.loads(bench.headline_line(bare))
     assert hb["roofline"] is None and hb["cpu_baseline"] is None and hb["measured_shapes"] is None and hb["value"] == full["value"]
+
+
+def test_seeded_full_models_are_the_reference_models():
+    """conftest.seeded_full_model (the weights of the chain_<data>_full fixtures rebuilt from their seed, for the GPU tests that
+    run the conv stacks at the BASELINE models' real width) against the imported reference Model built the way
+    tests/golden/make_golden.py::_full_chain builds it: every tensor identical.  Needs the reference checkout (skipped on the GPU
+    box; the GPU tests additionally hold the resulting (mu, scale) to the fixtures')."""
+    import os
+    import subprocess
+    import sys
+    ref = os.environ.get("BITSWAP_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        pytest.skip("reference not present on this host")
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import make_golden as mg
+from conftest import seeded_full_model, FULL_CHAIN_SEEDS
+for data, (xs, nz, zch, rw) in {"cifar": ((3, 32, 32), 8, 8, 252), "mnist": ((1, 32, 32), 2, 1, 63)}.items():
+    torch.manual_seed(FULL_CHAIN_SEEDS[data])
+    ref = mg.RefModel(xs=xs, nz=nz, zchannels=zch, nprocessing=4, kernel_size=3, resdepth=8, reswidth=rw, root_process=False)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if n.endswith(".b") or n.endswith("gen_std"):
+                p.add_(torch.randn_like(p) * 0.3)
+            if n.endswith(".gain"):
+                p.add_(torch.randn_like(p) * 0.2)
+    g = np.load(%r + "/golden/chain_" + data + "_full_bitswap.npz")
+    ours = seeded_full_model(g, data)
+    a, b = ref.state_dict(), ours.state_dict()
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a), data
+print("same")
+""" % (os.path.join(here, "golden"), here, os.path.dirname(here), here)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("same"), out.stderr[-2000:]
