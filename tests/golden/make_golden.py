@@ -20,6 +20,9 @@ the fixtures are outputs of the reference's own classes on seeded synthetic inpu
   demo_surface.npz   tiling, demo container (.npy), pickle: outputs of the reference's own extract_blocks,
                   demo_compress.compress and demo_decompress.decompress functions (see make_surface_fixture)
   discretize_small.npz  the sampling procedure of discretize() with explicit seeds (see make_discretize_fixture)
+  chain_{mnist,cifar,imagenet}_full_*.npz   the reference's sender at the BASELINE models' REAL width (configs[0]: 100 blocks;
+                  configs[1]: 6 blocks; configs[2]/[4]: 4 blocks), compact per-op layout; the weights are not stored -- they are
+                  the seeded default init + a seeded perturbation (tests/conftest.py::seeded_full_model rebuilds them)
 
 The reference is imported unmodified; torchvision and tensorboardX (absent here) are
 stubbed exactly as SURVEY.md section 8(c) describes.
